@@ -1,0 +1,188 @@
+"""ctypes mirror of include/ddamg_hip.h (same names, argument meaning and error behaviour)."""
+import ctypes, os, re
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBNAME = os.path.join(_HERE, "libddamg_hip.so")
+_HEADER = os.path.join(os.path.dirname(_HERE), "include", "ddamg_hip.h")
+MAX_LEVELS = 4
+
+
+class DDAMGError(RuntimeError):
+    pass
+
+
+class Params(ctypes.Structure):
+    """struct ddamg_hip_params (include/ddamg_hip.h); lattices in T,Z,Y,X order."""
+    _fields_ = [
+        ("num_levels", ctypes.c_int),
+        ("local_lattice", (ctypes.c_int * 4) * MAX_LEVELS),
+        ("block_lattice", (ctypes.c_int * 4) * MAX_LEVELS),
+        ("num_vect", ctypes.c_int * MAX_LEVELS),
+        ("post_smooth_iter", ctypes.c_int * MAX_LEVELS),
+        ("block_iter", ctypes.c_int * MAX_LEVELS),
+        ("setup_iter", ctypes.c_int * MAX_LEVELS),
+        ("restart", ctypes.c_int), ("max_restart", ctypes.c_int),
+        ("tol", ctypes.c_double),
+        ("coarse_iter", ctypes.c_int), ("coarse_restart", ctypes.c_int),
+        ("coarse_tol", ctypes.c_double),
+        ("kcycle", ctypes.c_int), ("kcycle_restart", ctypes.c_int), ("kcycle_max_restart", ctypes.c_int),
+        ("kcycle_tol", ctypes.c_double),
+        ("mixed_precision", ctypes.c_int),
+        ("odd_even", ctypes.c_int),
+        ("method", ctypes.c_int),
+        ("m0", ctypes.c_double), ("csw", ctypes.c_double),
+        ("device", ctypes.c_int),
+    ]
+
+
+_lib = None
+
+
+def library_path():
+    return _LIBNAME
+
+
+def declared_symbols():
+    """every function include/ddamg_hip.h declares"""
+    txt = open(_HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(ddamg_hip_[a-z0-9_]+)\s*\(", txt)))
+
+
+def load_library():
+    """Load libddamg_hip.so; raises DDAMGError (never falls back to anything) if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIBNAME):
+        raise DDAMGError(f"{_LIBNAME} not built: run __graft_entry__.build() (hipcc --offload-arch=gfx950); "
+                         "there is no CPU fallback for the HIP path")
+    lib = ctypes.CDLL(_LIBNAME)
+    vp = ctypes.c_void_p
+    dp = ctypes.POINTER(ctypes.c_double)
+    lib.ddamg_hip_last_error.restype = ctypes.c_char_p
+    lib.ddamg_hip_default_params.argtypes = [ctypes.POINTER(Params)]
+    lib.ddamg_hip_default_params.restype = None
+    sigs = {
+        "ddamg_hip_create": [ctypes.POINTER(Params), ctypes.POINTER(vp)],
+        "ddamg_hip_destroy": [vp],
+        "ddamg_hip_set_gauge": [vp, dp, ctypes.c_int, dp],
+        "ddamg_hip_set_operator": [vp, dp, dp],
+        "ddamg_hip_get_operator": [vp, dp, dp],
+        "ddamg_hip_vec_create": [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)],
+        "ddamg_hip_vec_destroy": [vp, vp],
+        "ddamg_hip_vec_upload": [vp, vp, dp],
+        "ddamg_hip_vec_download": [vp, vp, dp],
+        "ddamg_hip_dirac_apply": [vp, vp, vp],
+        "ddamg_hip_timer_begin": [vp],
+        "ddamg_hip_timer_end": [vp, ctypes.POINTER(ctypes.c_float)],
+        "ddamg_hip_sync": [vp],
+    }
+    for name, args in sigs.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = ctypes.c_int
+    _lib = lib
+    return lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise DDAMGError(load_library().ddamg_hip_last_error().decode())
+
+
+def _dp(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def default_params():
+    p = Params()
+    load_library().ddamg_hip_default_params(ctypes.byref(p))
+    return p
+
+
+class Vector:
+    def __init__(self, ctx, level, precision):
+        self.ctx, self.level, self.precision = ctx, level, precision
+        self.ndof = ctx.ndof(level)
+        self.V = ctx.volume(level)
+        self._h = ctypes.c_void_p()
+        _check(ctx._lib.ddamg_hip_vec_create(ctx._h, level, precision, ctypes.byref(self._h)))
+
+    def upload(self, host_lex):
+        a = np.ascontiguousarray(host_lex, dtype=np.float64)
+        if a.size != self.V * self.ndof * 2:
+            raise DDAMGError(f"vector upload: expected {self.V * self.ndof * 2} reals, got {a.size}")
+        _check(self.ctx._lib.ddamg_hip_vec_upload(self.ctx._h, self._h, _dp(a)))
+        return self
+
+    def download(self):
+        out = np.empty((self.V, self.ndof, 2), dtype=np.float64)
+        _check(self.ctx._lib.ddamg_hip_vec_download(self.ctx._h, self._h, _dp(out)))
+        return out
+
+    def free(self):
+        if self._h:
+            self.ctx._lib.ddamg_hip_vec_destroy(self.ctx._h, self._h)
+            self._h = ctypes.c_void_p()
+
+
+class Context:
+    """Mirror of ddamg_hip_ctx; one per process and GPU."""
+
+    def __init__(self, params):
+        self._lib = load_library()
+        self.params = params
+        self._h = ctypes.c_void_p()
+        _check(self._lib.ddamg_hip_create(ctypes.byref(params), ctypes.byref(self._h)))
+
+    def volume(self, level=0):
+        return int(np.prod(list(self.params.local_lattice[level])))
+
+    def ndof(self, level=0):
+        return 12 if level == 0 else 2 * self.params.num_vect[level - 1]
+
+    def set_gauge(self, gauge_lex, anti_pbc=True):
+        a = np.ascontiguousarray(gauge_lex, dtype=np.float64)
+        if a.size != self.volume(0) * 72:
+            raise DDAMGError("set_gauge: gauge field must hold V*4*9 complex numbers")
+        plaq = ctypes.c_double(0)
+        _check(self._lib.ddamg_hip_set_gauge(self._h, _dp(a), int(bool(anti_pbc)), ctypes.byref(plaq)))
+        return plaq.value
+
+    def set_operator(self, D_lex, clover_lex):
+        D = np.ascontiguousarray(D_lex, dtype=np.float64)
+        cl = np.ascontiguousarray(clover_lex, dtype=np.float64)
+        V = self.volume(0)
+        if D.size != V * 72 or cl.size != V * 84:
+            raise DDAMGError("set_operator: D must be [V][36] complex and clover [V][42] complex")
+        _check(self._lib.ddamg_hip_set_operator(self._h, _dp(D), _dp(cl)))
+
+    def get_operator(self):
+        V = self.volume(0)
+        D = np.empty((V, 36, 2)); cl = np.empty((V, 42, 2))
+        _check(self._lib.ddamg_hip_get_operator(self._h, _dp(D), _dp(cl)))
+        return D, cl
+
+    def vector(self, level=0, precision=32):
+        return Vector(self, level, precision)
+
+    def dirac_apply(self, out, inp):
+        _check(self._lib.ddamg_hip_dirac_apply(self._h, out._h, inp._h))
+
+    def timer_begin(self):
+        _check(self._lib.ddamg_hip_timer_begin(self._h))
+
+    def timer_end(self):
+        ms = ctypes.c_float(0)
+        _check(self._lib.ddamg_hip_timer_end(self._h, ctypes.byref(ms)))
+        return ms.value
+
+    def sync(self):
+        _check(self._lib.ddamg_hip_sync(self._h))
+
+    def close(self):
+        if self._h:
+            self._lib.ddamg_hip_destroy(self._h)
+            self._h = ctypes.c_void_p()

@@ -1,0 +1,246 @@
+// capi.cpp -- implementation of the thin C-ABI (include/ddamg_hip.h).
+#include "context.h"
+#include "gauge.h"
+#include <cstring>
+#include <string>
+
+using namespace ddamg;
+
+static thread_local std::string g_last_error;
+
+#define DDAMG_API_BEGIN try {
+#define DDAMG_API_END                                  \
+  }                                                    \
+  catch (const std::exception& e) {                    \
+    g_last_error = e.what();                           \
+    return 1;                                          \
+  }                                                    \
+  catch (...) {                                        \
+    g_last_error = "unknown error";                    \
+    return 1;                                          \
+  }                                                    \
+  return 0;
+
+double* ddamg_hip_ctx::stage(size_t bytes) {
+  if (bytes > stage_bytes) {
+    if (d_stage) DDAMG_HIP_CHECK(hipFree(d_stage));
+    DDAMG_HIP_CHECK(hipMalloc(&d_stage, bytes));
+    stage_bytes = bytes;
+  }
+  return d_stage;
+}
+
+extern "C" {
+
+const char* ddamg_hip_last_error(void) { return g_last_error.c_str(); }
+
+void ddamg_hip_default_params(ddamg_hip_params* p) {
+  // reference defaults: src/init.c:778-812 (per level), :833-868 (general), :946-953 (k-cycle)
+  memset(p, 0, sizeof *p);
+  p->num_levels = 2;
+  for (int i = 0; i < DDAMG_HIP_MAX_LEVELS; i++) {
+    for (int mu = 0; mu < 4; mu++) { p->local_lattice[i][mu] = 0; p->block_lattice[i][mu] = 0; }
+    p->num_vect[i] = 20;
+    p->post_smooth_iter[i] = 2;
+    p->block_iter[i] = 4;
+    p->setup_iter[i] = (i == 0) ? 6 : (i == 1 ? 3 : 2);
+  }
+  p->restart = 10; p->max_restart = 100; p->tol = 1e-10;
+  p->coarse_iter = 25; p->coarse_restart = 40; p->coarse_tol = 5e-2;
+  p->kcycle = 1; p->kcycle_restart = 5; p->kcycle_max_restart = 2; p->kcycle_tol = 1e-1;
+  p->mixed_precision = 2; p->odd_even = 1; p->method = 2;
+  p->m0 = 0; p->csw = 0; p->device = 0;
+}
+
+int ddamg_hip_create(const ddamg_hip_params* p, ddamg_hip_ctx** out) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(p && out, "null argument");
+  DDAMG_REQUIRE(p->num_levels >= 1 && p->num_levels <= DDAMG_HIP_MAX_LEVELS, "1 <= num_levels <= 4");
+  int ndev = 0;
+  DDAMG_HIP_CHECK(hipGetDeviceCount(&ndev));
+  DDAMG_REQUIRE(ndev > 0, "no HIP device visible: the MI355X path has no CPU fallback");
+  DDAMG_REQUIRE(p->device >= 0 && p->device < ndev, "device ordinal out of range");
+  DDAMG_HIP_CHECK(hipSetDevice(p->device));
+  std::unique_ptr<ddamg_hip_ctx> c(new ddamg_hip_ctx);
+  c->par = *p;
+  c->device = p->device;
+  DDAMG_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  DDAMG_HIP_CHECK(hipEventCreate(&c->ev0));
+  DDAMG_HIP_CHECK(hipEventCreate(&c->ev1));
+  for (int d = 0; d < p->num_levels; d++) {
+    std::unique_ptr<Level> lv(new Level);
+    lv->depth = d;
+    lv->ndof = (d == 0) ? 12 : 2 * p->num_vect[d - 1];
+    int A[4], B[4];
+    for (int mu = 0; mu < 4; mu++) {
+      const int L = p->local_lattice[d][mu];
+      DDAMG_REQUIRE(L > 0, "local lattice extent must be positive");
+      if (d + 1 < p->num_levels) {
+        DDAMG_REQUIRE(p->local_lattice[d + 1][mu] > 0 && L % p->local_lattice[d + 1][mu] == 0,
+                      "coarse lattice must divide the finer lattice");
+        A[mu] = L / p->local_lattice[d + 1][mu];
+        B[mu] = p->block_lattice[d][mu] > 0 ? p->block_lattice[d][mu] : A[mu];
+      } else {
+        A[mu] = L;
+        B[mu] = L;  // coarsest level: one parity-ordered block (odd-even Schur complement solve)
+      }
+    }
+    if (p->num_levels == 1) for (int mu = 0; mu < 4; mu++) {
+      // single-level (pure Krylov / operator only): keep a Schwarz-friendly ordering if blocks are given
+      if (p->block_lattice[0][mu] > 0 && p->local_lattice[0][mu] % p->block_lattice[0][mu] == 0) {
+        B[mu] = p->block_lattice[0][mu];
+        A[mu] = B[mu];
+      }
+    }
+    lv->geom.build(p->local_lattice[d], B, A);
+    DDAMG_HIP_CHECK(hipMalloc(&lv->d_lex_of_site, sizeof(int) * lv->geom.V));
+    DDAMG_HIP_CHECK(hipMemcpy(lv->d_lex_of_site, lv->geom.lex_of_site.data(), sizeof(int) * lv->geom.V, hipMemcpyHostToDevice));
+    c->levels.push_back(std::move(lv));
+  }
+  *out = c.release();
+  DDAMG_API_END
+}
+
+int ddamg_hip_destroy(ddamg_hip_ctx* c) {
+  DDAMG_API_BEGIN
+  if (!c) return 0;
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  (void)hipStreamSynchronize(c->stream);
+  for (auto& lv : c->levels) if (lv->d_lex_of_site) (void)hipFree(lv->d_lex_of_site);
+  if (c->d_stage) (void)hipFree(c->d_stage);
+  (void)hipEventDestroy(c->ev0);
+  (void)hipEventDestroy(c->ev1);
+  (void)hipStreamDestroy(c->stream);
+  delete c;
+  DDAMG_API_END
+}
+
+static void upload_operator(ddamg_hip_ctx* c) {
+  const Geometry& g = c->levels[0]->geom;
+  c->fop64.upload(g, c->D_host.data(), c->clover_host.data(), c->stream);
+  c->fop32.upload(g, c->D_host.data(), c->clover_host.data(), c->stream);
+  c->have_operator = true;
+}
+
+int ddamg_hip_set_gauge(ddamg_hip_ctx* c, const double* gauge_lex, int anti_pbc, double* plaquette) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && gauge_lex, "null argument");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  const Geometry& g = c->levels[0]->geom;
+  c->D_host.resize((size_t)g.V * 72);
+  c->clover_host.resize((size_t)g.V * 84);
+  double pl = gauge_to_operator(g.L, gauge_lex, anti_pbc, c->par.m0, c->par.csw, c->D_host.data(), c->clover_host.data());
+  if (plaquette) *plaquette = pl;
+  upload_operator(c);
+  DDAMG_API_END
+}
+
+int ddamg_hip_set_operator(ddamg_hip_ctx* c, const double* D_lex, const double* clover_lex) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && D_lex && clover_lex, "null argument");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  const Geometry& g = c->levels[0]->geom;
+  c->D_host.assign(D_lex, D_lex + (size_t)g.V * 72);
+  c->clover_host.assign(clover_lex, clover_lex + (size_t)g.V * 84);
+  upload_operator(c);
+  DDAMG_API_END
+}
+
+int ddamg_hip_get_operator(ddamg_hip_ctx* c, double* D_lex, double* clover_lex) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && c->have_operator, "no operator set");
+  if (D_lex) memcpy(D_lex, c->D_host.data(), sizeof(double) * c->D_host.size());
+  if (clover_lex) memcpy(clover_lex, c->clover_host.data(), sizeof(double) * c->clover_host.size());
+  DDAMG_API_END
+}
+
+int ddamg_hip_vec_create(ddamg_hip_ctx* c, int level, int precision, ddamg_hip_vec** out) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && out, "null argument");
+  DDAMG_REQUIRE(level >= 0 && level < (int)c->levels.size(), "level out of range");
+  DDAMG_REQUIRE(precision == 32 || precision == 64, "precision must be 32 or 64");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  std::unique_ptr<ddamg_hip_vec> v(new ddamg_hip_vec);
+  v->level = level; v->precision = precision;
+  v->ndof = c->levels[level]->ndof;
+  v->V = c->levels[level]->geom.V;
+  v->bytes = (size_t)v->V * v->ndof * 2 * (precision / 8);
+  DDAMG_HIP_CHECK(hipMalloc(&v->data, v->bytes));
+  DDAMG_HIP_CHECK(hipMemsetAsync(v->data, 0, v->bytes, c->stream));
+  *out = v.release();
+  DDAMG_API_END
+}
+
+int ddamg_hip_vec_destroy(ddamg_hip_ctx* c, ddamg_hip_vec* v) {
+  DDAMG_API_BEGIN
+  if (!v) return 0;
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  (void)hipStreamSynchronize(c->stream);
+  if (v->data) (void)hipFree(v->data);
+  delete v;
+  DDAMG_API_END
+}
+
+int ddamg_hip_vec_upload(ddamg_hip_ctx* c, ddamg_hip_vec* v, const double* host_lex) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && v && host_lex, "null argument");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  size_t nb = (size_t)v->V * v->ndof * 2 * sizeof(double);
+  double* st = c->stage(nb);
+  DDAMG_HIP_CHECK(hipMemcpyAsync(st, host_lex, nb, hipMemcpyHostToDevice, c->stream));
+  const int* tab = c->levels[v->level]->d_lex_of_site;
+  if (v->precision == 32) vec_from_lex<float>((float*)v->data, st, tab, v->V, v->ndof, c->stream);
+  else vec_from_lex<double>((double*)v->data, st, tab, v->V, v->ndof, c->stream);
+  DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
+  DDAMG_API_END
+}
+
+int ddamg_hip_vec_download(ddamg_hip_ctx* c, const ddamg_hip_vec* v, double* host_lex) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && v && host_lex, "null argument");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  size_t nb = (size_t)v->V * v->ndof * 2 * sizeof(double);
+  double* st = c->stage(nb);
+  const int* tab = c->levels[v->level]->d_lex_of_site;
+  if (v->precision == 32) vec_to_lex<float>(st, (const float*)v->data, tab, v->V, v->ndof, c->stream);
+  else vec_to_lex<double>(st, (const double*)v->data, tab, v->V, v->ndof, c->stream);
+  DDAMG_HIP_CHECK(hipMemcpyAsync(host_lex, st, nb, hipMemcpyDeviceToHost, c->stream));
+  DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
+  DDAMG_API_END
+}
+
+int ddamg_hip_dirac_apply(ddamg_hip_ctx* c, ddamg_hip_vec* out, const ddamg_hip_vec* in) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && out && in, "null argument");
+  DDAMG_REQUIRE(c->have_operator, "no operator set (call ddamg_hip_set_gauge / ddamg_hip_set_operator)");
+  DDAMG_REQUIRE(out->level == 0 && in->level == 0, "fine-level vectors expected");
+  DDAMG_REQUIRE(out->precision == in->precision, "precision mismatch");
+  DDAMG_REQUIRE(out->data != in->data, "in-place apply is not supported");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  if (in->precision == 32) c->fop32.apply((float*)out->data, (const float*)in->data, c->stream);
+  else c->fop64.apply((double*)out->data, (const double*)in->data, c->stream);
+  DDAMG_API_END
+}
+
+int ddamg_hip_timer_begin(ddamg_hip_ctx* c) {
+  DDAMG_API_BEGIN
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  DDAMG_HIP_CHECK(hipEventRecord(c->ev0, c->stream));
+  DDAMG_API_END
+}
+int ddamg_hip_timer_end(ddamg_hip_ctx* c, float* ms) {
+  DDAMG_API_BEGIN
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  DDAMG_HIP_CHECK(hipEventRecord(c->ev1, c->stream));
+  DDAMG_HIP_CHECK(hipEventSynchronize(c->ev1));
+  DDAMG_HIP_CHECK(hipEventElapsedTime(ms, c->ev0, c->ev1));
+  DDAMG_API_END
+}
+int ddamg_hip_sync(ddamg_hip_ctx* c) {
+  DDAMG_API_BEGIN
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
+  DDAMG_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,102 @@
+// common.h -- shared host/device helpers for the MI355X (gfx950) DDalphaAMG hot path.
+//
+// Data layout (all levels, both precisions): "chunked SoA".  A field with NR reals per site is
+// stored as NR/CH full chunks of CH reals (CH*sizeof(T) == 16 bytes: float4 / double2) plus an
+// optional narrower tail; chunk k of site s lives at  base + (k*V + s)*CH , so the 64 lanes of a
+// wavefront working on 64 consecutive sites issue one fully coalesced 1 KiB (16 B/lane) load
+// per chunk.  Sites are ordered aggregate -> Schwarz block -> parity -> lexicographic
+// (geometry.h), so one Schwarz block is a contiguous run of sites in every chunk row.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+
+#define DDAMG_HIP_CHECK(expr)                                                                  \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess) {                                                                    \
+      char _buf[512];                                                                          \
+      snprintf(_buf, sizeof _buf, "HIP error %s at %s:%d: %s", hipGetErrorName(_e), __FILE__,  \
+               __LINE__, hipGetErrorString(_e));                                               \
+      throw std::runtime_error(_buf);                                                          \
+    }                                                                                          \
+  } while (0)
+
+#define DDAMG_REQUIRE(cond, msg)                                                               \
+  do {                                                                                         \
+    if (!(cond)) {                                                                             \
+      char _buf[512];                                                                          \
+      snprintf(_buf, sizeof _buf, "ddamg: requirement failed (%s) at %s:%d: %s", #cond,        \
+               __FILE__, __LINE__, msg);                                                       \
+      throw std::runtime_error(_buf);                                                          \
+    }                                                                                          \
+  } while (0)
+
+namespace ddamg {
+
+enum { DIR_T = 0, DIR_Z = 1, DIR_Y = 2, DIR_X = 3 };  // reference src/clifford.h:33
+
+template <typename T> struct Chunk;
+template <> struct Chunk<float> { static constexpr int CH = 4; using vec = float4; using half = float2; };
+template <> struct Chunk<double> { static constexpr int CH = 2; using vec = double2; using half = double; };
+
+// number of T elements a field with NR reals per site occupies for V sites
+template <typename T> __host__ __device__ inline size_t field_elems(int NR, size_t V) { return (size_t)NR * V; }
+
+#ifdef __HIPCC__
+// ---- chunked-SoA per-site load / store of NR reals --------------------------------------
+template <typename T, int NR>
+__device__ __forceinline__ void load_site(const T* __restrict__ base, size_t V, size_t s, T (&out)[NR]) {
+  constexpr int CH = Chunk<T>::CH;
+  constexpr int NF = NR / CH;
+  using vec = typename Chunk<T>::vec;
+#pragma unroll
+  for (int k = 0; k < NF; k++) {
+    vec v = *reinterpret_cast<const vec*>(base + ((size_t)k * V + s) * CH);
+    if constexpr (CH == 4) { out[4 * k] = v.x; out[4 * k + 1] = v.y; out[4 * k + 2] = v.z; out[4 * k + 3] = v.w; }
+    else { out[2 * k] = v.x; out[2 * k + 1] = v.y; }
+  }
+  constexpr int TL = NR % CH;
+  if constexpr (TL == 2) {  // only float (CH==4) can have a 2-wide tail
+    float2 v = *reinterpret_cast<const float2*>(base + (size_t)NF * V * CH + s * 2);
+    out[NF * CH] = v.x; out[NF * CH + 1] = v.y;
+  } else {
+    static_assert(TL == 0, "unsupported tail width");
+  }
+}
+
+template <typename T, int NR>
+__device__ __forceinline__ void store_site(T* __restrict__ base, size_t V, size_t s, const T (&in)[NR]) {
+  constexpr int CH = Chunk<T>::CH;
+  constexpr int NF = NR / CH;
+  using vec = typename Chunk<T>::vec;
+#pragma unroll
+  for (int k = 0; k < NF; k++) {
+    vec v;
+    if constexpr (CH == 4) { v.x = in[4 * k]; v.y = in[4 * k + 1]; v.z = in[4 * k + 2]; v.w = in[4 * k + 3]; }
+    else { v.x = in[2 * k]; v.y = in[2 * k + 1]; }
+    *reinterpret_cast<vec*>(base + ((size_t)k * V + s) * CH) = v;
+  }
+  constexpr int TL = NR % CH;
+  if constexpr (TL == 2) {
+    float2 v; v.x = in[NF * CH]; v.y = in[NF * CH + 1];
+    *reinterpret_cast<float2*>(base + (size_t)NF * V * CH + s * 2) = v;
+  } else {
+    static_assert(TL == 0, "unsupported tail width");
+  }
+}
+#endif  // __HIPCC__
+
+// host-side index of real r of site s in a chunked-SoA field with NR reals/site
+template <typename T> inline size_t soa_index(int NR, size_t V, size_t s, int r) {
+  constexpr int CH = Chunk<T>::CH;
+  int NF = NR / CH;
+  if (r < NF * CH) return ((size_t)(r / CH) * V + s) * CH + (r % CH);
+  int TL = NR % CH;
+  return (size_t)NF * V * CH + s * TL + (r - NF * CH);
+}
+
+}  // namespace ddamg

@@ -1,0 +1,47 @@
+// context.h -- solver context behind the C-ABI (include/ddamg_hip.h).
+// Reference counterpart: global_struct g + level_struct l (src/main.h:263-390).
+#pragma once
+#include "common.h"
+#include "geometry.h"
+#include "fine_op.h"
+#include "../../include/ddamg_hip.h"
+#include <vector>
+#include <memory>
+
+struct ddamg_hip_vec {
+  int level = 0;
+  int precision = 32;
+  int ndof = 12;
+  int V = 0;
+  void* data = nullptr;
+  size_t bytes = 0;
+};
+
+namespace ddamg {
+
+struct Level {
+  int depth = 0;
+  int ndof = 12;  // complex dof per site
+  Geometry geom;
+  int* d_lex_of_site = nullptr;
+};
+
+}  // namespace ddamg
+
+struct ddamg_hip_ctx {
+  ddamg_hip_params par;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  std::vector<std::unique_ptr<ddamg::Level>> levels;
+  // fine operator in the reference's host storage (fp64) + device copies in both precisions
+  std::vector<double> D_host, clover_host;
+  bool have_operator = false;
+  ddamg::FineOp<float> fop32;
+  ddamg::FineOp<double> fop64;
+  // staging buffer for host<->device vector transfers (lexicographic fp64)
+  double* d_stage = nullptr;
+  size_t stage_bytes = 0;
+
+  double* stage(size_t bytes);
+};

@@ -1,0 +1,58 @@
+// fine_op.h -- the fine-level Wilson-Clover operator on the device (level 0).
+// Reference counterpart: operator_PRECISION_struct {D, clover, neighbor_table} of depth 0
+// (src/main_pre_def_generic.h:47-60) and d_plus_clover_PRECISION (src/dirac_generic.c:159-277).
+//
+// Device storage per site (T = float or double), chunked SoA (common.h):
+//   D      : 4 directions x 18 reals  (row-major 3x3 complex, holds U/2 as the reference does,
+//            src/dirac.c:80); direction mu starts at  D + mu*18*V
+//   clover : 72 reals = two Hermitian 6x6 blocks, each 6 real diagonal entries followed by the
+//            15 complex strict-upper entries in row-major order (the reference keeps 42 complex,
+//            src/dirac.c:386-398; the diagonal is real so its imaginary parts are not stored)
+//   nb     : 8 x V int32 neighbour sites (+T,+Z,+Y,+X,-T,-Z,-Y,-X)
+#pragma once
+#include "common.h"
+#include "geometry.h"
+
+namespace ddamg {
+
+template <typename T>
+struct FineOpDev {
+  const T* D;
+  const T* clover;
+  const T* clover_inv;  // explicit inverse of both 6x6 blocks (same packing), for odd-even SAP
+  const int* nb;
+  int V;
+};
+
+template <typename T>
+class FineOp {
+ public:
+  FineOp() = default;
+  ~FineOp();
+  FineOp(const FineOp&) = delete;
+  FineOp& operator=(const FineOp&) = delete;
+
+  // D_ref: [V][4][9] complex (lexicographic sites), clover_ref: [V][42] complex, both fp64 as the
+  // reference holds them in g.op_double (src/dirac.c:60-168)
+  void upload(const Geometry& g, const double* D_ref, const double* clover_ref, hipStream_t st);
+  void apply(T* eta, const T* phi, hipStream_t st) const;  // eta = D_W phi
+  FineOpDev<T> dev() const { return FineOpDev<T>{D_, clover_, clover_inv_, nb_, V_}; }
+  int V() const { return V_; }
+
+ private:
+  T* D_ = nullptr;
+  T* clover_ = nullptr;
+  T* clover_inv_ = nullptr;
+  int* nb_ = nullptr;
+  int V_ = 0;
+};
+
+// layout converters between the reference's lexicographic AoS fp64 vectors
+// ([V][ndof] complex, src/main_pre_def_generic.h:25-27) and device chunked-SoA vectors.
+// `lex_of_site` is a device table.  ndof = complex dof per site.
+template <typename T>
+void vec_from_lex(T* dst, const double* src_lex_dev, const int* lex_of_site, int V, int ndof, hipStream_t st);
+template <typename T>
+void vec_to_lex(double* dst_lex_dev, const T* src, const int* lex_of_site, int V, int ndof, hipStream_t st);
+
+}  // namespace ddamg

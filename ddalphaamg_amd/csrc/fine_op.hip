@@ -1,0 +1,196 @@
+// fine_op.hip -- fine Wilson-Clover apply (gather form, one site per lane) + layout converters.
+// Reference: d_plus_clover_PRECISION src/dirac_generic.c:159-277 (six passes + 8 half-spinor
+// scratch fields there; one fused pass here), trans/trans_back src/schwarz_generic.c:1807-1846.
+#include "fine_op.h"
+#include "dirac_device.h"
+#include <vector>
+#include <complex>
+#include <cstring>
+
+namespace ddamg {
+
+template <typename T, int MU>
+__device__ __forceinline__ void hop_pair(const T* __restrict__ phi, const FineOpDev<T>& op, size_t s, T (&eta)[24]) {
+  const size_t V = op.V;
+  {
+    int j = op.nb[(size_t)MU * V + s];
+    T pn[24], U[18];
+    load_site<T, 24>(phi, V, j, pn);
+    load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, s, U);
+    hop_accumulate<T, MU, true>(U, pn, eta);
+  }
+  {
+    int j = op.nb[(size_t)(4 + MU) * V + s];
+    T pn[24], U[18];
+    load_site<T, 24>(phi, V, j, pn);
+    load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, j, U);
+    hop_accumulate<T, MU, false>(U, pn, eta);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : 3)) void dirac_apply_kernel(T* __restrict__ eta, const T* __restrict__ phi, FineOpDev<T> op) {
+  const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+  const size_t V = op.V;
+  if (s >= V) return;
+  T e[24];
+  {
+    T p[24], cl[36];
+    load_site<T, 24>(phi, V, s, p);
+    load_site<T, 36>(op.clover, V, s, cl);
+    herm6_mul<T>(cl, p, e);
+    load_site<T, 36>(op.clover + (size_t)36 * V, V, s, cl);
+    herm6_mul<T>(cl, p + 12, e + 12);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  hop_pair<T, 0>(phi, op, s, e);
+  __builtin_amdgcn_sched_barrier(0);
+  hop_pair<T, 1>(phi, op, s, e);
+  __builtin_amdgcn_sched_barrier(0);
+  hop_pair<T, 2>(phi, op, s, e);
+  __builtin_amdgcn_sched_barrier(0);
+  hop_pair<T, 3>(phi, op, s, e);
+  __builtin_amdgcn_sched_barrier(0);
+  store_site<T, 24>(eta, V, s, e);
+}
+
+template <typename T>
+void FineOp<T>::apply(T* eta, const T* phi, hipStream_t st) const {
+  DDAMG_REQUIRE(D_ != nullptr, "fine operator not uploaded");
+  int grid = (V_ + 255) / 256;
+  hipLaunchKernelGGL(dirac_apply_kernel<T>, dim3(grid), dim3(256), 0, st, eta, phi, dev());
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+FineOp<T>::~FineOp() {
+  if (D_) (void)hipFree(D_);
+  if (clover_) (void)hipFree(clover_);
+  if (clover_inv_) (void)hipFree(clover_inv_);
+  if (nb_) (void)hipFree(nb_);
+}
+
+// inverse of a Hermitian positive definite-ish 6x6 matrix (Gauss-Jordan with partial pivoting)
+static void invert6(std::complex<double> a[6][6], std::complex<double> inv[6][6]) {
+  std::complex<double> m[6][12];
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) { m[i][j] = a[i][j]; m[i][6 + j] = (i == j) ? 1.0 : 0.0; }
+  for (int c = 0; c < 6; c++) {
+    int p = c;
+    for (int r = c + 1; r < 6; r++) if (std::abs(m[r][c]) > std::abs(m[p][c])) p = r;
+    if (p != c) for (int j = 0; j < 12; j++) std::swap(m[c][j], m[p][j]);
+    std::complex<double> d = 1.0 / m[c][c];
+    for (int j = 0; j < 12; j++) m[c][j] *= d;
+    for (int r = 0; r < 6; r++) if (r != c) {
+      std::complex<double> f = m[r][c];
+      if (f != 0.0) for (int j = 0; j < 12; j++) m[r][j] -= f * m[c][j];
+    }
+  }
+  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) inv[i][j] = m[i][6 + j];
+}
+
+template <typename T>
+void FineOp<T>::upload(const Geometry& g, const double* D_ref, const double* clover_ref, hipStream_t st) {
+  const size_t V = g.V;
+  V_ = g.V;
+  std::vector<T> hD(72 * V), hC(72 * V), hI(72 * V);
+  for (size_t s = 0; s < V; s++) {
+    const size_t lx = g.lex_of_site[s];
+    for (int mu = 0; mu < 4; mu++)
+      for (int r = 0; r < 18; r++)
+        hD[(size_t)mu * 18 * V + soa_index<T>(18, V, s, r)] = (T)D_ref[(lx * 36 + mu * 9) * 2 + r];
+    const double* c = clover_ref + lx * 42 * 2;
+    for (int b = 0; b < 2; b++) {
+      std::complex<double> a[6][6], inv[6][6];
+      for (int i = 0; i < 6; i++) a[i][i] = c[2 * (6 * b + i)];
+      int k = 12 + 15 * b;
+      for (int i = 0; i < 6; i++)
+        for (int j = i + 1; j < 6; j++, k++) {
+          a[i][j] = std::complex<double>(c[2 * k], c[2 * k + 1]);
+          a[j][i] = std::conj(a[i][j]);
+        }
+      invert6(a, inv);
+      int r = 36 * b;
+      for (int i = 0; i < 6; i++) {
+        hC[soa_index<T>(72, V, s, r + i)] = (T)a[i][i].real();
+        hI[soa_index<T>(72, V, s, r + i)] = (T)inv[i][i].real();
+      }
+      r += 6;
+      for (int i = 0; i < 6; i++)
+        for (int j = i + 1; j < 6; j++) {
+          hC[soa_index<T>(72, V, s, r)] = (T)a[i][j].real();
+          hC[soa_index<T>(72, V, s, r + 1)] = (T)a[i][j].imag();
+          hI[soa_index<T>(72, V, s, r)] = (T)inv[i][j].real();
+          hI[soa_index<T>(72, V, s, r + 1)] = (T)inv[i][j].imag();
+          r += 2;
+        }
+    }
+  }
+  if (!D_) {
+    DDAMG_HIP_CHECK(hipMalloc(&D_, sizeof(T) * 72 * V));
+    DDAMG_HIP_CHECK(hipMalloc(&clover_, sizeof(T) * 72 * V));
+    DDAMG_HIP_CHECK(hipMalloc(&clover_inv_, sizeof(T) * 72 * V));
+    DDAMG_HIP_CHECK(hipMalloc(&nb_, sizeof(int) * 8 * V));
+  }
+  DDAMG_HIP_CHECK(hipMemcpyAsync(D_, hD.data(), sizeof(T) * 72 * V, hipMemcpyHostToDevice, st));
+  DDAMG_HIP_CHECK(hipMemcpyAsync(clover_, hC.data(), sizeof(T) * 72 * V, hipMemcpyHostToDevice, st));
+  DDAMG_HIP_CHECK(hipMemcpyAsync(clover_inv_, hI.data(), sizeof(T) * 72 * V, hipMemcpyHostToDevice, st));
+  DDAMG_HIP_CHECK(hipMemcpyAsync(nb_, g.nb.data(), sizeof(int) * 8 * V, hipMemcpyHostToDevice, st));
+  DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+}
+
+// ---- layout converters ---------------------------------------------------------------------
+template <typename T>
+__global__ void vec_from_lex_kernel(T* __restrict__ dst, const double* __restrict__ src, const int* __restrict__ lex_of_site, int V, int nreal) {
+  // one thread per (site, real): coalesced on the SoA side
+  constexpr int CH = Chunk<T>::CH;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)V * nreal;
+  if (i >= total) return;
+  // SoA linear index i -> (chunk k, site s, lane-in-chunk c)
+  size_t k = i / ((size_t)V * CH);
+  size_t rem = i - k * (size_t)V * CH;
+  size_t s = rem / CH;
+  int c = rem % CH;
+  int r = (int)k * CH + c;
+  dst[i] = (T)src[(size_t)lex_of_site[s] * nreal + r];
+}
+template <typename T>
+__global__ void vec_to_lex_kernel(double* __restrict__ dst, const T* __restrict__ src, const int* __restrict__ lex_of_site, int V, int nreal) {
+  constexpr int CH = Chunk<T>::CH;
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  size_t total = (size_t)V * nreal;
+  if (i >= total) return;
+  size_t k = i / ((size_t)V * CH);
+  size_t rem = i - k * (size_t)V * CH;
+  size_t s = rem / CH;
+  int c = rem % CH;
+  int r = (int)k * CH + c;
+  dst[(size_t)lex_of_site[s] * nreal + r] = (double)src[i];
+}
+
+template <typename T>
+void vec_from_lex(T* dst, const double* src, const int* lex_of_site, int V, int ndof, hipStream_t st) {
+  int nreal = 2 * ndof;
+  DDAMG_REQUIRE(nreal % Chunk<T>::CH == 0, "dof per site must fill whole 16-byte chunks");
+  size_t total = (size_t)V * nreal;
+  hipLaunchKernelGGL(vec_from_lex_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, st, dst, src, lex_of_site, V, nreal);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+template <typename T>
+void vec_to_lex(double* dst, const T* src, const int* lex_of_site, int V, int ndof, hipStream_t st) {
+  int nreal = 2 * ndof;
+  DDAMG_REQUIRE(nreal % Chunk<T>::CH == 0, "dof per site must fill whole 16-byte chunks");
+  size_t total = (size_t)V * nreal;
+  hipLaunchKernelGGL(vec_to_lex_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, st, dst, src, lex_of_site, V, nreal);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
+template class FineOp<float>;
+template class FineOp<double>;
+template void vec_from_lex<float>(float*, const double*, const int*, int, int, hipStream_t);
+template void vec_from_lex<double>(double*, const double*, const int*, int, int, hipStream_t);
+template void vec_to_lex<float>(double*, const float*, const int*, int, int, hipStream_t);
+template void vec_to_lex<double>(double*, const double*, const int*, int, int, hipStream_t);
+
+}  // namespace ddamg

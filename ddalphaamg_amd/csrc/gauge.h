@@ -1,0 +1,9 @@
+// gauge.h -- see gauge.cpp
+#pragma once
+namespace ddamg {
+// gauge_in: [V][4][9] complex fp64 lexicographic (T,Z,Y,X; X fastest).  Writes D_out [V][36] complex
+// (= U/2, after the optional anti-periodic sign) and clover_out [V][42] complex in the reference's
+// storage; returns the average plaquette in [0,3].
+double gauge_to_operator(const int L[4], const double* gauge_in, int anti_pbc, double m0, double csw,
+                         double* D_out, double* clover_out);
+}

@@ -1,0 +1,116 @@
+// geometry.cpp -- see geometry.h
+#include "geometry.h"
+#include "common.h"
+
+namespace ddamg {
+
+void Geometry::build(const int L_[4], const int B_[4], const int A_[4]) {
+  V = 1; block_sites = 1; agg_sites = 1; num_blocks = 1; num_aggs = 1;
+  for (int mu = 0; mu < 4; mu++) {
+    L[mu] = L_[mu]; B[mu] = B_[mu]; A[mu] = A_[mu];
+    P[mu] = 1; pc[mu] = 0;
+    DDAMG_REQUIRE(L[mu] > 0 && B[mu] > 0 && A[mu] > 0, "lattice extents must be positive");
+    DDAMG_REQUIRE(L[mu] % A[mu] == 0, "aggregate lattice must divide the local lattice");
+    DDAMG_REQUIRE(A[mu] % B[mu] == 0, "Schwarz block lattice must divide the aggregate lattice");
+    nblk[mu] = L[mu] / B[mu];
+    nagg[mu] = L[mu] / A[mu];
+    V *= L[mu]; block_sites *= B[mu]; agg_sites *= A[mu];
+    num_blocks *= nblk[mu]; num_aggs *= nagg[mu];
+  }
+  oe_offset = 0;
+  site_of_lex.assign(V, -1);
+  lex_of_site.assign(V, -1);
+  coord.assign((size_t)V * 4, 0);
+  parity.assign(V, 0);
+  block_color.assign(num_blocks, 0);
+  block_list.assign(num_blocks, 0);
+
+  // enumerate: aggregates -> blocks in aggregate -> parity -> lexicographic in block
+  int bpa[4];  // blocks per aggregate per direction
+  for (int mu = 0; mu < 4; mu++) bpa[mu] = A[mu] / B[mu];
+  int s = 0, blk = 0;
+  int a[4], b[4], r[4], c[4];
+  for (a[0] = 0; a[0] < nagg[0]; a[0]++) for (a[1] = 0; a[1] < nagg[1]; a[1]++)
+  for (a[2] = 0; a[2] < nagg[2]; a[2]++) for (a[3] = 0; a[3] < nagg[3]; a[3]++)
+    for (b[0] = 0; b[0] < bpa[0]; b[0]++) for (b[1] = 0; b[1] < bpa[1]; b[1]++)
+    for (b[2] = 0; b[2] < bpa[2]; b[2]++) for (b[3] = 0; b[3] < bpa[3]; b[3]++) {
+      int gb[4], minus = 0, plus = 0, inner = 0, csum = 0;
+      for (int mu = 0; mu < 4; mu++) {
+        gb[mu] = a[mu] * bpa[mu] + b[mu];
+        csum += gb[mu];
+        if (gb[mu] == 0) minus++;
+        if (gb[mu] + 1 == nblk[mu]) plus++;
+        if (gb[mu] != 0 && gb[mu] + 1 != nblk[mu]) inner++;
+      }
+      int col = csum & 1;
+      block_color[blk] = col;
+      // the reference's 8 red-black lists: per colour {inner, one-sided, two-sided, other one-sided}
+      int list;
+      if (inner == 4) list = 4 * col;
+      else if (minus == 0) list = col == 0 ? 1 : 7;
+      else if (plus == 0) list = col == 0 ? 3 : 5;
+      else list = 2 + 4 * col;
+      block_list[blk] = list;
+      for (int par = 0; par < 2; par++)
+        for (r[0] = 0; r[0] < B[0]; r[0]++) for (r[1] = 0; r[1] < B[1]; r[1]++)
+        for (r[2] = 0; r[2] < B[2]; r[2]++) for (r[3] = 0; r[3] < B[3]; r[3]++) {
+          if (((r[0] + r[1] + r[2] + r[3]) & 1) != par) continue;
+          for (int mu = 0; mu < 4; mu++) c[mu] = gb[mu] * B[mu] + r[mu];
+          int lx = lex(c);
+          site_of_lex[lx] = s;
+          lex_of_site[s] = lx;
+          for (int mu = 0; mu < 4; mu++) coord[(size_t)s * 4 + mu] = c[mu];
+          parity[s] = (c[0] + c[1] + c[2] + c[3] + oe_offset) & 1;
+          s++;
+        }
+      blk++;
+    }
+  DDAMG_REQUIRE(s == V && blk == num_blocks, "site enumeration is inconsistent");
+
+  // neighbour tables (periodic wrap inside the local volume: single process per direction)
+  nb.assign((size_t)8 * V, -1);
+  for (int st = 0; st < V; st++) {
+    for (int mu = 0; mu < 4; mu++) {
+      int cc[4] = {coord[(size_t)st * 4], coord[(size_t)st * 4 + 1], coord[(size_t)st * 4 + 2], coord[(size_t)st * 4 + 3]};
+      cc[mu] = (coord[(size_t)st * 4 + mu] + 1) % L[mu];
+      nb[(size_t)mu * V + st] = site_of_lex[lex(cc)];
+      cc[mu] = (coord[(size_t)st * 4 + mu] - 1 + L[mu]) % L[mu];
+      nb[(size_t)(4 + mu) * V + st] = site_of_lex[lex(cc)];
+    }
+  }
+
+  // block-local neighbour table (same for every block): index inside the block or -1
+  blk_nb.assign((size_t)8 * block_sites, -1);
+  block_even_sites = 0;
+  {
+    std::vector<int> local_of_lex(block_sites, -1);
+    std::vector<std::array<int, 4>> rc(block_sites);
+    int i = 0;
+    for (int par = 0; par < 2; par++) {
+      for (r[0] = 0; r[0] < B[0]; r[0]++) for (r[1] = 0; r[1] < B[1]; r[1]++)
+      for (r[2] = 0; r[2] < B[2]; r[2]++) for (r[3] = 0; r[3] < B[3]; r[3]++) {
+        if (((r[0] + r[1] + r[2] + r[3]) & 1) != par) continue;
+        int lb = ((r[0] * B[1] + r[1]) * B[2] + r[2]) * B[3] + r[3];
+        local_of_lex[lb] = i;
+        rc[i] = {r[0], r[1], r[2], r[3]};
+        i++;
+      }
+      if (par == 0) block_even_sites = i;
+    }
+    for (i = 0; i < block_sites; i++)
+      for (int mu = 0; mu < 4; mu++) {
+        auto q = rc[i];
+        if (q[mu] + 1 < B[mu]) {
+          q[mu]++;
+          blk_nb[(size_t)mu * block_sites + i] = local_of_lex[((q[0] * B[1] + q[1]) * B[2] + q[2]) * B[3] + q[3]];
+        }
+        q = rc[i];
+        if (q[mu] - 1 >= 0) {
+          q[mu]--;
+          blk_nb[(size_t)(4 + mu) * block_sites + i] = local_of_lex[((q[0] * B[1] + q[1]) * B[2] + q[2]) * B[3] + q[3]];
+        }
+      }
+  }
+}
+
+}  // namespace ddamg

@@ -1,0 +1,41 @@
+// geometry.h -- host-side lattice geometry of one multigrid level (built once, uploaded).
+//
+// Plays the role of the reference's index tables (src/data_layout.c:152-251 define_nt_bt_tt,
+// src/schwarz_generic.c:312-645 schwarz_layout_PRECISION_define, src/coarsening_generic.c:114-165)
+// but with ONE site ordering per level that serves the stencil, the Schwarz smoother and the
+// aggregation at the same time:
+//     site = aggregate (lexicographic) -> Schwarz block inside the aggregate (lexicographic)
+//            -> block-local parity (even sites first) -> lexicographic inside the block.
+// Direction order is T,Z,Y,X with X fastest (reference src/clifford.h:33, src/data_layout.h:30-32).
+#pragma once
+#include <vector>
+#include <array>
+
+namespace ddamg {
+
+struct Geometry {
+  int L[4];   // local lattice
+  int B[4];   // Schwarz block lattice
+  int A[4];   // aggregate (coarsening) lattice; == L on the coarsest level
+  int P[4];   // process grid (1,1,1,1 on a single GPU)
+  int pc[4];  // my process coordinates
+  int V = 0, block_sites = 0, num_blocks = 0, agg_sites = 0, num_aggs = 0;
+  int nblk[4];  // blocks per direction in the local lattice
+  int nagg[4];  // aggregates per direction in the local lattice
+  int oe_offset = 0;  // parity of the rank origin (reference src/data_layout.c:47-49)
+
+  std::vector<int> site_of_lex;  // [V] lexicographic -> site
+  std::vector<int> lex_of_site;  // [V]
+  std::vector<int> coord;        // [V*4] local coordinates of a site
+  std::vector<int> parity;       // [V] global parity (t+z+y+x+oe_offset)&1 : 0 even, 1 odd
+  std::vector<int> nb;           // [8*V] neighbour site: dir 0..3 = +T,+Z,+Y,+X ; 4..7 = -T,-Z,-Y,-X
+  std::vector<int> blk_nb;       // [8*block_sites] in-block neighbour (block-local index) or -1
+  std::vector<int> block_color;  // [num_blocks] red-black colour (src/schwarz_generic.c:383-395)
+  std::vector<int> block_list;   // [num_blocks] 0..7: red-black list of the reference (:415-428)
+  int block_even_sites = 0;      // number of block-local even sites (first in the block)
+
+  void build(const int L_[4], const int B_[4], const int A_[4]);
+  int lex(const int c[4]) const { return ((c[0] * L[1] + c[1]) * L[2] + c[2]) * L[3] + c[3]; }
+};
+
+}  // namespace ddamg

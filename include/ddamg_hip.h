@@ -1,0 +1,94 @@
+/*
+ * ddamg_hip.h -- thin C-ABI of the MI355X (gfx950) implementation of the DDalphaAMG V-cycle hot path.
+ *
+ * This is the drop-in boundary *below* the reference's library interface (include/dd_alpha_amg.h):
+ * plain pointers and sizes, no C++ / torch types.  Every entry point names the reference
+ * interface it replaces (paths relative to the reference tree, mrottmann/DDalphaAMG).
+ *
+ * Conventions
+ *  - directions / lattice extents are ordered T,Z,Y,X (reference src/clifford.h:33), X fastest;
+ *  - host vectors are the reference's outer layout: lexicographic sites, `ndof` interleaved
+ *    (re,im) double complex numbers per site (src/main_pre_def_generic.h:25-27,
+ *    src/data_layout.h:30-32); ndof = 12 on the fine level, 2*num_vect on coarse levels;
+ *  - every function returns 0 on success and a non-zero code on failure; the message is
+ *    available from ddamg_hip_last_error().  (The reference aborts through error0/MPI_Abort,
+ *    src/main.h:424-439; the dd_alpha_amg_* facade keeps that behaviour on top of these codes.)
+ *  - one context per process and GPU; all work is enqueued on the context's HIP stream.
+ */
+#ifndef DDAMG_HIP_H
+#define DDAMG_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DDAMG_HIP_MAX_LEVELS 4
+
+typedef struct ddamg_hip_ctx ddamg_hip_ctx;
+typedef struct ddamg_hip_vec ddamg_hip_vec;
+
+/* Mirrors the parameters the reference reads from its .ini / dd_alpha_amg_parameters
+ * (src/init.c:778-953, src/dd_alpha_amg_parameters.h:26-51).  Lattices in T,Z,Y,X order. */
+typedef struct ddamg_hip_params {
+  int num_levels;
+  int local_lattice[DDAMG_HIP_MAX_LEVELS][4];
+  int block_lattice[DDAMG_HIP_MAX_LEVELS][4];
+  int num_vect[DDAMG_HIP_MAX_LEVELS];          /* "test vectors" per level                    */
+  int post_smooth_iter[DDAMG_HIP_MAX_LEVELS];  /* Schwarz cycles per V-cycle                  */
+  int block_iter[DDAMG_HIP_MAX_LEVELS];        /* MinRes steps per block solve                */
+  int setup_iter[DDAMG_HIP_MAX_LEVELS];
+  int restart, max_restart;                    /* outer FGMRES                                */
+  double tol;
+  int coarse_iter, coarse_restart;             /* coarsest-level GMRES                        */
+  double coarse_tol;
+  int kcycle, kcycle_restart, kcycle_max_restart;
+  double kcycle_tol;
+  int mixed_precision;                         /* 0: fp64 everywhere, 1: fp32 V-cycle / fp64 FGMRES, 2: fgmres_MP */
+  int odd_even;
+  int method;                                  /* 0 pure GMRES, 2 FGMRES + red-black SAP      */
+  double m0, csw;
+  int device;                                  /* HIP device ordinal                          */
+} ddamg_hip_params;
+
+const char* ddamg_hip_last_error(void);
+
+/* fills the reference's defaults (src/init.c:833-868,946-953) */
+void ddamg_hip_default_params(ddamg_hip_params* p);
+
+/* replaces method_init + operator_double_alloc/define (src/init.c:376-421) */
+int ddamg_hip_create(const ddamg_hip_params* p, ddamg_hip_ctx** ctx);
+/* replaces method_free + method_finalize (src/init.c:285-323,424-445) */
+int ddamg_hip_destroy(ddamg_hip_ctx* ctx);
+
+/* replaces dirac_setup (src/dirac.c:60-168): gauge links U [V][4][3x3 row-major complex] fp64,
+ * lexicographic.  D = U/2, clover term from the four plaquette leaves, average plaquette returned.
+ * anti_pbc != 0 negates the T-links of the last time slice first, as read_conf does
+ * (src/io.c:536-541). */
+int ddamg_hip_set_gauge(ddamg_hip_ctx* ctx, const double* gauge_lex, int anti_pbc, double* plaquette);
+
+/* direct upload of an operator in the reference's own storage (g.op_double.D: [V][36] complex,
+ * g.op_double.clover: [V][42] complex; src/dirac.c:80,386-398) -- the path behind
+ * dd_alpha_amg_get_gauge_pointer / dd_alpha_amg_get_clover_pointer (src/dirac.c:171-176). */
+int ddamg_hip_set_operator(ddamg_hip_ctx* ctx, const double* D_lex, const double* clover_lex);
+/* read back the fp64 operator in the reference's storage (for parity tests) */
+int ddamg_hip_get_operator(ddamg_hip_ctx* ctx, double* D_lex, double* clover_lex);
+
+/* device vectors; precision is 32 or 64 */
+int ddamg_hip_vec_create(ddamg_hip_ctx* ctx, int level, int precision, ddamg_hip_vec** v);
+int ddamg_hip_vec_destroy(ddamg_hip_ctx* ctx, ddamg_hip_vec* v);
+/* replaces trans_PRECISION / trans_back_PRECISION (src/schwarz_generic.c:1807-1846) */
+int ddamg_hip_vec_upload(ddamg_hip_ctx* ctx, ddamg_hip_vec* v, const double* host_lex);
+int ddamg_hip_vec_download(ddamg_hip_ctx* ctx, const ddamg_hip_vec* v, double* host_lex);
+
+/* replaces d_plus_clover_float / d_plus_clover_double (src/dirac_generic.c:159-277) */
+int ddamg_hip_dirac_apply(ddamg_hip_ctx* ctx, ddamg_hip_vec* out, const ddamg_hip_vec* in);
+
+/* HIP-event timing on the context stream (bench.py's live roofline measurement) */
+int ddamg_hip_timer_begin(ddamg_hip_ctx* ctx);
+int ddamg_hip_timer_end(ddamg_hip_ctx* ctx, float* milliseconds);
+int ddamg_hip_sync(ddamg_hip_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DDAMG_HIP_H */

@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""oracle/make_golden.py -- TEST INFRASTRUCTURE ONLY.
+
+Generates the committed golden fixtures tests/golden/*.npz by running the REAL reference
+(oracle/_ref/ref_dump, built by `make -C oracle ref` from /root/reference) on the reference's own
+sample gauge configurations.  Runs only in the build container (needs /root/reference); the
+fixtures themselves are pure data (inputs + expected outputs) and travel with the repo.
+
+usage: python oracle/make_golden.py [case ...]      cases: 4x4 8x8_dirac
+"""
+import os, subprocess, sys, tempfile, shutil
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = os.environ.get("DDAMG_REFERENCE", "/root/reference")
+GOLD = os.path.join(REPO, "tests", "golden")
+
+INI_COMMON = """configuration: {conf}
+format: 0
+right hand side: 0
+antiperiodic boundary conditions: 1
+number of levels: {levels}
+number of openmp threads: 1
+d0 global lattice: {L}
+d0 local lattice: {L}
+d0 block lattice: {B}
+d0 post smooth iter: 2
+d0 block iter: 4
+d0 test vectors: {nvec}
+d0 setup iter: {setup}
+{extra}
+m0: -0.5
+csw: 1.0
+tolerance for relative residual: 1E-10
+iterations between restarts: 50
+maximum of restarts: 20
+coarse grid tolerance: 5E-2
+coarse grid iterations: 100
+coarse grid restarts: 5
+print mode: 1
+method: {method}
+mixed precision: {mp}
+randomize test vectors: 0
+"""
+
+CASES = {
+    # BASELINE.md explicit 2-level 4^4 case (11 iterations, 2.44e-11)
+    "4x4": dict(conf="conf/4x4x4x4b6.0000id3n1", levels=2, L="4 4 4 4", B="2 2 2 2", nvec=20, setup=4,
+                extra="", method=2, mp=1),
+    # 8^4 fine operator only (BASELINE config 2): 2-level hierarchy is built but only stage 1 is kept
+    "8x8_dirac": dict(conf="conf/8x8x8x8b6.0000id3n1", levels=2, L="8 8 8 8", B="4 4 4 4", nvec=4, setup=0,
+                      extra="d1 global lattice: 2 2 2 2", method=2, mp=1, keep=["meta_int", "meta_f64", "dirac_in",
+                      "dirac_out_f64", "dirac_out_f32_as_f64", "clover_sample", "gauge", "conf_dims", "conf_plaq"]),
+}
+
+def run_case(name):
+    cfg = dict(CASES[name])
+    keep = cfg.pop("keep", None)
+    cfg["conf"] = os.path.join(REF, cfg["conf"])
+    tmp = tempfile.mkdtemp(prefix="ddamg_gold_")
+    try:
+        ini = os.path.join(tmp, "case.ini")
+        open(ini, "w").write(INI_COMMON.format(**cfg))
+        log = subprocess.run([os.path.join(HERE, "_ref", "ref_dump"), ini, tmp], capture_output=True, text=True)
+        if log.returncode != 0:
+            sys.stderr.write(log.stdout[-3000:] + log.stderr[-3000:])
+            raise SystemExit("ref_dump failed")
+        arrays = {}
+        for line in open(os.path.join(tmp, "manifest.txt")):
+            nm, dt, shape = line.split()
+            shape = tuple(int(x) for x in shape.split(","))
+            a = np.fromfile(os.path.join(tmp, nm + ".bin"), dtype=np.dtype("<" + dt)).reshape(shape)
+            arrays[nm] = a
+        if keep is not None:
+            if "clover" in arrays:  # a few sites of the reference clover term, to pin set_gauge at 8^4
+                arrays["clover_sample"] = arrays["clover"][::97].copy()
+                arrays["D_sample"] = arrays["D"][::97].copy()
+                keep = keep + ["D_sample"]
+            keep_now = keep
+        # the gauge configuration itself (input data of the reference's own sample runs):
+        # 4 x int32 (T,Z,Y,X) + double plaquette header, then [t][z][y][x][mu][3x3] complex doubles
+        # (reference src/io.c:489-520)
+        raw = open(cfg["conf"], "rb").read()
+        dims = np.frombuffer(raw[:16], dtype="<i4")
+        arrays["conf_dims"] = dims.copy()
+        arrays["conf_plaq"] = np.frombuffer(raw[16:24], dtype="<f8").copy()
+        arrays["gauge"] = np.frombuffer(raw[24:], dtype="<f8").reshape(int(np.prod(dims)), 4, 9, 2).copy()
+        # the text log holds the reference's residual history / iteration count
+        hist = [float(l.split(":")[1].split("|")[0]) for l in log.stdout.splitlines() if "approx. rel. res. after" in l]
+        arrays["ref_log_residual_history"] = np.array(hist)
+        if keep is not None:
+            arrays = {k: v for k, v in arrays.items() if k in keep_now or k.startswith("ref_log")}
+        os.makedirs(GOLD, exist_ok=True)
+        out = os.path.join(GOLD, f"ref_{name}.npz")
+        np.savez_compressed(out, **arrays)
+        print(f"{out}: {os.path.getsize(out)/1e3:.0f} kB, arrays: {sorted(arrays)}")
+    finally:
+        shutil.rmtree(tmp)
+
+if __name__ == "__main__":
+    for c in (sys.argv[1:] or list(CASES)):
+        run_case(c)

@@ -1,0 +1,41 @@
+"""CPU tests: the C-ABI library builds/loads and exports every symbol include/*.h declares
+(no compute calls without a GPU)."""
+import ctypes, os
+import pytest
+import ddalphaamg_amd as dd
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(dd.library_path()):
+        import __graft_entry__
+        __graft_entry__.build()
+    lib = ctypes.CDLL(dd.library_path())
+    syms = dd.declared_symbols()
+    assert len(syms) >= 10
+    missing = [s for s in syms if not hasattr(lib, s)]
+    assert not missing, f"symbols declared in include/ddamg_hip.h but not exported: {missing}"
+
+
+def test_default_params_match_reference_defaults():
+    from ddalphaamg_amd import api
+    p = api.default_params()
+    # reference src/init.c:833-868, 946-953
+    assert (p.mixed_precision, p.method, p.odd_even) == (2, 2, 1)
+    assert (p.restart, p.max_restart, p.tol) == (10, 100, 1e-10)
+    assert (p.coarse_iter, p.coarse_restart, p.coarse_tol) == (25, 40, 5e-2)
+    assert (p.kcycle, p.kcycle_restart, p.kcycle_max_restart, p.kcycle_tol) == (1, 5, 2, 1e-1)
+    assert list(p.setup_iter)[:3] == [6, 3, 2] and p.num_vect[0] == 20
+
+
+def test_create_without_gpu_fails_loudly():
+    """no silent CPU fallback: without a HIP device the context cannot be created"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from ddalphaamg_amd import api
+    p = api.default_params()
+    p.num_levels = 1
+    for mu in range(4):
+        p.local_lattice[0][mu] = 4
+    with pytest.raises(dd.DDAMGError):
+        dd.Context(p)
