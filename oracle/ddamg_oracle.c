@@ -144,6 +144,7 @@ void orc_dirac_apply_f32(const int L[4], const double *D, const double *clover, 
 
 double orc_dirac_time_f32(const int L[4], const double *D, const double *clover, const double *phi, int reps, int *threads)
 {
+  if (threads && *threads > 0) omp_set_num_threads(*threads);
   const size_t V = (size_t)L[0] * L[1] * L[2] * L[3];
   float *Df = to_float(D, V * 72), *cf = to_float(clover, V * 84), *pf = to_float(phi, V * 24), *ef = malloc(sizeof(float) * V * 24);
   dirac_apply_core_f32(L, (const float complex *)Df, (const float complex *)cf, (const float complex *)pf, (float complex *)ef);

@@ -51,8 +51,17 @@ def dirac_apply(L, D, clover, phi, precision=64):
     f(_L(L), _dp(D), _dp(clover), _dp(phi), _dp(eta))
     return eta
 
-def dirac_time_f32(L, D, clover, phi, reps):
-    nt = ctypes.c_int(0)
+def host_threads():
+    """threads to use on this box: its CPU share (16 per GPU on the pool), never the raw core count"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
+def dirac_time_f32(L, D, clover, phi, reps, threads=None):
+    nt = ctypes.c_int(threads or host_threads())
     D = np.ascontiguousarray(D, dtype=np.float64); clover = np.ascontiguousarray(clover, dtype=np.float64)
     phi = np.ascontiguousarray(phi, dtype=np.float64)
     t = lib().orc_dirac_time_f32(_L(L), _dp(D), _dp(clover), _dp(phi), int(reps), ctypes.byref(nt))
