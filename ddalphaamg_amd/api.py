@@ -75,6 +75,21 @@ def load_library():
         "ddamg_hip_vec_upload": [vp, vp, dp],
         "ddamg_hip_vec_download": [vp, vp, dp],
         "ddamg_hip_dirac_apply": [vp, vp, vp],
+        "ddamg_hip_setup": [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
+        "ddamg_hip_setup_update": [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
+        "ddamg_hip_set_test_vectors": [vp, dp, ctypes.c_int],
+        "ddamg_hip_get_interpolation": [vp, dp],
+        "ddamg_hip_get_coarse_operator": [vp, dp, dp],
+        "ddamg_hip_set_coarse_operator": [vp, dp, dp],
+        "ddamg_hip_smoother": [vp, vp, vp, ctypes.c_int, ctypes.c_int],
+        "ddamg_hip_restrict": [vp, vp, vp],
+        "ddamg_hip_interpolate": [vp, vp, vp, ctypes.c_int],
+        "ddamg_hip_coarse_apply": [vp, vp, vp],
+        "ddamg_hip_coarse_solve": [vp, vp, vp, ctypes.POINTER(ctypes.c_int)],
+        "ddamg_hip_vcycle": [vp, vp, vp],
+        "ddamg_hip_solve": [vp, dp, dp, ctypes.c_double, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), dp],
+        "ddamg_hip_residual_history": [vp, dp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
+        "ddamg_hip_get_site_order": [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
         "ddamg_hip_timer_begin": [vp],
         "ddamg_hip_timer_end": [vp, ctypes.POINTER(ctypes.c_float)],
         "ddamg_hip_sync": [vp],
@@ -170,6 +185,85 @@ class Context:
 
     def dirac_apply(self, out, inp):
         _check(self._lib.ddamg_hip_dirac_apply(self._h, out._h, inp._h))
+
+    # ---- multigrid ----
+    def vprec(self):
+        return 64 if self.params.mixed_precision == 0 else 32
+
+    def setup(self, setup_iterations=-1):
+        ci = ctypes.c_int(0)
+        _check(self._lib.ddamg_hip_setup(self._h, int(setup_iterations), ctypes.byref(ci)))
+        return ci.value
+
+    def setup_update(self, iterations):
+        ci = ctypes.c_int(0)
+        _check(self._lib.ddamg_hip_setup_update(self._h, int(iterations), ctypes.byref(ci)))
+        return ci.value
+
+    def set_test_vectors(self, tv_lex, orthonormalised=False):
+        a = np.ascontiguousarray(tv_lex, dtype=np.float64)
+        if a.size != self.params.num_vect[0] * self.volume(0) * 24:
+            raise DDAMGError("set_test_vectors: expected [num_vect][V][12] complex numbers")
+        _check(self._lib.ddamg_hip_set_test_vectors(self._h, _dp(a), int(bool(orthonormalised))))
+
+    def get_interpolation(self):
+        out = np.empty((self.params.num_vect[0], self.volume(0), 12, 2))
+        _check(self._lib.ddamg_hip_get_interpolation(self._h, _dp(out)))
+        return out
+
+    def get_coarse_operator(self):
+        n = self.ndof(1); Vc = self.volume(1)
+        D = np.empty((Vc, 4, n * n, 2)); cl = np.empty((Vc, n * (n + 1) // 2, 2))
+        _check(self._lib.ddamg_hip_get_coarse_operator(self._h, _dp(D), _dp(cl)))
+        return D, cl
+
+    def set_coarse_operator(self, D, cl):
+        n = self.ndof(1); Vc = self.volume(1)
+        D = np.ascontiguousarray(D, dtype=np.float64); cl = np.ascontiguousarray(cl, dtype=np.float64)
+        if D.size != Vc * 4 * n * n * 2 or cl.size != Vc * n * (n + 1):
+            raise DDAMGError("set_coarse_operator: wrong array sizes")
+        _check(self._lib.ddamg_hip_set_coarse_operator(self._h, _dp(D), _dp(cl)))
+
+    def smoother(self, phi, eta, cycles, initial_guess_zero=True):
+        _check(self._lib.ddamg_hip_smoother(self._h, phi._h, eta._h, int(cycles), int(bool(initial_guess_zero))))
+
+    def restrict(self, coarse, fine):
+        _check(self._lib.ddamg_hip_restrict(self._h, coarse._h, fine._h))
+
+    def interpolate(self, fine, coarse, add=False):
+        _check(self._lib.ddamg_hip_interpolate(self._h, fine._h, coarse._h, int(bool(add))))
+
+    def coarse_apply(self, out, inp):
+        _check(self._lib.ddamg_hip_coarse_apply(self._h, out._h, inp._h))
+
+    def coarse_solve(self, x, b):
+        it = ctypes.c_int(0)
+        _check(self._lib.ddamg_hip_coarse_solve(self._h, x._h, b._h, ctypes.byref(it)))
+        return it.value
+
+    def vcycle(self, phi, eta):
+        _check(self._lib.ddamg_hip_vcycle(self._h, phi._h, eta._h))
+
+    def solve(self, b_lex, tol=0.0):
+        """returns (x_lex, iterations, coarse_iterations, true relative residual)"""
+        b = np.ascontiguousarray(b_lex, dtype=np.float64)
+        if b.size != self.volume(0) * 24:
+            raise DDAMGError("solve: right-hand side must hold V*12 complex numbers")
+        x = np.empty((self.volume(0), 12, 2))
+        it = ctypes.c_int(0); ci = ctypes.c_int(0); rr = ctypes.c_double(0)
+        _check(self._lib.ddamg_hip_solve(self._h, _dp(x), _dp(b), float(tol), ctypes.byref(it), ctypes.byref(ci), ctypes.byref(rr)))
+        return x, it.value, ci.value, rr.value
+
+    def residual_history(self):
+        n = ctypes.c_int(0)
+        buf = np.empty(4096)
+        _check(self._lib.ddamg_hip_residual_history(self._h, _dp(buf), 4096, ctypes.byref(n)))
+        return buf[:n.value].copy()
+
+    def site_order(self, level=0):
+        out = np.empty(self.volume(level), dtype=np.int32)
+        _check(self._lib.ddamg_hip_get_site_order(self._h, level, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+        return out
 
     def timer_begin(self):
         _check(self._lib.ddamg_hip_timer_begin(self._h))

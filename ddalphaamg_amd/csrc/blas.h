@@ -1,0 +1,64 @@
+// blas.h -- BLAS-1 and reductions on device vectors.
+// Reference counterpart: src/linalg_generic.c:29-353 (global_norm, global_inner_product,
+// process_multi_inner_product, vector_PRECISION_{saxpy,multi_saxpy,scale,real_scale,plus,minus,copy}),
+// src/linalg.c:25-111 (the fp64-accumulating mixed-precision variants) and
+// vector_PRECISION_define (src/data_generic.c:25-39).
+//
+// A "view" addresses a site range of a chunked-SoA vector: `rows` chunk rows of `len` reals each,
+// row r starting at  off + r*stride.  A whole vector is the single row {1, 0, 0, n}.
+// Consecutive (even,odd) reals of a row are the (re,im) parts of one complex number.
+// All reductions accumulate in fp64 and are deterministic (two-stage, no atomics).
+#pragma once
+#include "common.h"
+
+namespace ddamg {
+
+struct View {
+  int rows;
+  size_t stride, off, len;  // in reals
+  __host__ __device__ size_t total() const { return (size_t)rows * len; }
+};
+inline View whole(size_t n) { return View{1, 0, 0, n}; }
+// sites [s0,s1) of a vector with V sites and nreal reals/site in chunked-SoA layout
+template <typename T>
+inline View site_range(int nreal, size_t V, size_t s0, size_t s1) {
+  constexpr int CH = Chunk<T>::CH;
+  if (s0 == 0 && s1 == V) return whole((size_t)nreal * V);
+  return View{nreal / CH, V * CH, s0 * CH, (s1 - s0) * CH};
+}
+
+// workspace for reductions (per stream user); holds per-block partials and the device/host result slots
+struct ReduceWork {
+  double* d_partial = nullptr;  // [max_blocks][2*max_m]
+  double* d_result = nullptr;   // [2*max_m + 2]
+  double* h_result = nullptr;   // pinned mirror
+  double* d_coef = nullptr;     // [2*max_m] coefficients uploaded from the host
+  double* h_coef = nullptr;     // pinned
+  int max_m = 0, max_blocks = 0;
+  void init(int max_m_);
+  void destroy();
+};
+
+template <typename T> void vec_zero(T* x, View v, hipStream_t st);
+template <typename T> void vec_copy(T* y, const T* x, View v, hipStream_t st);
+// precision conversion between the float and double chunked-SoA layouts (V sites, nreal reals/site)
+template <typename TO, typename TI> void vec_convert(TO* y, const TI* x, size_t V, int nreal, hipStream_t st);
+// z = x + a*y  (a complex, by value)
+template <typename T> void vec_axpy(T* z, const T* x, const T* y, double are, double aim, View v, hipStream_t st);
+// z = a*x  (a complex, by value)
+template <typename T> void vec_scale(T* z, const T* x, double are, double aim, View v, hipStream_t st);
+// z = x / d_scalar[0]  (real scalar in device memory; no-op copy if |scalar| <= 1e-15, cf. linsolve_generic.c:889)
+template <typename T> void vec_scale_inv_dev(T* z, const T* x, const double* d_scalar, View v, hipStream_t st);
+// z = x - y
+template <typename T> void vec_minus(T* z, const T* x, const T* y, View v, hipStream_t st);
+template <typename T> void vec_plus(T* z, const T* x, const T* y, View v, hipStream_t st);
+// w += sign * sum_{i<m} coef[i] * (X + i*xstride)   coefficients complex fp64 in device memory
+template <typename T> void vec_multi_axpy_dev(T* w, const T* X, size_t xstride, int m, const double* d_coef, double sign, View v, hipStream_t st);
+// d_out[2i..2i+1] = < X+i*xstride , w >  for i<m  (conjugate-linear in the first argument)
+template <typename T> void vec_multi_dot(const T* X, size_t xstride, int m, const T* w, View v, ReduceWork& rw, double* d_out, hipStream_t st);
+// d_out[0] = ||x||_2
+template <typename T> void vec_norm(const T* x, View v, ReduceWork& rw, double* d_out, hipStream_t st);
+// fused pair used by MinRes-type updates:  d_out[0..1] = <x,y>, d_out[2] = <x,x>
+template <typename T> void vec_dot_and_norm2(const T* x, const T* y, View v, ReduceWork& rw, double* d_out, hipStream_t st);
+
+}  // namespace ddamg

@@ -6,7 +6,8 @@
 
 using namespace ddamg;
 
-static thread_local std::string g_last_error;
+thread_local std::string g_ddamg_last_error;
+#define g_last_error g_ddamg_last_error
 
 #define DDAMG_API_BEGIN try {
 #define DDAMG_API_END                                  \
@@ -97,6 +98,7 @@ int ddamg_hip_create(const ddamg_hip_params* p, ddamg_hip_ctx** out) {
     DDAMG_HIP_CHECK(hipMemcpy(lv->d_lex_of_site, lv->geom.lex_of_site.data(), sizeof(int) * lv->geom.V, hipMemcpyHostToDevice));
     c->levels.push_back(std::move(lv));
   }
+  srand(0);  // reference: srand( 1000*g.my_rank ) unless "randomize test vectors" (src/init.c:870-873)
   *out = c.release();
   DDAMG_API_END
 }
@@ -106,6 +108,10 @@ int ddamg_hip_destroy(ddamg_hip_ctx* c) {
   if (!c) return 0;
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
   (void)hipStreamSynchronize(c->stream);
+  c->mg32.reset(); c->mg64.reset();
+  if (c->outer_ready) { c->outer.release(); c->rw_outer.destroy(); }
+  if (c->p32_in) (void)hipFree(c->p32_in);
+  if (c->p32_out) (void)hipFree(c->p32_out);
   for (auto& lv : c->levels) if (lv->d_lex_of_site) (void)hipFree(lv->d_lex_of_site);
   if (c->d_stage) (void)hipFree(c->d_stage);
   (void)hipEventDestroy(c->ev0);
@@ -120,6 +126,8 @@ static void upload_operator(ddamg_hip_ctx* c) {
   c->fop64.upload(g, c->D_host.data(), c->clover_host.data(), c->stream);
   c->fop32.upload(g, c->D_host.data(), c->clover_host.data(), c->stream);
   c->have_operator = true;
+  if (c->mg32 && c->setup_done) c->mg32->operator_changed();
+  if (c->mg64 && c->setup_done) c->mg64->operator_changed();
 }
 
 int ddamg_hip_set_gauge(ddamg_hip_ctx* c, const double* gauge_lex, int anti_pbc, double* plaquette) {
@@ -164,6 +172,7 @@ int ddamg_hip_vec_create(ddamg_hip_ctx* c, int level, int precision, ddamg_hip_v
   v->level = level; v->precision = precision;
   v->ndof = c->levels[level]->ndof;
   v->V = c->levels[level]->geom.V;
+  v->aos = level > 0 ? 1 : 0;
   v->bytes = (size_t)v->V * v->ndof * 2 * (precision / 8);
   DDAMG_HIP_CHECK(hipMalloc(&v->data, v->bytes));
   DDAMG_HIP_CHECK(hipMemsetAsync(v->data, 0, v->bytes, c->stream));
@@ -189,8 +198,13 @@ int ddamg_hip_vec_upload(ddamg_hip_ctx* c, ddamg_hip_vec* v, const double* host_
   double* st = c->stage(nb);
   DDAMG_HIP_CHECK(hipMemcpyAsync(st, host_lex, nb, hipMemcpyHostToDevice, c->stream));
   const int* tab = c->levels[v->level]->d_lex_of_site;
-  if (v->precision == 32) vec_from_lex<float>((float*)v->data, st, tab, v->V, v->ndof, c->stream);
-  else vec_from_lex<double>((double*)v->data, st, tab, v->V, v->ndof, c->stream);
+  if (v->aos) {
+    if (v->precision == 32) aos_from_lex<float>((float*)v->data, st, tab, v->V, v->ndof, c->stream);
+    else aos_from_lex<double>((double*)v->data, st, tab, v->V, v->ndof, c->stream);
+  } else {
+    if (v->precision == 32) vec_from_lex<float>((float*)v->data, st, tab, v->V, v->ndof, c->stream);
+    else vec_from_lex<double>((double*)v->data, st, tab, v->V, v->ndof, c->stream);
+  }
   DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
   DDAMG_API_END
 }
@@ -202,8 +216,13 @@ int ddamg_hip_vec_download(ddamg_hip_ctx* c, const ddamg_hip_vec* v, double* hos
   size_t nb = (size_t)v->V * v->ndof * 2 * sizeof(double);
   double* st = c->stage(nb);
   const int* tab = c->levels[v->level]->d_lex_of_site;
-  if (v->precision == 32) vec_to_lex<float>(st, (const float*)v->data, tab, v->V, v->ndof, c->stream);
-  else vec_to_lex<double>(st, (const double*)v->data, tab, v->V, v->ndof, c->stream);
+  if (v->aos) {
+    if (v->precision == 32) aos_to_lex<float>(st, (const float*)v->data, tab, v->V, v->ndof, c->stream);
+    else aos_to_lex<double>(st, (const double*)v->data, tab, v->V, v->ndof, c->stream);
+  } else {
+    if (v->precision == 32) vec_to_lex<float>(st, (const float*)v->data, tab, v->V, v->ndof, c->stream);
+    else vec_to_lex<double>(st, (const double*)v->data, tab, v->V, v->ndof, c->stream);
+  }
   DDAMG_HIP_CHECK(hipMemcpyAsync(host_lex, st, nb, hipMemcpyDeviceToHost, c->stream));
   DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
   DDAMG_API_END
@@ -219,6 +238,15 @@ int ddamg_hip_dirac_apply(ddamg_hip_ctx* c, ddamg_hip_vec* out, const ddamg_hip_
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
   if (in->precision == 32) c->fop32.apply((float*)out->data, (const float*)in->data, c->stream);
   else c->fop64.apply((double*)out->data, (const double*)in->data, c->stream);
+  DDAMG_API_END
+}
+
+int ddamg_hip_get_site_order(ddamg_hip_ctx* c, int level, int* lex_of_site) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && lex_of_site, "null argument");
+  DDAMG_REQUIRE(level >= 0 && level < (int)c->levels.size(), "level out of range");
+  const Geometry& g = c->levels[level]->geom;
+  for (int s = 0; s < g.V; s++) lex_of_site[s] = g.lex_of_site[s];
   DDAMG_API_END
 }
 

@@ -1,0 +1,67 @@
+// coarse_op.h -- coarse-grid operator (dense n x n complex couplings per site and link, n = 2*Nvec).
+// Reference: apply_coarse_operator_PRECISION src/coarse_operator_generic.c:383-394,
+//   coarse_self_couplings :288-315, coarse_hopp / coarse_daggered_hopp src/coarse_operator_generic.h:119-172,
+//   coarse_hopping_term / coarse_n_hopping_term src/coarse_oddeven_generic.c:447-729,
+//   coarse_diag_ee / coarse_diag_oo_inv :123-198, coarse_apply_schur_complement :1162-1189,
+//   coarse_solve_odd_even :1139-1159.
+//
+// Storage (device): per site five dense matrices  M[0] = self coupling [A B; -B^H D],
+// M[1+mu] = forward link U_mu(x) = [A B; C D];  the backward coupling is derived on the fly as
+// G5 U_mu(x-mu)^H G5 with G5 = diag(+1_N, -1_N) (the reference's [A^H -C^H; -B^H D^H] rule), so only
+// forward links are stored, as in the reference's scalar path.  The odd-even solver additionally
+// keeps the explicit inverse of the self coupling (the reference keeps an LU factorisation).
+// Each matrix is padded to np = 8*ceil(n/8) and stored in 8x8-lane tiles: element (i,j),
+// i = a+8p, j = b+8q lives at complex offset (p*nt+q)*64 + a*8+b, so the 64 lanes of a wavefront
+// read one tile as 512 contiguous bytes and both M*v and M^H*v are computed from the same load
+// with three wavefront shuffles per output.  Vectors on coarse levels are site-major (AoS).
+#pragma once
+#include "common.h"
+#include "geometry.h"
+#include <vector>
+
+namespace ddamg {
+
+template <typename T>
+struct CoarseOpDev {
+  const T* M;      // [V][5][msize] complex
+  const T* Minv;   // [V][msize] complex (self-coupling inverse)
+  const int* nb;   // [8][V]
+  int V, n, nt;    // sites, dof per site, tiles per matrix dimension
+  size_t msize;    // complex numbers per stored matrix = nt*nt*64
+};
+
+template <typename T>
+class CoarseOp {
+ public:
+  ~CoarseOp();
+  void alloc(const Geometry& g, int n);
+  // import from the reference's storage (lexicographic coarse sites):
+  //   D_ref [V][4][n*n] complex: blocks A,C,B,D each (n/2)^2 column-major (src/coarse_operator_generic.h:124-143)
+  //   clover_ref [V][n(n+1)/2] complex: triu(A), triu(D) packed column-major, then B full column-major (src/coarse_operator_generic.c:109-111)
+  void import_reference(const Geometry& g, const double* D_ref, const double* clover_ref, hipStream_t st);
+  void export_reference(const Geometry& g, double* D_ref, double* clover_ref, hipStream_t st) const;
+  void compute_self_inverse(hipStream_t st);  // Minv = M[0]^-1 on every site
+  CoarseOpDev<T> dev() const { return CoarseOpDev<T>{M_, Minv_, nb_, V_, n_, nt_, msize_}; }
+  int V() const { return V_; }
+  int n() const { return n_; }
+  T* matrices() { return M_; }
+  size_t msize() const { return msize_; }
+  int nt() const { return nt_; }
+
+  // out = D_c in on all sites
+  void apply(T* out, const T* in, hipStream_t st) const;
+  // out[s0,s1) (+)= sign * sum over the 8 neighbours of the hopping terms of `in`
+  //   accumulate=false: out = sign*H(in) ; accumulate=true: out += sign*H(in)
+  void hop(T* out, const T* in, int s0, int s1, double sign, bool accumulate, hipStream_t st) const;
+  // out[s0,s1) = M0 in   or   M0^-1 in
+  void self_mul(T* out, const T* in, int s0, int s1, bool inverse, hipStream_t st) const;
+
+ private:
+  T* M_ = nullptr;
+  T* Minv_ = nullptr;
+  int* nb_ = nullptr;
+  int V_ = 0, n_ = 0, nt_ = 0;
+  size_t msize_ = 0;
+};
+
+}  // namespace ddamg

@@ -1,0 +1,304 @@
+// coarse_op.hip -- see coarse_op.h.  One workgroup per output site, one wavefront per dense
+// n x n product (self coupling, 4 forward links, 4 backward links); every product streams its
+// matrix exactly once in 512-byte tiles: the kernel is bound by the HBM read of the couplings.
+#include "coarse_op.h"
+#include <complex>
+
+namespace ddamg {
+
+enum { MODE_FULL = 0, MODE_HOP = 1, MODE_SELF = 2, MODE_SELFINV = 3 };
+
+template <typename T> struct C2;
+template <> struct C2<float> { using t = float2; };
+template <> struct C2<double> { using t = double2; };
+
+// one wavefront: res[0..np) = M * v   (DAG=false)   or   G5 M^H G5 v   (DAG=true)
+template <typename T, int NT, bool DAG>
+__device__ __forceinline__ void wave_mv(const T* __restrict__ Mbase, const T* __restrict__ v, int n, T* __restrict__ res) {
+  using c2 = typename C2<T>::t;
+  const int l = threadIdx.x & 63, a = l >> 3, b = l & 7;
+  const int half = n >> 1;
+  T xr[NT], xi[NT];  // input entries this lane needs
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const int k = (DAG ? a : b) + 8 * t;
+    if (k < n) {
+      c2 z = *reinterpret_cast<const c2*>(v + 2 * k);
+      const T sg = (DAG && k >= half) ? (T)-1 : (T)1;
+      xr[t] = sg * z.x; xi[t] = sg * z.y;
+    } else { xr[t] = 0; xi[t] = 0; }
+  }
+  T ar[NT], ai[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) { ar[t] = 0; ai[t] = 0; }
+  const c2* M = reinterpret_cast<const c2*>(Mbase) + l;
+#pragma unroll
+  for (int p = 0; p < NT; p++)
+#pragma unroll
+    for (int q = 0; q < NT; q++) {
+      const c2 m = M[(p * NT + q) * 64];
+      if constexpr (!DAG) {  // y_i += M_ij v_j   (i <-> p, j <-> q)
+        ar[p] += m.x * xr[q] - m.y * xi[q];
+        ai[p] += m.x * xi[q] + m.y * xr[q];
+      } else {               // z_j += conj(M_ij) w_i
+        ar[q] += m.x * xr[p] + m.y * xi[p];
+        ai[q] += m.x * xi[p] - m.y * xr[p];
+      }
+    }
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    if constexpr (!DAG) {
+#pragma unroll
+      for (int o = 1; o < 8; o <<= 1) { ar[t] += __shfl_xor(ar[t], o, 64); ai[t] += __shfl_xor(ai[t], o, 64); }
+      if (b == 0) { res[2 * (a + 8 * t)] = ar[t]; res[2 * (a + 8 * t) + 1] = ai[t]; }
+    } else {
+#pragma unroll
+      for (int o = 8; o < 64; o <<= 1) { ar[t] += __shfl_xor(ar[t], o, 64); ai[t] += __shfl_xor(ai[t], o, 64); }
+      if (a == 0) {
+        const int k = b + 8 * t;
+        const T sg = (k >= half) ? (T)-1 : (T)1;
+        res[2 * k] = sg * ar[t]; res[2 * k + 1] = sg * ai[t];
+      }
+    }
+  }
+}
+
+template <typename T, int NT>
+__global__ void coarse_site_kernel(T* __restrict__ out, const T* __restrict__ in, CoarseOpDev<T> op, int s0, int mode,
+                                   T sign_self, T sign_hop, int accumulate) {
+  __shared__ T res[9 * 2 * 8 * NT];
+  const int x = s0 + blockIdx.x;
+  const int w = threadIdx.x >> 6;
+  const int n = op.n, np = 8 * NT;
+  const size_t V = op.V;
+  T* r = res + (size_t)w * 2 * np;
+  int prod = w;                       // MODE_FULL: 0 self, 1..4 fwd, 5..8 bwd
+  if (mode == MODE_HOP) prod = w + 1; // 1..4 fwd, 5..8 bwd
+  const T* Mx = op.M + (size_t)x * 5 * op.msize * 2;
+  if (mode == MODE_SELF || (mode == MODE_FULL && prod == 0)) {
+    wave_mv<T, NT, false>(Mx, in + (size_t)x * n * 2, n, r);
+  } else if (mode == MODE_SELFINV) {
+    wave_mv<T, NT, false>(op.Minv + (size_t)x * op.msize * 2, in + (size_t)x * n * 2, n, r);
+  } else if (prod <= 4) {
+    const int mu = prod - 1;
+    const int y = op.nb[(size_t)mu * V + x];
+    wave_mv<T, NT, false>(Mx + (size_t)(1 + mu) * op.msize * 2, in + (size_t)y * n * 2, n, r);
+  } else {
+    const int mu = prod - 5;
+    const int y = op.nb[(size_t)(4 + mu) * V + x];
+    wave_mv<T, NT, true>(op.M + ((size_t)y * 5 + 1 + mu) * op.msize * 2, in + (size_t)y * n * 2, n, r);
+  }
+  __syncthreads();
+  const int nwaves = blockDim.x >> 6;
+  for (int k = threadIdx.x; k < 2 * n; k += blockDim.x) {
+    T v = accumulate ? out[(size_t)x * n * 2 + k] : (T)0;
+    if (mode == MODE_FULL) {
+      v += sign_self * res[k];
+      for (int ww = 1; ww < nwaves; ww++) v += sign_hop * res[(size_t)ww * 2 * np + k];
+    } else if (mode == MODE_HOP) {
+      T s = 0;
+      for (int ww = 0; ww < nwaves; ww++) s += res[(size_t)ww * 2 * np + k];
+      v += sign_hop * s;
+    } else {
+      v += sign_self * res[k];
+    }
+    out[(size_t)x * n * 2 + k] = v;
+  }
+}
+
+template <typename T>
+static void launch_site(const CoarseOpDev<T>& op, T* out, const T* in, int s0, int s1, int mode, double ss, double sh, bool acc, hipStream_t st) {
+  if (s1 <= s0) return;
+  const int waves = mode == MODE_FULL ? 9 : (mode == MODE_HOP ? 8 : 1);
+  dim3 grid(s1 - s0), block(64 * waves);
+#define DDAMG_CASE(NTV) case NTV: hipLaunchKernelGGL((coarse_site_kernel<T, NTV>), grid, block, 0, st, out, in, op, s0, mode, (T)ss, (T)sh, acc ? 1 : 0); break;
+  switch (op.nt) {
+    DDAMG_CASE(1) DDAMG_CASE(2) DDAMG_CASE(3) DDAMG_CASE(4) DDAMG_CASE(5) DDAMG_CASE(6) DDAMG_CASE(7) DDAMG_CASE(8)
+    default: DDAMG_REQUIRE(false, "coarse operator: more than 64 dof per site are not supported");
+  }
+#undef DDAMG_CASE
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T> void CoarseOp<T>::apply(T* out, const T* in, hipStream_t st) const {
+  DDAMG_REQUIRE(out != in, "coarse apply cannot run in place");
+  launch_site<T>(dev(), out, in, 0, V_, MODE_FULL, 1.0, -1.0, false, st);
+}
+template <typename T> void CoarseOp<T>::hop(T* out, const T* in, int s0, int s1, double sign, bool accumulate, hipStream_t st) const {
+  DDAMG_REQUIRE(out != in, "coarse hopping term cannot run in place");
+  launch_site<T>(dev(), out, in, s0, s1, MODE_HOP, 0.0, sign, accumulate, st);
+}
+template <typename T> void CoarseOp<T>::self_mul(T* out, const T* in, int s0, int s1, bool inverse, hipStream_t st) const {
+  DDAMG_REQUIRE(out != in, "coarse self coupling cannot run in place");
+  launch_site<T>(dev(), out, in, s0, s1, inverse ? MODE_SELFINV : MODE_SELF, 1.0, 0.0, false, st);
+}
+
+// ---- batched in-place Gauss-Jordan inverse of the self couplings (fp64 in LDS) ------------------
+template <typename T>
+__global__ void invert_self_kernel(T* __restrict__ Minv, const T* __restrict__ M, int n, int nt, size_t msize) {
+  extern __shared__ double lds[];  // [n*n][2] + [n][2] column copy + [2] pivot
+  double* A = lds; double* col = lds + (size_t)2 * n * n; double* piv = col + 2 * n;
+  const int x = blockIdx.x;
+  const T* Ms = M + (size_t)x * 5 * msize * 2;
+  for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+    const int i = e / n, j = e % n;
+    const size_t o = ((size_t)((i >> 3) * nt + (j >> 3)) * 64 + (i & 7) * 8 + (j & 7)) * 2;
+    A[2 * e] = Ms[o]; A[2 * e + 1] = Ms[o + 1];
+  }
+  __syncthreads();
+  for (int k = 0; k < n; k++) {
+    if (threadIdx.x == 0) {
+      const double pr = A[2 * (k * n + k)], pi = A[2 * (k * n + k) + 1], d = pr * pr + pi * pi;
+      piv[0] = pr / d; piv[1] = -pi / d;
+    }
+    for (int i = threadIdx.x; i < n; i += blockDim.x) { col[2 * i] = A[2 * (i * n + k)]; col[2 * i + 1] = A[2 * (i * n + k) + 1]; }
+    __syncthreads();
+    const double pr = piv[0], pi = piv[1];
+    // scale row k
+    for (int j = threadIdx.x; j < n; j += blockDim.x) {
+      double* a = A + 2 * (k * n + j);
+      if (j == k) { a[0] = pr; a[1] = pi; }
+      else { const double r = a[0] * pr - a[1] * pi, im = a[0] * pi + a[1] * pr; a[0] = r; a[1] = im; }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < n * n; e += blockDim.x) {
+      const int i = e / n, j = e % n;
+      if (i == k) continue;
+      const double fr = col[2 * i], fi = col[2 * i + 1];
+      double* a = A + 2 * e;
+      const double kr = A[2 * (k * n + j)], ki = A[2 * (k * n + j) + 1];
+      if (j == k) { a[0] = -(fr * kr - fi * ki); a[1] = -(fr * ki + fi * kr); }
+      else { a[0] -= fr * kr - fi * ki; a[1] -= fr * ki + fi * kr; }
+    }
+    __syncthreads();
+  }
+  T* Mo = Minv + (size_t)x * msize * 2;
+  for (int e = threadIdx.x; e < 64 * nt * nt; e += blockDim.x) {
+    const int tile = e >> 6, l = e & 63, i = (tile / nt) * 8 + (l >> 3), j = (tile % nt) * 8 + (l & 7);
+    const bool in = i < n && j < n;
+    Mo[2 * (size_t)e] = in ? (T)A[2 * (i * n + j)] : (T)0;
+    Mo[2 * (size_t)e + 1] = in ? (T)A[2 * (i * n + j) + 1] : (T)0;
+  }
+}
+
+template <typename T>
+void CoarseOp<T>::compute_self_inverse(hipStream_t st) {
+  const size_t lds = sizeof(double) * (2 * (size_t)n_ * n_ + 2 * n_ + 2);
+  DDAMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&invert_self_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(invert_self_kernel<T>, dim3(V_), dim3(256), lds, st, Minv_, M_, n_, nt_, msize_);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
+// ---- allocation / import / export ---------------------------------------------------------------
+template <typename T> CoarseOp<T>::~CoarseOp() {
+  if (M_) (void)hipFree(M_);
+  if (Minv_) (void)hipFree(Minv_);
+  if (nb_) (void)hipFree(nb_);
+}
+template <typename T>
+void CoarseOp<T>::alloc(const Geometry& g, int n) {
+  V_ = g.V; n_ = n; nt_ = (n + 7) / 8; msize_ = (size_t)nt_ * nt_ * 64;
+  DDAMG_REQUIRE(n % 2 == 0 && nt_ <= 8, "coarse dof per site must be even and at most 64");
+  DDAMG_HIP_CHECK(hipMalloc(&M_, sizeof(T) * 2 * msize_ * 5 * V_));
+  DDAMG_HIP_CHECK(hipMalloc(&Minv_, sizeof(T) * 2 * msize_ * V_));
+  DDAMG_HIP_CHECK(hipMemset(M_, 0, sizeof(T) * 2 * msize_ * 5 * V_));
+  DDAMG_HIP_CHECK(hipMemset(Minv_, 0, sizeof(T) * 2 * msize_ * V_));
+  DDAMG_HIP_CHECK(hipMalloc(&nb_, sizeof(int) * 8 * V_));
+  DDAMG_HIP_CHECK(hipMemcpy(nb_, g.nb.data(), sizeof(int) * 8 * V_, hipMemcpyHostToDevice));
+}
+
+static inline size_t tile_off(int nt, int i, int j) { return ((size_t)((i >> 3) * nt + (j >> 3)) * 64 + (i & 7) * 8 + (j & 7)) * 2; }
+
+template <typename T>
+void CoarseOp<T>::import_reference(const Geometry& g, const double* D_ref, const double* clover_ref, hipStream_t st) {
+  const int n = n_, N = n / 2;
+  const size_t csz = (size_t)n * (n + 1) / 2;
+  std::vector<T> h((size_t)2 * msize_ * 5 * V_, (T)0);
+  for (int s = 0; s < V_; s++) {
+    const size_t lx = g.lex_of_site[s];
+    T* ms = h.data() + (size_t)s * 5 * msize_ * 2;
+    // self coupling: triu(A), triu(D) packed column-major, B full column-major; C = -B^H
+    const double* c = clover_ref + lx * csz * 2;
+    for (int blk = 0; blk < 2; blk++) {
+      const double* p = c + (size_t)blk * (N * (N + 1) / 2) * 2;
+      for (int j = 0; j < N; j++)
+        for (int i = 0; i <= j; i++) {
+          const size_t k = (size_t)j * (j + 1) / 2 + i;
+          const double re = p[2 * k], im = p[2 * k + 1];
+          const int I = blk * N + i, J = blk * N + j;
+          ms[tile_off(nt_, I, J)] = (T)re; ms[tile_off(nt_, I, J) + 1] = (T)im;
+          if (i != j) { ms[tile_off(nt_, J, I)] = (T)re; ms[tile_off(nt_, J, I) + 1] = (T)(-im); }
+        }
+    }
+    const double* B = c + (size_t)(N * (N + 1)) * 2;
+    for (int j = 0; j < N; j++)
+      for (int i = 0; i < N; i++) {
+        const double re = B[2 * ((size_t)j * N + i)], im = B[2 * ((size_t)j * N + i) + 1];
+        ms[tile_off(nt_, i, N + j)] = (T)re; ms[tile_off(nt_, i, N + j) + 1] = (T)im;          // B_ij
+        ms[tile_off(nt_, N + j, i)] = (T)(-re); ms[tile_off(nt_, N + j, i) + 1] = (T)im;        // C_ji = -conj(B_ij)
+      }
+    for (int mu = 0; mu < 4; mu++) {
+      const double* d = D_ref + (lx * 4 + mu) * (size_t)n * n * 2;
+      T* mm = ms + (size_t)(1 + mu) * msize_ * 2;
+      for (int bj = 0; bj < 2; bj++)
+        for (int bi = 0; bi < 2; bi++) {
+          // block order A(0,0), C(1,0), B(0,1), D(1,1)
+          const double* blkp = d + (size_t)(bj * 2 + bi) * N * N * 2;
+          for (int j = 0; j < N; j++)
+            for (int i = 0; i < N; i++) {
+              const size_t o = tile_off(nt_, bi * N + i, bj * N + j);
+              mm[o] = (T)blkp[2 * ((size_t)j * N + i)]; mm[o + 1] = (T)blkp[2 * ((size_t)j * N + i) + 1];
+            }
+        }
+    }
+  }
+  DDAMG_HIP_CHECK(hipMemcpyAsync(M_, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice, st));
+  DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+  compute_self_inverse(st);
+}
+
+template <typename T>
+void CoarseOp<T>::export_reference(const Geometry& g, double* D_ref, double* clover_ref, hipStream_t st) const {
+  const int n = n_, N = n / 2;
+  const size_t csz = (size_t)n * (n + 1) / 2;
+  std::vector<T> h((size_t)2 * msize_ * 5 * V_);
+  DDAMG_HIP_CHECK(hipMemcpyAsync(h.data(), M_, sizeof(T) * h.size(), hipMemcpyDeviceToHost, st));
+  DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+  for (int s = 0; s < V_; s++) {
+    const size_t lx = g.lex_of_site[s];
+    const T* ms = h.data() + (size_t)s * 5 * msize_ * 2;
+    double* c = clover_ref + lx * csz * 2;
+    for (int blk = 0; blk < 2; blk++) {
+      double* p = c + (size_t)blk * (N * (N + 1) / 2) * 2;
+      for (int j = 0; j < N; j++)
+        for (int i = 0; i <= j; i++) {
+          const size_t k = (size_t)j * (j + 1) / 2 + i, o = tile_off(nt_, blk * N + i, blk * N + j);
+          p[2 * k] = ms[o]; p[2 * k + 1] = ms[o + 1];
+        }
+    }
+    double* B = c + (size_t)(N * (N + 1)) * 2;
+    for (int j = 0; j < N; j++)
+      for (int i = 0; i < N; i++) {
+        const size_t o = tile_off(nt_, i, N + j);
+        B[2 * ((size_t)j * N + i)] = ms[o]; B[2 * ((size_t)j * N + i) + 1] = ms[o + 1];
+      }
+    for (int mu = 0; mu < 4; mu++) {
+      double* d = D_ref + (lx * 4 + mu) * (size_t)n * n * 2;
+      const T* mm = ms + (size_t)(1 + mu) * msize_ * 2;
+      for (int bj = 0; bj < 2; bj++)
+        for (int bi = 0; bi < 2; bi++) {
+          double* blkp = d + (size_t)(bj * 2 + bi) * N * N * 2;
+          for (int j = 0; j < N; j++)
+            for (int i = 0; i < N; i++) {
+              const size_t o = tile_off(nt_, bi * N + i, bj * N + j);
+              blkp[2 * ((size_t)j * N + i)] = mm[o]; blkp[2 * ((size_t)j * N + i) + 1] = mm[o + 1];
+            }
+        }
+    }
+  }
+}
+
+template class CoarseOp<float>;
+template class CoarseOp<double>;
+
+}  // namespace ddamg

@@ -4,6 +4,8 @@
 #include "common.h"
 #include "geometry.h"
 #include "fine_op.h"
+#include "mg.h"
+#include "krylov.h"
 #include "../../include/ddamg_hip.h"
 #include <vector>
 #include <memory>
@@ -13,6 +15,7 @@ struct ddamg_hip_vec {
   int precision = 32;
   int ndof = 12;
   int V = 0;
+  int aos = 0;  // 0: chunked SoA (fine level), 1: site-major AoS (coarse levels)
   void* data = nullptr;
   size_t bytes = 0;
 };
@@ -44,4 +47,18 @@ struct ddamg_hip_ctx {
   size_t stage_bytes = 0;
 
   double* stage(size_t bytes);
+
+  // multigrid preconditioner (V-cycle precision float when mixed_precision >= 1, double otherwise)
+  std::unique_ptr<ddamg::Multigrid<float>> mg32;
+  std::unique_ptr<ddamg::Multigrid<double>> mg64;
+  bool setup_done = false;
+  // outer FGMRES (fp64) and its workspace
+  ddamg::Gmres<double> outer;
+  ddamg::ReduceWork rw_outer;
+  bool outer_ready = false;
+  float *p32_in = nullptr, *p32_out = nullptr;
+  // results of the last solve
+  int last_iter = 0, last_coarse_iter = 0;
+  double last_relres = 0;
+  std::vector<double> last_history;
 };

@@ -55,4 +55,10 @@ void vec_from_lex(T* dst, const double* src_lex_dev, const int* lex_of_site, int
 template <typename T>
 void vec_to_lex(double* dst_lex_dev, const T* src, const int* lex_of_site, int V, int ndof, hipStream_t st);
 
+// site-major (AoS) coarse vectors <-> lexicographic host layout
+template <typename T>
+void aos_from_lex(T* dst, const double* src_lex_dev, const int* lex_of_site, int V, int ndof, hipStream_t st);
+template <typename T>
+void aos_to_lex(double* dst_lex_dev, const T* src, const int* lex_of_site, int V, int ndof, hipStream_t st);
+
 }  // namespace ddamg

@@ -186,6 +186,31 @@ void vec_to_lex(double* dst, const T* src, const int* lex_of_site, int V, int nd
   DDAMG_HIP_CHECK(hipGetLastError());
 }
 
+template <typename T, bool TO_LEX>
+__global__ void aos_lex_kernel(T* __restrict__ v, double* __restrict__ lexv, const int* __restrict__ lex_of_site, int V, int nreal) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)V * nreal) return;
+  const size_t s = i / nreal; const int r = (int)(i - s * nreal);
+  if constexpr (TO_LEX) lexv[(size_t)lex_of_site[s] * nreal + r] = (double)v[i];
+  else v[i] = (T)lexv[(size_t)lex_of_site[s] * nreal + r];
+}
+template <typename T>
+void aos_from_lex(T* dst, const double* src, const int* lex_of_site, int V, int ndof, hipStream_t st) {
+  size_t total = (size_t)V * 2 * ndof;
+  hipLaunchKernelGGL((aos_lex_kernel<T, false>), dim3((total + 255) / 256), dim3(256), 0, st, dst, const_cast<double*>(src), lex_of_site, V, 2 * ndof);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+template <typename T>
+void aos_to_lex(double* dst, const T* src, const int* lex_of_site, int V, int ndof, hipStream_t st) {
+  size_t total = (size_t)V * 2 * ndof;
+  hipLaunchKernelGGL((aos_lex_kernel<T, true>), dim3((total + 255) / 256), dim3(256), 0, st, const_cast<T*>(src), dst, lex_of_site, V, 2 * ndof);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+template void aos_from_lex<float>(float*, const double*, const int*, int, int, hipStream_t);
+template void aos_from_lex<double>(double*, const double*, const int*, int, int, hipStream_t);
+template void aos_to_lex<float>(double*, const float*, const int*, int, int, hipStream_t);
+template void aos_to_lex<double>(double*, const double*, const int*, int, int, hipStream_t);
+
 template class FineOp<float>;
 template class FineOp<double>;
 template void vec_from_lex<float>(float*, const double*, const int*, int, int, hipStream_t);

@@ -1,0 +1,180 @@
+// krylov.h -- restarted flexible GMRES on device vectors (host-orchestrated).
+// Reference: fgmres_PRECISION src/linsolve_generic.c:219-413, arnoldi_step_PRECISION default branch
+// (classical Gram-Schmidt + separate norm) :810-893, qr_update :898-940, compute_solution :943-982;
+// the mixed-precision outer variant fgmres_MP / arnoldi_step_MP src/linsolve.c:153-424 is the same
+// control flow with T=float vectors (the Hessenberg matrix, Givens rotations and all inner
+// products are fp64 here in every case).
+//
+// Device/host split: one Arnoldi step enqueues  op/prec -> multi-dot -> multi-axpy -> norm -> scale
+// with the Gram-Schmidt coefficients staying in device memory; the host reads back one small
+// column (j+2 numbers) per step for the Givens update and the stopping test: ONE stream
+// synchronisation per iteration.
+#pragma once
+#include "blas.h"
+#include <complex>
+#include <functional>
+#include <vector>
+#include <cmath>
+
+namespace ddamg {
+
+enum { RES = 0, NO_RES = 1 };  // reference enum { _RES, _NO_RES } (src/main.h)
+
+template <typename T>
+struct Gmres {
+  typedef std::complex<double> cd;
+  // configuration
+  int restart_length = 10, num_restart = 1;
+  double tol = 1e-10;
+  bool initial_guess_zero = true;
+  double breakdown_tol = -1;      // |H(j+1,j)| threshold; <0: tol/10 (src/linsolve_generic.c:318), fgmres_MP uses 1e-15 (src/linsolve.c:236)
+  View view{1, 0, 0, 0};
+  size_t vec_elems = 0;
+  hipStream_t st = nullptr;
+  ReduceWork* rw = nullptr;
+  std::function<void(T*, const T*)> op;                                   // out = A in
+  std::function<void(T* phi, T* Dphi, const T* eta, int res)> prec;       // right preconditioner (may be empty)
+  bool prec_gives_Dphi = false;  // preconditioner also returns A*phi in Dphi (src/linsolve_generic.c:832-835)
+  // storage (owned)
+  T* slab = nullptr;
+  T *x = nullptr, *b = nullptr, *r = nullptr, *w = nullptr, *Vb = nullptr, *Zb = nullptr;
+  size_t vstride = 0;
+  // results
+  int iter = 0;
+  double norm_r0 = 1, gamma_jp1 = 1;
+  std::vector<double> history;
+  bool track_history = false;
+
+  void alloc(size_t vec_elems_, int restart_length_, bool with_Z) {
+    vec_elems = vec_elems_;
+    restart_length = restart_length_;
+    vstride = (vec_elems + 63) / 64 * 64;
+    size_t nvec = 4 + (restart_length + 1) + (with_Z ? restart_length + 1 : 0);
+    DDAMG_HIP_CHECK(hipMalloc(&slab, sizeof(T) * vstride * nvec));
+    DDAMG_HIP_CHECK(hipMemset(slab, 0, sizeof(T) * vstride * nvec));
+    x = slab; b = x + vstride; r = b + vstride; w = r + vstride;
+    Vb = w + vstride;
+    Zb = with_Z ? Vb + vstride * (restart_length + 1) : nullptr;
+    H.assign((size_t)(restart_length + 1) * (restart_length + 2), cd(0));
+    y.assign(restart_length + 2, cd(0)); gamma.assign(restart_length + 2, cd(0));
+    c.assign(restart_length + 2, cd(0)); s.assign(restart_length + 2, cd(0));
+  }
+  void release() { if (slab) (void)hipFree(slab); slab = nullptr; }
+  T* V(int i) const { return Vb + vstride * i; }
+  T* Z(int i) const { return Zb + vstride * i; }
+
+  int solve() {
+    DDAMG_REQUIRE(slab && rw && op, "gmres not set up");
+    DDAMG_REQUIRE(restart_length + 2 <= rw->max_m, "reduction workspace too small for this restart length");
+    const bool right = (bool)prec;
+    int j = -1, finish = 0, res;
+    iter = 0; norm_r0 = 1; gamma_jp1 = 1;
+    history.clear();
+    for (int ol = 0; ol < num_restart && !finish; ol++) {
+      if (ol == 0 && initial_guess_zero) {
+        res = NO_RES;
+        vec_copy<T>(r, b, view, st);
+      } else {
+        res = RES;
+        op(w, x);
+        vec_minus<T>(r, b, w, view, st);
+      }
+      vec_norm<T>(r, view, *rw, rw->d_result, st);
+      DDAMG_HIP_CHECK(hipMemcpyAsync(rw->h_result, rw->d_result, sizeof(double), hipMemcpyDeviceToHost, st));
+      DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+      const double gamma0 = rw->h_result[0];
+      gamma[0] = gamma0;
+      if (ol == 0) norm_r0 = gamma0;
+      if (!(gamma0 > 0)) {  // zero right-hand side / exact solution (the reference is not designed for this case)
+        if (ol == 0 && initial_guess_zero) vec_zero<T>(x, view, st);
+        gamma_jp1 = 0;
+        break;
+      }
+      vec_scale<T>(V(0), r, 1.0 / gamma0, 0.0, view, st);
+      j = -1;
+      for (int il = 0; il < restart_length && !finish; il++) {
+        j = il; iter++;
+        arnoldi_step(j, right);
+        cd* Hj = &H[(size_t)j * (restart_length + 2)];
+        if (std::abs(Hj[j + 1]) > (breakdown_tol < 0 ? tol / 10 : breakdown_tol)) {
+          qr_update(j);
+          gamma_jp1 = std::abs(gamma[j + 1]);
+          if (track_history) history.push_back(gamma_jp1 / norm_r0);
+          if (gamma_jp1 / norm_r0 < tol || gamma_jp1 / norm_r0 > 1e5) finish = 1;
+        } else {
+          finish = 1;
+          break;
+        }
+      }
+      compute_solution(right ? Zb : Vb, j, (res == NO_RES) ? ol : 1);
+    }
+    return iter;
+  }
+
+  // true residual norm ||b - A x|| / norm_r0  (FGMRES_RESTEST, src/linsolve_generic.c:351-357)
+  double true_residual() {
+    op(w, x);
+    vec_minus<T>(r, b, w, view, st);
+    vec_norm<T>(r, view, *rw, rw->d_result, st);
+    DDAMG_HIP_CHECK(hipMemcpyAsync(rw->h_result, rw->d_result, sizeof(double), hipMemcpyDeviceToHost, st));
+    DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+    return rw->h_result[0] / norm_r0;
+  }
+
+ private:
+  std::vector<cd> H, y, gamma, c, s;  // H column-major: H[j*(m+2) + i] = reference H[j][i]
+
+  void arnoldi_step(int j, bool right) {
+    if (right) {
+      if (prec_gives_Dphi) {
+        prec(Z(j), w, V(j), NO_RES);
+      } else {
+        prec(Z(j), nullptr, V(j), NO_RES);
+        op(w, Z(j));
+      }
+    } else {
+      op(w, V(j));
+    }
+    double* dh = rw->d_result;
+    vec_multi_dot<T>(Vb, vstride, j + 1, w, view, *rw, dh, st);
+    vec_multi_axpy_dev<T>(w, Vb, vstride, j + 1, dh, -1.0, view, st);
+    vec_norm<T>(w, view, *rw, dh + 2 * (j + 1), st);
+    vec_scale_inv_dev<T>(V(j + 1), w, dh + 2 * (j + 1), view, st);
+    DDAMG_HIP_CHECK(hipMemcpyAsync(rw->h_result, dh, sizeof(double) * (2 * (j + 1) + 1), hipMemcpyDeviceToHost, st));
+    DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+    cd* Hj = &H[(size_t)j * (restart_length + 2)];
+    for (int i = 0; i <= j; i++) Hj[i] = cd(rw->h_result[2 * i], rw->h_result[2 * i + 1]);
+    Hj[j + 1] = rw->h_result[2 * (j + 1)];
+  }
+
+  void qr_update(int j) {
+    cd* Hj = &H[(size_t)j * (restart_length + 2)];
+    for (int i = 0; i < j; i++) {
+      cd beta = (-s[i]) * Hj[i] + c[i] * Hj[i + 1];
+      Hj[i] = std::conj(c[i]) * Hj[i] + std::conj(s[i]) * Hj[i + 1];
+      Hj[i + 1] = beta;
+    }
+    cd beta = std::sqrt(std::norm(Hj[j]) + std::norm(Hj[j + 1]));
+    s[j] = Hj[j + 1] / beta; c[j] = Hj[j] / beta;
+    gamma[j + 1] = (-s[j]) * gamma[j]; gamma[j] = std::conj(c[j]) * gamma[j];
+    Hj[j] = beta; Hj[j + 1] = 0;
+  }
+
+  void compute_solution(T* basis, int j, int ol) {
+    if (j < 0) return;
+    const int ld = restart_length + 2;
+    for (int i = j; i >= 0; i--) {
+      y[i] = gamma[i];
+      for (int k = i + 1; k <= j; k++) y[i] -= H[(size_t)k * ld + i] * y[k];
+      y[i] /= H[(size_t)i * ld + i];
+    }
+    for (int i = 0; i <= j; i++) { rw->h_coef[2 * i] = y[i].real(); rw->h_coef[2 * i + 1] = y[i].imag(); }
+    DDAMG_HIP_CHECK(hipMemcpyAsync(rw->d_coef, rw->h_coef, sizeof(double) * 2 * (j + 1), hipMemcpyHostToDevice, st));
+    if (!ol) vec_zero<T>(x, view, st);
+    vec_multi_axpy_dev<T>(x, basis, vstride, j + 1, rw->d_coef, 1.0, view, st);
+    // h_coef is reused by the next restart cycle: make sure the upload has been consumed
+    DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+  }
+};
+
+}  // namespace ddamg

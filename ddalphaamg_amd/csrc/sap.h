@@ -1,0 +1,54 @@
+// sap.h -- red-black multiplicative Schwarz (SAP) smoother with odd-even preconditioned block
+// solves on the fine level.
+// Reference: red_black_schwarz_PRECISION src/schwarz_generic.c:1260-1431,
+//            block_solve_oddeven_PRECISION / apply_block_schur_complement_PRECISION
+//            src/oddeven_generic.c:1317-1360, block_(n_)hopping_term :1051-1315,
+//            block_diag_ee / block_diag_oo_inv :975-1047, local_minres_PRECISION
+//            src/linsolve_generic.c:985-1029, (n_)block_PRECISION_boundary_op
+//            src/schwarz_generic.c:743-971.
+//
+// GPU mapping: all blocks of one colour are solved concurrently; one workgroup owns one block
+// (several small blocks share a workgroup), thread t owns even site t and odd site t of its block;
+// the block's even / odd spinors are exchanged through LDS for the in-block hopping terms, the
+// MinRes inner products are wavefront-shuffle reductions; the residual update with the
+// couplings that cross block faces (n_boundary_op) is fused into the solve kernel's prologue.
+#pragma once
+#include "common.h"
+#include "geometry.h"
+#include "fine_op.h"
+
+namespace ddamg {
+
+template <typename T>
+struct SapDev {
+  FineOpDev<T> op;
+  const int* blk_nb;      // [8][block_sites] block-local neighbour or -1
+  const int* block_list;  // [num_blocks] reference red-black list id 0..7 of every block
+  int block_sites, half_sites;
+  int block_iter;
+};
+
+template <typename T>
+class SapSmoother {
+ public:
+  ~SapSmoother();
+  void setup(const Geometry& g, const FineOp<T>* op, int block_iter, hipStream_t st);
+  // phi = smoothed iterate after `cycles` red-black sweeps.  res==NO_RES: start from phi=0, r=eta;
+  // res==RES: start from the given phi.  (Dphi output of the reference's mixed_precision==2 path is
+  // produced when Dphi != nullptr.)
+  void smooth(T* phi, T* Dphi, const T* eta, int cycles, int res, hipStream_t st);
+  bool ready() const { return op_ != nullptr; }
+  // work vectors (exposed for tests): residual r, latest_iter, x
+  T *r = nullptr, *latest = nullptr, *x = nullptr;
+
+ private:
+  const FineOp<T>* op_ = nullptr;
+  int V_ = 0, BS_ = 0, HS_ = 0, nblocks_ = 0, block_iter_ = 4;
+  int ncol_[2] = {0, 0};
+  int* d_blk_nb_ = nullptr;
+  int* d_block_list_ = nullptr;
+  int* d_color_blocks_[2] = {nullptr, nullptr};  // block indices per colour
+  void launch(int color, int mode_default, unsigned skip_mask, const T* eta, hipStream_t st);
+};
+
+}  // namespace ddamg

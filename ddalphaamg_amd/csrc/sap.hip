@@ -1,0 +1,396 @@
+// sap.hip -- see sap.h
+#include "sap.h"
+#include "dirac_device.h"
+#include "blas.h"
+#include "krylov.h"
+#include <vector>
+
+namespace ddamg {
+
+enum { MODE_NONE = 0, MODE_NBOUNDARY = 1, MODE_FULLRES = 2 };
+
+template <typename T>
+struct SapArgs {
+  SapDev<T> s;
+  T* x; T* r; T* latest;
+  const T* eta;          // only read in MODE_FULLRES
+  const int* blocks;     // block indices to process
+  int nblocks;           // number of entries in `blocks`
+  int mode;              // residual update for blocks whose list bit is NOT in skip_mask
+  unsigned skip_mask;    // blocks whose red-black list id bit is set here use MODE_NONE
+  int solve;             // 0: only update and store the residual
+};
+
+template <typename T> struct Eps;
+template <> struct Eps<float> { static constexpr float v = 1e-6f; };    // EPS_float  (src/main.h:45)
+template <> struct Eps<double> { static constexpr double v = 1e-14; };  // EPS_double (src/main.h:46)
+
+// acc -= hop_d(phi(nb)) for the couplings of `site` that leave the block (mask bit d set), phi in global memory
+template <typename T, int MU>
+__device__ __forceinline__ void ext_hop_pair(const T* __restrict__ phi, const FineOpDev<T>& op, size_t site, unsigned mask, T (&acc)[24]) {
+  const size_t V = op.V;
+  if (mask & (1u << MU)) {
+    int j = op.nb[(size_t)MU * V + site];
+    T pn[24], U[18];
+    load_site<T, 24>(phi, V, j, pn);
+    load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, site, U);
+    hop_accumulate<T, MU, true>(U, pn, acc);
+  }
+  if (mask & (1u << (4 + MU))) {
+    int j = op.nb[(size_t)(4 + MU) * V + site];
+    T pn[24], U[18];
+    load_site<T, 24>(phi, V, j, pn);
+    load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, j, U);
+    hop_accumulate<T, MU, false>(U, pn, acc);
+  }
+}
+template <typename T>
+__device__ __forceinline__ void ext_hops(const T* __restrict__ phi, const FineOpDev<T>& op, size_t site, unsigned mask, T (&acc)[24]) {
+  ext_hop_pair<T, 0>(phi, op, site, mask, acc);
+  ext_hop_pair<T, 1>(phi, op, site, mask, acc);
+  ext_hop_pair<T, 2>(phi, op, site, mask, acc);
+  ext_hop_pair<T, 3>(phi, op, site, mask, acc);
+}
+
+// acc -= sum over in-block neighbours of hop_d(src(nb)), src = LDS image [24][HS] of the other parity
+template <typename T, int HS, int MU>
+__device__ __forceinline__ void blk_hop_pair(const T* __restrict__ lds, const int (&nbl)[8], const FineOpDev<T>& op,
+                                             size_t site, size_t src_base, T (&acc)[24]) {
+  const size_t V = op.V;
+  {
+    const int j = nbl[MU];
+    if (j >= 0) {
+      T pn[24], U[18];
+#pragma unroll
+      for (int c = 0; c < 24; c++) pn[c] = lds[c * HS + j];
+      load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, site, U);
+      hop_accumulate<T, MU, true>(U, pn, acc);
+    }
+  }
+  {
+    const int j = nbl[4 + MU];
+    if (j >= 0) {
+      T pn[24], U[18];
+#pragma unroll
+      for (int c = 0; c < 24; c++) pn[c] = lds[c * HS + j];
+      load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, src_base + j, U);
+      hop_accumulate<T, MU, false>(U, pn, acc);
+    }
+  }
+}
+template <typename T, int HS>
+__device__ __forceinline__ void blk_hops(const T* __restrict__ lds, const int (&nbl)[8], const FineOpDev<T>& op,
+                                         size_t site, size_t src_base, T (&acc)[24]) {
+  blk_hop_pair<T, HS, 0>(lds, nbl, op, site, src_base, acc);
+  blk_hop_pair<T, HS, 1>(lds, nbl, op, site, src_base, acc);
+  blk_hop_pair<T, HS, 2>(lds, nbl, op, site, src_base, acc);
+  blk_hop_pair<T, HS, 3>(lds, nbl, op, site, src_base, acc);
+}
+
+template <typename T>
+__device__ __forceinline__ void clover_apply(const T* __restrict__ cl, size_t V, size_t site, const T (&in)[24], T (&out)[24]) {
+  T c[36];
+  load_site<T, 36>(cl, V, site, c);
+  herm6_mul<T>(c, in, out);
+  load_site<T, 36>(cl + (size_t)36 * V, V, site, c);
+  herm6_mul<T>(c, in + 12, out + 12);
+}
+
+// sum over the HS threads of one block (all of them get the result)
+template <typename T, int HS, int NT>
+__device__ __forceinline__ void block_allreduce3(T& a, T& b, T& c, T* red /* LDS [3][NT/64] */) {
+  constexpr int W = HS < 64 ? HS : 64;
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64);
+  }
+  if constexpr (HS > 64) {
+    constexpr int NW = NT / 64;
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[w] = a; red[NW + w] = b; red[2 * NW + w] = c; }
+    __syncthreads();
+    a = 0; b = 0; c = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) { a += red[k]; b += red[NW + k]; c += red[2 * NW + k]; }
+  }
+}
+
+template <typename T, int HS>
+__global__ __launch_bounds__((HS < 64 ? 64 : HS)) void sap_block_kernel(SapArgs<T> a) {
+  constexpr int NT = HS < 64 ? 64 : HS;   // threads per workgroup
+  constexpr int BPW = NT / HS;            // blocks per workgroup
+  constexpr int BS = 2 * HS;
+  __shared__ T lds_e[BPW * 24 * HS];
+  __shared__ T lds_o[BPW * 24 * HS];
+  __shared__ T red[3 * (NT / 64)];
+  const FineOpDev<T>& op = a.s.op;
+  const size_t V = op.V;
+  const int bw = threadIdx.x / HS, i = threadIdx.x % HS;
+  const int bslot = blockIdx.x * BPW + bw;
+  const bool active = bslot < a.nblocks;
+  const int blk = active ? a.blocks[bslot] : a.blocks[0];
+  const size_t base = (size_t)blk * BS;
+  const size_t se = base + i, so = base + HS + i;
+  T* le = lds_e + bw * 24 * HS;
+  T* lo = lds_o + bw * 24 * HS;
+
+  // block-local neighbour indices in the other parity's numbering (or -1), and the mask of
+  // directions that leave the block
+  int nbE[8], nbO[8];
+  unsigned extE = 0, extO = 0;
+#pragma unroll
+  for (int d = 0; d < 8; d++) {
+    int v = a.s.blk_nb[d * BS + i];
+    nbE[d] = v < 0 ? -1 : v - HS;
+    if (v < 0) extE |= 1u << d;
+    v = a.s.blk_nb[d * BS + HS + i];
+    nbO[d] = v;
+    if (v < 0) extO |= 1u << d;
+  }
+
+  // ---- prologue: block residual -------------------------------------------------------------
+  int mode = a.mode;
+  if ((a.skip_mask >> a.s.block_list[blk]) & 1u) mode = MODE_NONE;
+  T re[24], ro[24];
+  if (mode == MODE_FULLRES) {
+    // r_b = eta_b - (D x)_b with the full operator, x from global memory (block_op + boundary_op)
+    T xs[24], e[24], et[24];
+    load_site<T, 24>(a.x, V, se, xs);
+    clover_apply<T>(op.clover, V, se, xs, e);
+    ext_hops<T>(a.x, op, se, 0xffu, e);
+    load_site<T, 24>(a.eta, V, se, et);
+#pragma unroll
+    for (int k = 0; k < 24; k++) re[k] = et[k] - e[k];
+    load_site<T, 24>(a.x, V, so, xs);
+    clover_apply<T>(op.clover, V, so, xs, e);
+    ext_hops<T>(a.x, op, so, 0xffu, e);
+    load_site<T, 24>(a.eta, V, so, et);
+#pragma unroll
+    for (int k = 0; k < 24; k++) ro[k] = et[k] - e[k];
+  } else {
+    load_site<T, 24>(a.r, V, se, re);
+    load_site<T, 24>(a.r, V, so, ro);
+    if (mode == MODE_NBOUNDARY) {
+      // r_b -= D_{b,ext} latest_ext  (n_boundary_op): add the hopping terms that cross block faces
+      T acc[24];
+#pragma unroll
+      for (int k = 0; k < 24; k++) acc[k] = 0;
+      ext_hops<T>(a.latest, op, se, extE, acc);
+#pragma unroll
+      for (int k = 0; k < 24; k++) { re[k] -= acc[k]; acc[k] = 0; }
+      ext_hops<T>(a.latest, op, so, extO, acc);
+#pragma unroll
+      for (int k = 0; k < 24; k++) ro[k] -= acc[k];
+    }
+  }
+  if (!a.solve) {
+    if (active) { store_site<T, 24>(a.r, V, se, re); store_site<T, 24>(a.r, V, so, ro); }
+    return;
+  }
+
+  // ---- block solve (block_solve_oddeven) ------------------------------------------------------
+  T to[24];  // odd-site temporary
+  // t_o = D_oo^-1 r_o ; r_e <- r_e - D_eo t_o
+  clover_apply<T>(op.clover_inv, V, so, ro, to);
+#pragma unroll
+  for (int c = 0; c < 24; c++) lo[c * HS + i] = to[c];
+  __syncthreads();
+  T rm[24];
+  {
+    T acc[24];
+#pragma unroll
+    for (int k = 0; k < 24; k++) acc[k] = 0;
+    blk_hops<T, HS>(lo, nbE, op, se, base + HS, acc);
+#pragma unroll
+    for (int k = 0; k < 24; k++) rm[k] = re[k] - acc[k];
+  }
+  // MinRes on the even-site Schur complement (local_minres)
+  T lphi[24];
+#pragma unroll
+  for (int k = 0; k < 24; k++) lphi[k] = 0;
+  for (int it = 0; it < a.s.block_iter; it++) {
+    __syncthreads();  // previous readers of lds_e / lds_o are done
+#pragma unroll
+    for (int c = 0; c < 24; c++) le[c * HS + i] = rm[c];
+    __syncthreads();
+    {
+      T acc[24];
+#pragma unroll
+      for (int k = 0; k < 24; k++) acc[k] = 0;
+      blk_hops<T, HS>(le, nbO, op, so, base, acc);        // acc = D_oe rm
+      clover_apply<T>(op.clover_inv, V, so, acc, to);     // D_oo^-1 D_oe rm
+    }
+#pragma unroll
+    for (int c = 0; c < 24; c++) lo[c * HS + i] = to[c];
+    __syncthreads();
+    T Dr[24];
+    clover_apply<T>(op.clover, V, se, rm, Dr);            // D_ee rm
+    {
+      T acc[24];
+#pragma unroll
+      for (int k = 0; k < 24; k++) acc[k] = 0;
+      blk_hops<T, HS>(lo, nbE, op, se, base + HS, acc);   // acc = D_eo (..)
+#pragma unroll
+      for (int k = 0; k < 24; k++) Dr[k] -= acc[k];
+    }
+    // alpha = <Dr,rm>/<Dr,Dr>   (local_xy_over_xx, src/linalg_generic.c:158-169)
+    T nr = 0, ni = 0, dn = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      nr += Dr[2 * k] * rm[2 * k] + Dr[2 * k + 1] * rm[2 * k + 1];
+      ni += Dr[2 * k] * rm[2 * k + 1] - Dr[2 * k + 1] * rm[2 * k];
+      dn += Dr[2 * k] * Dr[2 * k] + Dr[2 * k + 1] * Dr[2 * k + 1];
+    }
+    block_allreduce3<T, HS, NT>(nr, ni, dn, red);
+    T ar = 0, ai = 0;
+    if (fabs(dn) >= Eps<T>::v) { ar = nr / dn; ai = ni / dn; }
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      lphi[2 * k]     += ar * rm[2 * k] - ai * rm[2 * k + 1];
+      lphi[2 * k + 1] += ar * rm[2 * k + 1] + ai * rm[2 * k];
+      rm[2 * k]       -= ar * Dr[2 * k] - ai * Dr[2 * k + 1];
+      rm[2 * k + 1]   -= ar * Dr[2 * k + 1] + ai * Dr[2 * k];
+    }
+  }
+  // even to odd: delta_o = D_oo^-1 ( r_o - D_oe delta_e )
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < 24; c++) le[c * HS + i] = lphi[c];
+  __syncthreads();
+  {
+    T acc[24];
+#pragma unroll
+    for (int k = 0; k < 24; k++) acc[k] = 0;
+    blk_hops<T, HS>(le, nbO, op, so, base, acc);
+#pragma unroll
+    for (int k = 0; k < 24; k++) ro[k] -= acc[k];
+    clover_apply<T>(op.clover_inv, V, so, ro, to);
+  }
+  if (active) {
+    // x += delta ; latest_iter = delta ; r_e = MinRes residual, r_o = 0
+    T xs[24];
+    load_site<T, 24>(a.x, V, se, xs);
+#pragma unroll
+    for (int k = 0; k < 24; k++) xs[k] += lphi[k];
+    store_site<T, 24>(a.x, V, se, xs);
+    store_site<T, 24>(a.latest, V, se, lphi);
+    store_site<T, 24>(a.r, V, se, rm);
+    load_site<T, 24>(a.x, V, so, xs);
+#pragma unroll
+    for (int k = 0; k < 24; k++) { xs[k] += to[k]; rm[k] = 0; }
+    store_site<T, 24>(a.x, V, so, xs);
+    store_site<T, 24>(a.latest, V, so, to);
+    store_site<T, 24>(a.r, V, so, rm);
+  }
+}
+
+template <typename T>
+SapSmoother<T>::~SapSmoother() {
+  if (r) (void)hipFree(r);
+  if (latest) (void)hipFree(latest);
+  if (x) (void)hipFree(x);
+  if (d_blk_nb_) (void)hipFree(d_blk_nb_);
+  if (d_block_list_) (void)hipFree(d_block_list_);
+  for (int c = 0; c < 2; c++) if (d_color_blocks_[c]) (void)hipFree(d_color_blocks_[c]);
+}
+
+template <typename T>
+void SapSmoother<T>::setup(const Geometry& g, const FineOp<T>* op, int block_iter, hipStream_t st) {
+  op_ = op; V_ = g.V; BS_ = g.block_sites; HS_ = g.block_sites / 2; nblocks_ = g.num_blocks; block_iter_ = block_iter;
+  DDAMG_REQUIRE(g.block_even_sites * 2 == g.block_sites, "Schwarz blocks need as many even as odd sites (even block extents)");
+  DDAMG_REQUIRE(HS_ == 8 || HS_ == 16 || HS_ == 32 || HS_ == 64 || HS_ == 128 || HS_ == 256,
+                "Schwarz block volume must be 16..512 sites and a power of two on the GPU smoother");
+  for (int mu = 0; mu < 4; mu++)
+    DDAMG_REQUIRE(g.nblk[mu] % 2 == 0, "red-black SAP needs an even number of blocks per direction");
+  const size_t n = (size_t)24 * V_;
+  DDAMG_HIP_CHECK(hipMalloc(&r, sizeof(T) * n));
+  DDAMG_HIP_CHECK(hipMalloc(&latest, sizeof(T) * n));
+  DDAMG_HIP_CHECK(hipMalloc(&x, sizeof(T) * n));
+  DDAMG_HIP_CHECK(hipMemsetAsync(r, 0, sizeof(T) * n, st));
+  DDAMG_HIP_CHECK(hipMemsetAsync(latest, 0, sizeof(T) * n, st));
+  DDAMG_HIP_CHECK(hipMemsetAsync(x, 0, sizeof(T) * n, st));
+  DDAMG_HIP_CHECK(hipMalloc(&d_blk_nb_, sizeof(int) * 8 * BS_));
+  DDAMG_HIP_CHECK(hipMemcpyAsync(d_blk_nb_, g.blk_nb.data(), sizeof(int) * 8 * BS_, hipMemcpyHostToDevice, st));
+  DDAMG_HIP_CHECK(hipMalloc(&d_block_list_, sizeof(int) * nblocks_));
+  DDAMG_HIP_CHECK(hipMemcpyAsync(d_block_list_, g.block_list.data(), sizeof(int) * nblocks_, hipMemcpyHostToDevice, st));
+  std::vector<int> cb[2];
+  for (int b = 0; b < nblocks_; b++) cb[g.block_color[b]].push_back(b);
+  for (int c = 0; c < 2; c++) {
+    ncol_[c] = (int)cb[c].size();
+    DDAMG_REQUIRE(ncol_[c] > 0, "red-black SAP needs blocks of both colours");
+    DDAMG_HIP_CHECK(hipMalloc(&d_color_blocks_[c], sizeof(int) * ncol_[c]));
+    DDAMG_HIP_CHECK(hipMemcpyAsync(d_color_blocks_[c], cb[c].data(), sizeof(int) * ncol_[c], hipMemcpyHostToDevice, st));
+  }
+  DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+}
+
+template <typename T, int HS>
+static void launch_hs(const SapArgs<T>& a, hipStream_t st) {
+  constexpr int NT = HS < 64 ? 64 : HS;
+  constexpr int BPW = NT / HS;
+  const int grid = (a.nblocks + BPW - 1) / BPW;
+  hipLaunchKernelGGL((sap_block_kernel<T, HS>), dim3(grid), dim3(NT), 0, st, a);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+void SapSmoother<T>::launch(int color, int mode, unsigned skip_mask, const T* eta, hipStream_t st) {
+  SapArgs<T> a;
+  a.s.op = op_->dev(); a.s.blk_nb = d_blk_nb_; a.s.block_list = d_block_list_;
+  a.s.block_sites = BS_; a.s.half_sites = HS_; a.s.block_iter = block_iter_;
+  a.x = x; a.r = r; a.latest = latest; a.eta = eta;
+  a.blocks = d_color_blocks_[color]; a.nblocks = ncol_[color];
+  a.mode = mode < 0 ? MODE_NBOUNDARY : mode; a.skip_mask = skip_mask; a.solve = mode < 0 ? 0 : 1;
+  switch (HS_) {
+    case 8: launch_hs<T, 8>(a, st); break;
+    case 16: launch_hs<T, 16>(a, st); break;
+    case 32: launch_hs<T, 32>(a, st); break;
+    case 64: launch_hs<T, 64>(a, st); break;
+    case 128: launch_hs<T, 128>(a, st); break;
+    case 256:
+      if constexpr (sizeof(T) == 4) { launch_hs<T, 256>(a, st); break; }
+      DDAMG_REQUIRE(false, "512-site Schwarz blocks are only supported in fp32 (LDS budget)");
+      break;
+    default: DDAMG_REQUIRE(false, "unsupported Schwarz block volume");
+  }
+}
+
+template <typename T>
+void SapSmoother<T>::smooth(T* phi, T* Dphi, const T* eta, int cycles, int res, hipStream_t st) {
+  DDAMG_REQUIRE(ready(), "SAP smoother not set up");
+  DDAMG_REQUIRE(phi != eta, "smoother: phi and eta must differ");  // ASSERT( phi != eta ), src/vcycle_generic.c:28
+  const View all = whole((size_t)24 * V_);
+  const int init_res = res;
+  if (res == NO_RES) {
+    vec_copy<T>(r, eta, all, st);
+    vec_zero<T>(x, all, st);
+  } else {
+    vec_copy<T>(x, phi, all, st);
+  }
+  // the reference walks 8 block lists per cycle (colour 0: lists 0-3, colour 1: lists 4-7) and, when
+  // started without a residual, only switches the residual update on after list 5 of the first
+  // cycle (src/schwarz_generic.c:1344): lists 4 and 5 of cycle 0 are solved against the stale r.
+  for (int k = 0; k < cycles; k++) {
+    for (int color = 0; color < 2; color++) {
+      int mode; unsigned skip = 0;
+      if (k == 0 && init_res == RES) mode = MODE_FULLRES;
+      else if (k == 0 && init_res == NO_RES) {
+        if (color == 0) mode = MODE_NONE;
+        else { mode = MODE_NBOUNDARY; skip = (1u << 4) | (1u << 5); }
+      } else mode = MODE_NBOUNDARY;
+      launch(color, mode, skip, eta, st);
+    }
+  }
+  vec_copy<T>(phi, x, all, st);  // relax_fac == 1 (the reference's default, src/init.c)
+  if (Dphi != nullptr) {
+    // D phi = eta - r, after bringing the colour-0 residuals up to date (src/schwarz_generic.c:1355-1396)
+    launch(0, -1, 0, eta, st);
+    vec_minus<T>(Dphi, eta, r, all, st);
+  }
+}
+
+template class SapSmoother<float>;
+template class SapSmoother<double>;
+
+}  // namespace ddamg

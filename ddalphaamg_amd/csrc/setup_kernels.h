@@ -1,0 +1,23 @@
+// setup_kernels.h -- device kernels for the Galerkin coarse-operator construction D_c = P^H D P.
+// Reference: coarse_operator_PRECISION_setup src/coarse_operator_generic.c:53-100,
+//   set_coarse_self_coupling / set_coarse_neighbor_coupling :103-205,
+//   d_plus_clover_aggregate_PRECISION / d_neighbor_aggregate_PRECISION src/dirac_generic.c:308-462.
+#pragma once
+#include "common.h"
+#include "fine_op.h"
+#include "transfer.h"
+#include "coarse_op.h"
+
+namespace ddamg {
+
+// W[0] = D restricted to couplings inside the aggregates, applied to the chirality-`chir` half of v;
+// W[1+mu] = coupling across the +mu face of the aggregates (positive hopping term), same input.
+// W is 5 consecutive fine vectors (stride 24*V).
+template <typename T>
+void aggregate_dirac(T* W, const T* v, int chir, const FineOp<T>& op, const unsigned char* d_agg_face, hipStream_t st);
+
+// column `col` of the five coarse matrices of every coarse site <- P^H W[part]
+template <typename T>
+void galerkin_column(CoarseOp<T>& cop, const Interpolation<T>& ip, const T* W, int col, T* work, hipStream_t st);
+
+}  // namespace ddamg

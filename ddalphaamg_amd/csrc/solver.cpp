@@ -1,0 +1,253 @@
+// solver.cpp -- setup / solve entry points of the C-ABI (include/ddamg_hip.h) on top of mg.h and krylov.h.
+// Reference: method_setup / method_update src/init.c:134-374, wilson_driver src/top_level.c:64-104,
+// fgmres_double + preconditioner (mixed precision 1) src/linsolve_generic.c:219-413, src/preconditioner.c:25-69.
+#include "context.h"
+#include <cstring>
+#include <string>
+
+using namespace ddamg;
+
+extern thread_local std::string g_ddamg_last_error;
+
+#define DDAMG_API_BEGIN try {
+#define DDAMG_API_END                                  \
+  }                                                    \
+  catch (const std::exception& e) {                    \
+    g_ddamg_last_error = e.what();                     \
+    return 1;                                          \
+  }                                                    \
+  catch (...) {                                        \
+    g_ddamg_last_error = "unknown error";              \
+    return 1;                                          \
+  }                                                    \
+  return 0;
+
+static void ensure_mg(ddamg_hip_ctx* c) {
+  DDAMG_REQUIRE(c->have_operator, "no operator set (call ddamg_hip_set_gauge / ddamg_hip_set_operator first)");
+  DDAMG_REQUIRE(c->par.num_levels == 2, "multigrid needs num_levels == 2 in this build");
+  DDAMG_REQUIRE(c->par.method == 2, "multigrid preconditioner needs method == 2 (red-black SAP)");
+  if (c->par.mixed_precision == 0) {
+    if (!c->mg64) c->mg64.reset(new Multigrid<double>(c->par, c->levels[0]->geom, c->levels[1]->geom, &c->fop64, c->stream));
+  } else {
+    if (!c->mg32) c->mg32.reset(new Multigrid<float>(c->par, c->levels[0]->geom, c->levels[1]->geom, &c->fop32, c->stream));
+  }
+}
+
+static void ensure_outer(ddamg_hip_ctx* c) {
+  if (c->outer_ready) return;
+  const size_t n = (size_t)24 * c->levels[0]->geom.V;
+  c->rw_outer.init(c->par.restart + 4);
+  c->outer.alloc(n, c->par.restart, c->par.method > 0);
+  c->outer.num_restart = c->par.max_restart;
+  c->outer.view = whole(n);
+  c->outer.st = c->stream;
+  c->outer.rw = &c->rw_outer;
+  c->outer.track_history = true;
+  c->outer.op = [c](double* out, const double* in) { c->fop64.apply(out, in, c->stream); };
+  if (c->par.method > 0) {
+    if (c->par.mixed_precision == 0) {
+      c->outer.prec = [c](double* phi, double* Dphi, const double* eta, int res) { c->mg64->vcycle(phi, Dphi, eta, res); };
+    } else {
+      DDAMG_HIP_CHECK(hipMalloc(&c->p32_in, sizeof(float) * n));
+      DDAMG_HIP_CHECK(hipMalloc(&c->p32_out, sizeof(float) * n));
+      // preconditioner(): trans_float -> vcycle_float -> trans_back_float (src/preconditioner.c:31-33)
+      c->outer.prec = [c](double* phi, double* Dphi, const double* eta, int res) {
+        const size_t V = c->levels[0]->geom.V;
+        vec_convert<float, double>(c->p32_in, eta, V, 24, c->stream);
+        c->mg32->vcycle(c->p32_out, nullptr, c->p32_in, res);
+        vec_convert<double, float>(phi, c->p32_out, V, 24, c->stream);
+      };
+    }
+  }
+  c->outer_ready = true;
+}
+
+extern "C" {
+
+int ddamg_hip_setup(ddamg_hip_ctx* c, int setup_iterations, int* coarse_iterations) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c, "null context");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  ensure_mg(c);
+  const int iters = setup_iterations < 0 ? c->par.setup_iter[0] : setup_iterations;
+  if (c->mg32) { c->mg32->coarse_iter_count = 0; c->mg32->initial_setup(); c->mg32->iterative_setup(iters); if (coarse_iterations) *coarse_iterations = c->mg32->coarse_iter_count; }
+  else { c->mg64->coarse_iter_count = 0; c->mg64->initial_setup(); c->mg64->iterative_setup(iters); if (coarse_iterations) *coarse_iterations = c->mg64->coarse_iter_count; }
+  c->setup_done = true;
+  DDAMG_API_END
+}
+
+int ddamg_hip_setup_update(ddamg_hip_ctx* c, int iterations, int* coarse_iterations) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && c->setup_done, "setup has not been run");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  if (c->mg32) { c->mg32->coarse_iter_count = 0; c->mg32->iterative_setup(iterations); if (coarse_iterations) *coarse_iterations = c->mg32->coarse_iter_count; }
+  else { c->mg64->coarse_iter_count = 0; c->mg64->iterative_setup(iterations); if (coarse_iterations) *coarse_iterations = c->mg64->coarse_iter_count; }
+  DDAMG_API_END
+}
+
+int ddamg_hip_set_test_vectors(ddamg_hip_ctx* c, const double* tv_lex, int orthonormalised) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && tv_lex, "null argument");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  ensure_mg(c);
+  if (c->mg32) { if (orthonormalised) c->mg32->import_interpolation(tv_lex); else c->mg32->import_test_vectors(tv_lex); }
+  else { if (orthonormalised) c->mg64->import_interpolation(tv_lex); else c->mg64->import_test_vectors(tv_lex); }
+  c->setup_done = true;
+  DDAMG_API_END
+}
+
+int ddamg_hip_get_interpolation(ddamg_hip_ctx* c, double* P_lex) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && c->setup_done && P_lex, "setup has not been run");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  const size_t V = c->levels[0]->geom.V, nel = 24 * V;
+  const int nvec = c->par.num_vect[0];
+  double* st = c->stage(sizeof(double) * nel);
+  for (int k = 0; k < nvec; k++) {
+    if (c->mg32) vec_to_lex<float>(st, c->mg32->interpolation().interp_vector(k), c->levels[0]->d_lex_of_site, (int)V, 12, c->stream);
+    else vec_to_lex<double>(st, c->mg64->interpolation().interp_vector(k), c->levels[0]->d_lex_of_site, (int)V, 12, c->stream);
+    DDAMG_HIP_CHECK(hipMemcpyAsync(P_lex + (size_t)k * nel, st, sizeof(double) * nel, hipMemcpyDeviceToHost, c->stream));
+    DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
+  }
+  DDAMG_API_END
+}
+
+int ddamg_hip_get_coarse_operator(ddamg_hip_ctx* c, double* D_lex, double* clover_lex) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && c->setup_done, "setup has not been run");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  if (c->mg32) c->mg32->coarse_op().export_reference(c->levels[1]->geom, D_lex, clover_lex, c->stream);
+  else c->mg64->coarse_op().export_reference(c->levels[1]->geom, D_lex, clover_lex, c->stream);
+  DDAMG_API_END
+}
+
+int ddamg_hip_set_coarse_operator(ddamg_hip_ctx* c, const double* D_lex, const double* clover_lex) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && D_lex && clover_lex, "null argument");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  ensure_mg(c);
+  if (c->mg32) c->mg32->coarse_op().import_reference(c->levels[1]->geom, D_lex, clover_lex, c->stream);
+  else c->mg64->coarse_op().import_reference(c->levels[1]->geom, D_lex, clover_lex, c->stream);
+  DDAMG_API_END
+}
+
+#define MG_CALL(expr32, expr64) do { if (c->mg32) { auto& mg = *c->mg32; typedef float T; (void)sizeof(T); expr32; } else { auto& mg = *c->mg64; typedef double T; (void)sizeof(T); expr64; } } while (0)
+
+static void check_vec(ddamg_hip_ctx* c, const ddamg_hip_vec* v, int level) {
+  DDAMG_REQUIRE(v && v->level == level, "vector lives on the wrong level");
+  DDAMG_REQUIRE(v->precision == (c->mg32 ? 32 : 64), "vector precision does not match the V-cycle precision");
+}
+
+int ddamg_hip_smoother(ddamg_hip_ctx* c, ddamg_hip_vec* phi, const ddamg_hip_vec* eta, int cycles, int initial_guess_zero) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c, "null context");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  ensure_mg(c);
+  check_vec(c, phi, 0); check_vec(c, eta, 0);
+  if (c->mg32) c->mg32->smoother((float*)phi->data, nullptr, (const float*)eta->data, cycles, initial_guess_zero ? NO_RES : RES);
+  else c->mg64->smoother((double*)phi->data, nullptr, (const double*)eta->data, cycles, initial_guess_zero ? NO_RES : RES);
+  DDAMG_API_END
+}
+
+int ddamg_hip_restrict(ddamg_hip_ctx* c, ddamg_hip_vec* coarse, const ddamg_hip_vec* fine) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && c->setup_done, "setup has not been run");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  check_vec(c, coarse, 1); check_vec(c, fine, 0);
+  if (c->mg32) c->mg32->restrict_to((float*)coarse->data, (const float*)fine->data);
+  else c->mg64->restrict_to((double*)coarse->data, (const double*)fine->data);
+  DDAMG_API_END
+}
+
+int ddamg_hip_interpolate(ddamg_hip_ctx* c, ddamg_hip_vec* fine, const ddamg_hip_vec* coarse, int add) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && c->setup_done, "setup has not been run");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  check_vec(c, coarse, 1); check_vec(c, fine, 0);
+  if (c->mg32) c->mg32->interpolate((float*)fine->data, (const float*)coarse->data, add != 0);
+  else c->mg64->interpolate((double*)fine->data, (const double*)coarse->data, add != 0);
+  DDAMG_API_END
+}
+
+int ddamg_hip_coarse_apply(ddamg_hip_ctx* c, ddamg_hip_vec* out, const ddamg_hip_vec* in) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && (c->mg32 || c->mg64), "no coarse operator");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  check_vec(c, out, 1); check_vec(c, in, 1);
+  if (c->mg32) c->mg32->coarse_apply((float*)out->data, (const float*)in->data);
+  else c->mg64->coarse_apply((double*)out->data, (const double*)in->data);
+  DDAMG_API_END
+}
+
+int ddamg_hip_coarse_solve(ddamg_hip_ctx* c, ddamg_hip_vec* x, const ddamg_hip_vec* b, int* iterations) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && (c->mg32 || c->mg64), "no coarse operator");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  check_vec(c, x, 1); check_vec(c, b, 1);
+  int it;
+  if (c->mg32) {
+    DDAMG_HIP_CHECK(hipMemcpyAsync(c->mg32->coarse_b(), b->data, b->bytes, hipMemcpyDeviceToDevice, c->stream));
+    it = c->mg32->coarse_solve();
+    DDAMG_HIP_CHECK(hipMemcpyAsync(x->data, c->mg32->coarse_x(), x->bytes, hipMemcpyDeviceToDevice, c->stream));
+  } else {
+    DDAMG_HIP_CHECK(hipMemcpyAsync(c->mg64->coarse_b(), b->data, b->bytes, hipMemcpyDeviceToDevice, c->stream));
+    it = c->mg64->coarse_solve();
+    DDAMG_HIP_CHECK(hipMemcpyAsync(x->data, c->mg64->coarse_x(), x->bytes, hipMemcpyDeviceToDevice, c->stream));
+  }
+  if (iterations) *iterations = it;
+  DDAMG_API_END
+}
+
+int ddamg_hip_vcycle(ddamg_hip_ctx* c, ddamg_hip_vec* phi, const ddamg_hip_vec* eta) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && c->setup_done, "setup has not been run");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  check_vec(c, phi, 0); check_vec(c, eta, 0);
+  if (c->mg32) c->mg32->vcycle((float*)phi->data, nullptr, (const float*)eta->data, NO_RES);
+  else c->mg64->vcycle((double*)phi->data, nullptr, (const double*)eta->data, NO_RES);
+  DDAMG_API_END
+}
+
+int ddamg_hip_solve(ddamg_hip_ctx* c, double* x_lex, const double* b_lex, double tol, int* iterations, int* coarse_iterations, double* relres) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && x_lex && b_lex, "null argument");
+  DDAMG_REQUIRE(c->have_operator, "no operator set");
+  DDAMG_REQUIRE(c->par.method == 0 || c->setup_done, "setup has not been run");
+  DDAMG_REQUIRE(c->par.mixed_precision <= 1, "mixed_precision 2 (fgmres_MP) is not available in this build");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  ensure_outer(c);
+  const int V = c->levels[0]->geom.V;
+  const size_t nb = sizeof(double) * 24 * V;
+  double* st = c->stage(nb);
+  DDAMG_HIP_CHECK(hipMemcpyAsync(st, b_lex, nb, hipMemcpyHostToDevice, c->stream));
+  vec_from_lex<double>(c->outer.b, st, c->levels[0]->d_lex_of_site, V, 12, c->stream);
+  c->outer.tol = tol > 0 ? tol : c->par.tol;
+  c->outer.initial_guess_zero = true;
+  if (c->mg32) c->mg32->coarse_iter_count = 0;
+  if (c->mg64) c->mg64->coarse_iter_count = 0;
+  const int it = c->outer.solve();
+  // FGMRES_RESTEST: true residual in the outer precision (src/linsolve_generic.c:351-357)
+  const double rr = c->outer.norm_r0 > 0 ? c->outer.true_residual() : 0.0;
+  vec_to_lex<double>(st, c->outer.x, c->levels[0]->d_lex_of_site, V, 12, c->stream);
+  DDAMG_HIP_CHECK(hipMemcpyAsync(x_lex, st, nb, hipMemcpyDeviceToHost, c->stream));
+  DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
+  c->last_iter = it;
+  c->last_coarse_iter = c->mg32 ? c->mg32->coarse_iter_count : (c->mg64 ? c->mg64->coarse_iter_count : 0);
+  c->last_relres = rr;
+  c->last_history = c->outer.history;
+  if (iterations) *iterations = it;
+  if (coarse_iterations) *coarse_iterations = c->last_coarse_iter;
+  if (relres) *relres = rr;
+  DDAMG_API_END
+}
+
+int ddamg_hip_residual_history(ddamg_hip_ctx* c, double* history, int max_len, int* len) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && len, "null argument");
+  const int n = (int)c->last_history.size();
+  *len = n;
+  for (int i = 0; i < n && i < max_len; i++) history[i] = c->last_history[i];
+  DDAMG_API_END
+}
+
+}  // extern "C"

@@ -1,0 +1,38 @@
+// transfer.h -- interpolation / restriction between the fine level (chunked-SoA, 12 dof) and the
+// first coarse level (site-major AoS, n = 2*Nvec dof), and the aggregate-wise Gram-Schmidt that
+// defines the interpolation operator.
+// Reference: interpolate_PRECISION / interpolate3_PRECISION / restrict_PRECISION
+//            src/interpolation_generic.c:93-207 (phi += P phi_c, phi = P phi_c, phi_c = P^dagger phi),
+//            gram_schmidt_on_aggregates_PRECISION src/linalg_generic.c:400-455,
+//            define_interpolation_PRECISION_operator src/interpolation_generic.c:74-90.
+//
+// The interpolation operator is NOT stored in a separate transposed layout as in the reference:
+// P is simply the Nvec orthonormalised test vectors in the ordinary fine vector layout.  Sites are
+// ordered aggregate-major, so aggregate a is the contiguous site range [a*S, (a+1)*S) in every
+// chunk row, and chirality h lives in chunks 3h..3h+2 (fp32).  Coarse dof index = h*Nvec + j.
+#pragma once
+#include "common.h"
+#include "geometry.h"
+
+namespace ddamg {
+
+template <typename T>
+struct Interpolation {
+  int V = 0, nvec = 0, num_aggs = 0, agg_sites = 0;
+  size_t pstride = 0;      // elements between consecutive vectors
+  T* tv = nullptr;         // test vectors   [nvec][24*V]
+  T* P = nullptr;          // orthonormalised interpolation vectors [nvec][24*V]
+  int* agg_csite = nullptr; // [num_aggs] coarse-level site index of every aggregate
+  void alloc(const Geometry& g, const Geometry& gc, int nvec_);
+  void release();
+  T* test_vector(int j) const { return tv + pstride * j; }
+  T* interp_vector(int j) const { return P + pstride * j; }
+  // P <- tv, then modified Gram-Schmidt per aggregate and chirality
+  void orthonormalize(hipStream_t st);
+  // phi_c = P^dagger phi          (coarse AoS, n = 2*nvec complex per coarse site = aggregate)
+  void restrict_to(T* phi_c, const T* phi, hipStream_t st) const;
+  // phi (+)= P phi_c
+  void interpolate(T* phi, const T* phi_c, bool add, hipStream_t st) const;
+};
+
+}  // namespace ddamg

@@ -1,0 +1,251 @@
+// transfer.hip -- see transfer.h.  All three kernels stream the interpolation vectors once
+// (Nvec * 96 B per fine site in fp32: the HBM-bound term) with one workgroup per aggregate.
+#include "transfer.h"
+
+namespace ddamg {
+
+static constexpr int TILE = 8;  // interpolation vectors handled per register tile in restrict
+
+static inline int wg_threads(int agg_sites) {
+  int t = 64;
+  while (t < agg_sites && t < 256) t *= 2;
+  return t;
+}
+
+template <typename T>
+void Interpolation<T>::alloc(const Geometry& g, const Geometry& gc, int nvec_) {
+  V = g.V; nvec = nvec_; num_aggs = g.num_aggs; agg_sites = g.agg_sites;
+  DDAMG_REQUIRE(gc.V == g.num_aggs, "coarse lattice does not match the aggregate decomposition");
+  // aggregate a (lexicographic in aggregate coordinates) is coarse lattice point with the same
+  // coordinates; its index in the coarse level's own site ordering:
+  DDAMG_HIP_CHECK(hipMalloc(&agg_csite, sizeof(int) * num_aggs));
+  DDAMG_HIP_CHECK(hipMemcpy(agg_csite, gc.site_of_lex.data(), sizeof(int) * num_aggs, hipMemcpyHostToDevice));
+  pstride = (size_t)24 * V;
+  DDAMG_HIP_CHECK(hipMalloc(&tv, sizeof(T) * pstride * nvec));
+  DDAMG_HIP_CHECK(hipMalloc(&P, sizeof(T) * pstride * nvec));
+  DDAMG_HIP_CHECK(hipMemset(tv, 0, sizeof(T) * pstride * nvec));
+  DDAMG_HIP_CHECK(hipMemset(P, 0, sizeof(T) * pstride * nvec));
+}
+template <typename T>
+void Interpolation<T>::release() {
+  if (tv) (void)hipFree(tv);
+  if (P) (void)hipFree(P);
+  if (agg_csite) (void)hipFree(agg_csite);
+  tv = P = nullptr; agg_csite = nullptr;
+}
+
+// ---- restriction: phi_c[a][h*N + j] = sum_{x in a, d in chirality h} conj(P_j(x,d)) phi(x,d) ------
+template <typename T>
+__global__ void restrict_kernel(T* __restrict__ phi_c, const T* __restrict__ phi, const T* __restrict__ P, size_t pstride,
+                                int nvec, int V, int agg_sites, const int* __restrict__ agg_csite) {
+  __shared__ double red[4 * TILE * 4];  // [value][wave]
+  const int a = blockIdx.x, nt = blockDim.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = nt >> 6;
+  const size_t s0 = (size_t)a * agg_sites;
+  for (int j0 = 0; j0 < nvec; j0 += TILE) {
+    const int jt = min(TILE, nvec - j0);
+    T acc[TILE][4];
+#pragma unroll
+    for (int t = 0; t < TILE; t++) { acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0; }
+    for (int i = threadIdx.x; i < agg_sites; i += nt) {
+      T f[24];
+      load_site<T, 24>(phi, V, s0 + i, f);
+#pragma unroll
+      for (int t = 0; t < TILE; t++) {
+        if (t < jt) {
+          T p[24];
+          load_site<T, 24>(P + (size_t)(j0 + t) * pstride, V, s0 + i, p);
+#pragma unroll
+          for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int d = 0; d < 6; d++) {
+              const int k = 2 * (6 * h + d);
+              acc[t][2 * h]     += p[k] * f[k] + p[k + 1] * f[k + 1];      // Re conj(p) f
+              acc[t][2 * h + 1] += p[k] * f[k + 1] - p[k + 1] * f[k];      // Im conj(p) f
+            }
+        }
+      }
+    }
+    // block reduction of 4*TILE values
+#pragma unroll
+    for (int t = 0; t < TILE; t++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        double v = (double)acc[t][q];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if (lane == 0) red[(t * 4 + q) * 4 + wv] = v;
+      }
+    __syncthreads();
+    if (threadIdx.x < 4 * jt) {
+      const int t = threadIdx.x >> 2, q = threadIdx.x & 3;  // q: 0 re(h=0) 1 im(h=0) 2 re(h=1) 3 im(h=1)
+      double v = 0;
+      for (int w = 0; w < nw; w++) v += red[(t * 4 + q) * 4 + w];
+      const int h = q >> 1, ri = q & 1;
+      phi_c[((size_t)agg_csite[a] * 2 * nvec + (size_t)h * nvec + j0 + t) * 2 + ri] = (T)v;
+    }
+    __syncthreads();
+  }
+}
+
+template <typename T>
+void Interpolation<T>::restrict_to(T* phi_c, const T* phi, hipStream_t st) const {
+  hipLaunchKernelGGL(restrict_kernel<T>, dim3(num_aggs), dim3(wg_threads(agg_sites)), 0, st, phi_c, phi, P, pstride, nvec, V, agg_sites, agg_csite);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
+// ---- interpolation: phi(x,d) (+)= sum_j P_j(x,d) phi_c[a][h(d)*N + j] -------------------------------
+template <typename T>
+__global__ void interpolate_kernel(T* __restrict__ phi, const T* __restrict__ phi_c, const T* __restrict__ P, size_t pstride,
+                                   int nvec, int V, int agg_sites, int add, const int* __restrict__ agg_csite) {
+  extern __shared__ char smem_raw[];
+  T* pc = reinterpret_cast<T*>(smem_raw);  // [2*nvec][2]
+  const int a = blockIdx.x, nt = blockDim.x;
+  const size_t s0 = (size_t)a * agg_sites;
+  for (int k = threadIdx.x; k < 4 * nvec; k += nt) pc[k] = phi_c[(size_t)agg_csite[a] * 4 * nvec + k];
+  __syncthreads();
+  for (int i = threadIdx.x; i < agg_sites; i += nt) {
+    T f[24];
+    if (add) load_site<T, 24>(phi, V, s0 + i, f);
+    else {
+#pragma unroll
+      for (int k = 0; k < 24; k++) f[k] = 0;
+    }
+    for (int j = 0; j < nvec; j++) {
+      T p[24];
+      load_site<T, 24>(P + (size_t)j * pstride, V, s0 + i, p);
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const T cr = pc[2 * (h * nvec + j)], ci = pc[2 * (h * nvec + j) + 1];
+#pragma unroll
+        for (int d = 0; d < 6; d++) {
+          const int k = 2 * (6 * h + d);
+          f[k]     += cr * p[k] - ci * p[k + 1];
+          f[k + 1] += cr * p[k + 1] + ci * p[k];
+        }
+      }
+    }
+    store_site<T, 24>(phi, V, s0 + i, f);
+  }
+}
+
+template <typename T>
+void Interpolation<T>::interpolate(T* phi, const T* phi_c, bool add, hipStream_t st) const {
+  hipLaunchKernelGGL(interpolate_kernel<T>, dim3(num_aggs), dim3(wg_threads(agg_sites)), sizeof(T) * 4 * nvec, st,
+                     phi, phi_c, P, pstride, nvec, V, agg_sites, add ? 1 : 0, agg_csite);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
+// ---- modified Gram-Schmidt per aggregate and chirality --------------------------------------------
+// all threads receive the sum of NV values over the workgroup
+template <int NV>
+__device__ __forceinline__ void wg_allreduce(double (&v)[NV], double* red /* [NV][4] */, int nw) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_xor(v[k], o, 64);
+  }
+  if (nw > 1) {
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+      for (int k = 0; k < NV; k++) red[k * 4 + wv] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) {
+      double s = 0;
+      for (int w = 0; w < nw; w++) s += red[k * 4 + w];
+      v[k] = s;
+    }
+  }
+}
+
+// SPT = sites per thread (agg_sites <= 256*SPT)
+template <typename T, int SPT>
+__global__ void gs_aggregates_kernel(T* __restrict__ P, size_t pstride, int nvec, int V, int agg_sites) {
+  __shared__ double red[4 * 4];
+  const int a = blockIdx.x, nt = blockDim.x, nw = nt >> 6;
+  const size_t s0 = (size_t)a * agg_sites;
+  for (int k1 = 0; k1 < nvec; k1++) {
+    T v[SPT][24];
+#pragma unroll
+    for (int q = 0; q < SPT; q++) {
+      const int i = threadIdx.x + q * nt;
+      if (i < agg_sites) load_site<T, 24>(P + (size_t)k1 * pstride, V, s0 + i, v[q]);
+      else {
+#pragma unroll
+        for (int k = 0; k < 24; k++) v[q][k] = 0;
+      }
+    }
+    for (int k2 = 0; k2 < k1; k2++) {
+      T u[SPT][24];
+      double al[4] = {0, 0, 0, 0};
+#pragma unroll
+      for (int q = 0; q < SPT; q++) {
+        const int i = threadIdx.x + q * nt;
+        if (i < agg_sites) load_site<T, 24>(P + (size_t)k2 * pstride, V, s0 + i, u[q]);
+        else {
+#pragma unroll
+          for (int k = 0; k < 24; k++) u[q][k] = 0;
+        }
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+#pragma unroll
+          for (int d = 0; d < 6; d++) {
+            const int k = 2 * (6 * h + d);
+            al[2 * h]     += (double)(u[q][k] * v[q][k] + u[q][k + 1] * v[q][k + 1]);
+            al[2 * h + 1] += (double)(u[q][k] * v[q][k + 1] - u[q][k + 1] * v[q][k]);
+          }
+      }
+      wg_allreduce<4>(al, red, nw);
+#pragma unroll
+      for (int q = 0; q < SPT; q++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const T ar = (T)al[2 * h], ai = (T)al[2 * h + 1];
+#pragma unroll
+          for (int d = 0; d < 6; d++) {
+            const int k = 2 * (6 * h + d);
+            v[q][k]     -= ar * u[q][k] - ai * u[q][k + 1];
+            v[q][k + 1] -= ar * u[q][k + 1] + ai * u[q][k];
+          }
+        }
+    }
+    double nr[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < SPT; q++)
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int d = 0; d < 12; d++) nr[h] += (double)(v[q][12 * h + d] * v[q][12 * h + d]);
+    wg_allreduce<2>(nr, red, nw);
+    const T n0 = (T)(1.0 / sqrt(nr[0])), n1 = (T)(1.0 / sqrt(nr[1]));
+#pragma unroll
+    for (int q = 0; q < SPT; q++) {
+      const int i = threadIdx.x + q * nt;
+#pragma unroll
+      for (int d = 0; d < 12; d++) { v[q][d] *= n0; v[q][12 + d] *= n1; }
+      if (i < agg_sites) store_site<T, 24>(P + (size_t)k1 * pstride, V, s0 + i, v[q]);
+    }
+    __syncthreads();  // make this vector visible to the loads of the next k1 (same workgroup, global memory)
+  }
+}
+
+template <typename T>
+void Interpolation<T>::orthonormalize(hipStream_t st) {
+  DDAMG_HIP_CHECK(hipMemcpyAsync(P, tv, sizeof(T) * pstride * nvec, hipMemcpyDeviceToDevice, st));
+  const int nt = wg_threads(agg_sites);
+  const int spt = (agg_sites + nt - 1) / nt;
+  if (spt == 1) hipLaunchKernelGGL((gs_aggregates_kernel<T, 1>), dim3(num_aggs), dim3(nt), 0, st, P, pstride, nvec, V, agg_sites);
+  else if (spt == 2) hipLaunchKernelGGL((gs_aggregates_kernel<T, 2>), dim3(num_aggs), dim3(nt), 0, st, P, pstride, nvec, V, agg_sites);
+  else if (spt <= 4) hipLaunchKernelGGL((gs_aggregates_kernel<T, 4>), dim3(num_aggs), dim3(nt), 0, st, P, pstride, nvec, V, agg_sites);
+  else DDAMG_REQUIRE(false, "aggregates larger than 1024 sites are not supported by the Gram-Schmidt kernel");
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
+template struct Interpolation<float>;
+template struct Interpolation<double>;
+
+}  // namespace ddamg

@@ -83,6 +83,52 @@ int ddamg_hip_vec_download(ddamg_hip_ctx* ctx, const ddamg_hip_vec* v, double* h
 /* replaces d_plus_clover_float / d_plus_clover_double (src/dirac_generic.c:159-277) */
 int ddamg_hip_dirac_apply(ddamg_hip_ctx* ctx, ddamg_hip_vec* out, const ddamg_hip_vec* in);
 
+/* ---- multigrid hierarchy ------------------------------------------------------------------ */
+/* replaces method_setup + method_update (src/init.c:134-374; dd_alpha_amg_setup, src/dd_alpha_amg.c:254-273):
+ * random test vectors (libc rand(), as vector_PRECISION_define_random) -> smoother passes -> aggregate-wise
+ * Gram-Schmidt -> Galerkin coarse operator, then `setup_iterations` bootstrap iterations
+ * (inv_iter_inv_fcycle, src/setup_generic.c:441-503).  setup_iterations < 0: use params.setup_iter[0]. */
+int ddamg_hip_setup(ddamg_hip_ctx* ctx, int setup_iterations, int* coarse_iterations);
+/* replaces method_update / dd_alpha_amg_setup_update (src/dd_alpha_amg.c:288-310) */
+int ddamg_hip_setup_update(ddamg_hip_ctx* ctx, int iterations, int* coarse_iterations);
+/* replaces the "interpolation: 4" path (test vectors from outside, src/setup_generic.c:131-160 + re_setup :278-321):
+ * tv_lex = [num_vect][V][12] complex fp64 lexicographic; orthonormalised != 0: the vectors are already
+ * the aggregate-orthonormal interpolation vectors and are used as they are. */
+int ddamg_hip_set_test_vectors(ddamg_hip_ctx* ctx, const double* tv_lex, int orthonormalised);
+int ddamg_hip_get_interpolation(ddamg_hip_ctx* ctx, double* P_lex);
+/* coarse operator in the reference's storage, lexicographic coarse sites: D [Vc][4][n*n] complex as blocks
+ * A,C,B,D column-major, clover [Vc][n(n+1)/2] complex packed (src/coarse_operator_generic.h:124-143,
+ * src/coarse_operator_generic.c:109-111) */
+int ddamg_hip_get_coarse_operator(ddamg_hip_ctx* ctx, double* D_lex, double* clover_lex);
+int ddamg_hip_set_coarse_operator(ddamg_hip_ctx* ctx, const double* D_lex, const double* clover_lex);
+
+/* ---- hot-path pieces, vectors in the V-cycle precision (32 unless mixed_precision == 0) ------ */
+/* replaces smoother_PRECISION / red_black_schwarz_PRECISION (src/vcycle_generic.c:25-88,
+ * src/schwarz_generic.c:1260-1431); initial_guess_zero != 0 is the reference's _NO_RES */
+int ddamg_hip_smoother(ddamg_hip_ctx* ctx, ddamg_hip_vec* phi, const ddamg_hip_vec* eta, int cycles, int initial_guess_zero);
+/* replaces restrict_PRECISION / interpolate3_PRECISION (add == 0) / interpolate_PRECISION (add != 0)
+ * (src/interpolation_generic.c:93-207) */
+int ddamg_hip_restrict(ddamg_hip_ctx* ctx, ddamg_hip_vec* coarse, const ddamg_hip_vec* fine);
+int ddamg_hip_interpolate(ddamg_hip_ctx* ctx, ddamg_hip_vec* fine, const ddamg_hip_vec* coarse, int add);
+/* replaces apply_coarse_operator_PRECISION (src/coarse_operator_generic.c:383-394) */
+int ddamg_hip_coarse_apply(ddamg_hip_ctx* ctx, ddamg_hip_vec* out, const ddamg_hip_vec* in);
+/* replaces coarse_solve_odd_even_PRECISION (src/coarse_oddeven_generic.c:1139-1159) */
+int ddamg_hip_coarse_solve(ddamg_hip_ctx* ctx, ddamg_hip_vec* x, const ddamg_hip_vec* b, int* iterations);
+/* replaces vcycle_PRECISION(phi, NULL, eta, _NO_RES) (src/vcycle_generic.c:91-141) */
+int ddamg_hip_vcycle(ddamg_hip_ctx* ctx, ddamg_hip_vec* phi, const ddamg_hip_vec* eta);
+
+/* replaces wilson_driver -> fgmres_double + preconditioner (src/top_level.c:64-104,
+ * src/linsolve_generic.c:219-413): host vectors lexicographic fp64.  tol <= 0: params.tol.
+ * relres = true relative residual ||b - D x|| / ||b|| recomputed in fp64 (FGMRES_RESTEST). */
+int ddamg_hip_solve(ddamg_hip_ctx* ctx, double* x_lex, const double* b_lex, double tol,
+                    int* iterations, int* coarse_iterations, double* relres);
+/* Arnoldi residual estimates gamma_{j+1}/||r0|| of the last solve (the reference prints them under -DTRACK_RES) */
+int ddamg_hip_residual_history(ddamg_hip_ctx* ctx, double* history, int max_len, int* len);
+
+/* device site ordering of a level: lex_of_site[s] = lexicographic index of device site s (the role of the
+ * reference's translation_table, src/data_layout.c:152-251) */
+int ddamg_hip_get_site_order(ddamg_hip_ctx* ctx, int level, int* lex_of_site);
+
 /* HIP-event timing on the context stream (bench.py's live roofline measurement) */
 int ddamg_hip_timer_begin(ddamg_hip_ctx* ctx);
 int ddamg_hip_timer_end(ddamg_hip_ctx* ctx, float* milliseconds);

@@ -91,6 +91,10 @@ def run_case(name):
         arrays["ref_log_residual_history"] = np.array(hist)
         if keep is not None:
             arrays = {k: v for k, v in arrays.items() if k in keep_now or k.startswith("ref_log")}
+        # arrays whose values are exactly representable in fp32 (dumps of float data) are stored as fp32
+        for k, v in list(arrays.items()):
+            if v.dtype == np.float64 and v.size > 4096 and np.array_equal(v, v.astype(np.float32).astype(np.float64)):
+                arrays[k] = v.astype(np.float32)
         os.makedirs(GOLD, exist_ok=True)
         out = os.path.join(GOLD, f"ref_{name}.npz")
         np.savez_compressed(out, **arrays)

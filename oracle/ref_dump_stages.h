@@ -51,7 +51,167 @@ static void dump_fine_operator(level_struct *l, struct Thread *threading)
   FREE(eta, complex_double, l->vector_size);
 }
 
+/* ---- ordering helpers ------------------------------------------------------------------- */
+/* position of lexicographic site `lx` inside a vector of level lv: depth 0 uses the Schwarz
+   layout (translation_table, src/schwarz_generic.c:371-486); the coarsest level with odd-even
+   preconditioning uses [even lex][odd lex] (src/gathering_generic.c:161-183) */
+static int *level_order(level_struct *lv)
+{
+  int n = lv->num_inner_lattice_sites, *ord = malloc(sizeof(int) * n);
+  if (lv->depth == 0) {
+    for (int i = 0; i < n; i++) ord[i] = lv->s_float.op.translation_table[i];
+  } else {
+    int *le = lv->local_lattice, i = 0;
+    for (int par = 0; par < 2; par++)
+      for (int t = 0; t < le[T]; t++) for (int z = 0; z < le[Z]; z++)
+        for (int y = 0; y < le[Y]; y++) for (int x = 0; x < le[X]; x++)
+          if ((t + z + y + x) % 2 == par) { ord[((t * le[Z] + z) * le[Y] + y) * le[X] + x] = i; i++; }
+  }
+  return ord;
+}
+/* float level vector -> lexicographic double */
+static void to_lex_f(double *out, vector_float v, int *ord, int nsites, int nv)
+{
+  for (int s = 0; s < nsites; s++)
+    for (int k = 0; k < nv; k++) {
+      out[2 * ((size_t)s * nv + k)] = crealf(v[(size_t)ord[s] * nv + k]);
+      out[2 * ((size_t)s * nv + k) + 1] = cimagf(v[(size_t)ord[s] * nv + k]);
+    }
+}
+static void from_lex_f(vector_float v, uint64_t seed, int *ord, int nsites, int nv, double *keep)
+{
+  for (int s = 0; s < nsites; s++)
+    for (int k = 0; k < nv; k++) {
+      size_t i = (size_t)s * nv + k;
+      double re = urand(seed, 2 * i), im = urand(seed, 2 * i + 1);
+      v[(size_t)ord[s] * nv + k] = (float)re + I * (float)im;
+      if (keep) { keep[2 * i] = (float)re; keep[2 * i + 1] = (float)im; }
+    }
+}
+
+/* ---- stage 2: two-level hierarchy and every hot-path function on it ---------------------- */
+static void dump_two_level(level_struct *l, struct Thread *threading)
+{
+  if (!(g.method == 2 && g.mixed_precision == 1 && g.num_levels == 2 && l->next_level)) return;
+  char sh[100];
+  level_struct *lc = l->next_level;
+  const int n0 = l->num_inner_lattice_sites, nc = lc->num_inner_lattice_sites;
+  const int nvec = l->num_eig_vect, m = lc->num_lattice_site_var;
+  int *ord0 = level_order(l), *ordc = level_order(lc);
+  double *buf = malloc(sizeof(double) * 2 * ((size_t)n0 * 12 > (size_t)nc * m ? (size_t)n0 * 12 : (size_t)nc * m));
+  double *buf2 = malloc(sizeof(double) * 2 * (size_t)n0 * 12);
+
+  /* interpolation vectors after Gram-Schmidt on aggregates (src/setup_generic.c:268-273) and the
+     raw test vectors they were built from */
+  {
+    double *P = malloc(sizeof(double) * 2 * (size_t)nvec * n0 * 12), *Tv = malloc(sizeof(double) * 2 * (size_t)nvec * n0 * 12);
+    for (int j = 0; j < nvec; j++) {
+      to_lex_f(P + 2 * (size_t)j * n0 * 12, l->is_float.interpolation[j], ord0, n0, 12);
+      to_lex_f(Tv + 2 * (size_t)j * n0 * 12, l->is_float.test_vector[j], ord0, n0, 12);
+    }
+    sprintf(sh, "%d,%d,12,2", nvec, n0);
+    dump("interp_vectors", "f8", P, sizeof(double) * 2 * (size_t)nvec * n0 * 12, sh);
+    dump("test_vectors", "f8", Tv, sizeof(double) * 2 * (size_t)nvec * n0 * 12, sh);
+    free(P); free(Tv);
+  }
+  /* coarse operator in the reference's own storage, lexicographic coarse sites
+     (src/coarse_operator_generic.c:53-205): D [site][mu][A,C,B,D blocks column-major],
+     clover packed [triu(A), triu(D), B] column-major */
+  {
+    size_t nD = (size_t)4 * m * m * nc, nC = (size_t)(m * (m + 1) / 2) * nc;
+    double *t = malloc(sizeof(double) * 2 * nD);
+    for (size_t i = 0; i < nD; i++) { t[2 * i] = crealf(lc->op_float.D[i]); t[2 * i + 1] = cimagf(lc->op_float.D[i]); }
+    sprintf(sh, "%d,4,%d,2", nc, m * m); dump("coarse_D", "f8", t, sizeof(double) * 2 * nD, sh);
+    for (size_t i = 0; i < nC; i++) { t[2 * i] = crealf(lc->op_float.clover[i]); t[2 * i + 1] = cimagf(lc->op_float.clover[i]); }
+    sprintf(sh, "%d,%d,2", nc, m * (m + 1) / 2); dump("coarse_clover", "f8", t, sizeof(double) * 2 * nC, sh);
+    free(t);
+  }
+  vector_float f1 = NULL, f2 = NULL, f3 = NULL, c1 = NULL, c2 = NULL;
+  MALLOC(f1, complex_float, l->schwarz_vector_size); MALLOC(f2, complex_float, l->schwarz_vector_size);
+  MALLOC(f3, complex_float, l->schwarz_vector_size);
+  MALLOC(c1, complex_float, lc->vector_size); MALLOC(c2, complex_float, lc->vector_size);
+
+  /* restrict / interpolate (src/interpolation_generic.c:93-207) */
+  from_lex_f(f1, 2001, ord0, n0, 12, buf);
+  sprintf(sh, "%d,12,2", n0); dump("restrict_in", "f8", buf, sizeof(double) * 2 * n0 * 12, sh);
+  restrict_float(c1, f1, l, threading);
+  to_lex_f(buf, c1, ordc, nc, m);
+  sprintf(sh, "%d,%d,2", nc, m); dump("restrict_out", "f8", buf, sizeof(double) * 2 * nc * m, sh);
+  from_lex_f(c1, 2002, ordc, nc, m, buf);
+  dump("interpolate_in", "f8", buf, sizeof(double) * 2 * nc * m, sh);
+  interpolate3_float(f1, c1, l, threading);
+  to_lex_f(buf, f1, ord0, n0, 12);
+  sprintf(sh, "%d,12,2", n0); dump("interpolate_out", "f8", buf, sizeof(double) * 2 * n0 * 12, sh);
+
+  /* coarse operator apply (src/coarse_operator_generic.c:383-394) */
+  from_lex_f(c1, 2003, ordc, nc, m, buf);
+  sprintf(sh, "%d,%d,2", nc, m); dump("coarse_apply_in", "f8", buf, sizeof(double) * 2 * nc * m, sh);
+  apply_coarse_operator_float(c2, c1, &(lc->s_float.op), lc, threading);
+  to_lex_f(buf, c2, ordc, nc, m);
+  dump("coarse_apply_out", "f8", buf, sizeof(double) * 2 * nc * m, sh);
+
+  /* coarsest-level odd-even solve (src/coarse_oddeven_generic.c:1139-1159) */
+  from_lex_f(lc->p_float.b, 2004, ordc, nc, m, buf);
+  dump("coarse_solve_in", "f8", buf, sizeof(double) * 2 * nc * m, sh);
+  { int before = g.coarse_iter_count;
+    coarse_solve_odd_even_float(&(lc->p_float), &(lc->oe_op_float), lc, threading);
+    int its[1] = { g.coarse_iter_count - before }; dump("coarse_solve_iters", "i4", its, sizeof its, "1"); }
+  to_lex_f(buf, lc->p_float.x, ordc, nc, m);
+  dump("coarse_solve_out", "f8", buf, sizeof(double) * 2 * nc * m, sh);
+
+  /* SAP smoother (src/schwarz_generic.c:1260-1431): from zero (_NO_RES) and with initial guess (_RES) */
+  sprintf(sh, "%d,12,2", n0);
+  from_lex_f(f1, 2005, ord0, n0, 12, buf);
+  dump("smoother_eta", "f8", buf, sizeof(double) * 2 * n0 * 12, sh);
+  for (int cyc = 1; cyc <= 3; cyc++) {
+    char nm[64];
+    smoother_float(f2, NULL, f1, cyc, _NO_RES, _NO_SHIFT, l, threading);
+    to_lex_f(buf, f2, ord0, n0, 12);
+    sprintf(nm, "smoother_nores_out_c%d", cyc); dump(nm, "f8", buf, sizeof(double) * 2 * n0 * 12, sh);
+  }
+  from_lex_f(f2, 2006, ord0, n0, 12, buf2);
+  dump("smoother_phi0", "f8", buf2, sizeof(double) * 2 * n0 * 12, sh);
+  smoother_float(f2, NULL, f1, 2, _RES, _NO_SHIFT, l, threading);
+  to_lex_f(buf, f2, ord0, n0, 12);
+  dump("smoother_res_out_c2", "f8", buf, sizeof(double) * 2 * n0 * 12, sh);
+
+  /* V-cycle (src/vcycle_generic.c:91-141) and the fp64 wrapper (src/preconditioner.c:25-69) */
+  from_lex_f(f1, 2007, ord0, n0, 12, buf);
+  dump("vcycle_eta", "f8", buf, sizeof(double) * 2 * n0 * 12, sh);
+  vcycle_float(f2, NULL, f1, _NO_RES, l, threading);
+  to_lex_f(buf, f2, ord0, n0, 12);
+  dump("vcycle_out", "f8", buf, sizeof(double) * 2 * n0 * 12, sh);
+
+  /* full solve: rhs deterministic, mixed precision 1 = fgmres_double + preconditioner
+     (src/linsolve_generic.c:219-413) */
+  {
+    fill_vec_double(g.p.b, l->inner_vector_size, 2008);
+    dump("solve_rhs", "f8", g.p.b, sizeof(complex_double) * l->inner_vector_size, sh);
+    g.coarse_iter_count = 0;
+    int it = fgmres_double(&(g.p), l, threading);
+    dump("solve_x", "f8", g.p.x, sizeof(complex_double) * l->inner_vector_size, sh);
+    int meta[2] = { it, g.coarse_iter_count };
+    dump("solve_iters", "i4", meta, sizeof meta, "2");
+    double nr[1] = { g.norm_res }; dump("solve_norm_res", "f8", nr, sizeof nr, "1");
+  }
+  /* probes: the reference's Schwarz site ordering and the order in which
+     vector_PRECISION_define_random consumes libc rand() (src/data_generic.c:42-56) */
+  dump("schwarz_order", "i4", ord0, sizeof(int) * n0, (sprintf(sh, "%d", n0), sh));
+  {
+    srand(12345);
+    vector_float_define_random(f1, 0, 8, l);
+    double pr[16];
+    for (int i = 0; i < 8; i++) { pr[2 * i] = crealf(f1[i]); pr[2 * i + 1] = cimagf(f1[i]); }
+    dump("rng_probe", "f8", pr, sizeof pr, "8,2");
+  }
+  FREE(f1, complex_float, l->schwarz_vector_size); FREE(f2, complex_float, l->schwarz_vector_size);
+  FREE(f3, complex_float, l->schwarz_vector_size);
+  FREE(c1, complex_float, lc->vector_size); FREE(c2, complex_float, lc->vector_size);
+  free(buf); free(buf2); free(ord0); free(ordc);
+}
+
 static void dump_all(level_struct *l, struct Thread *threading)
 {
   dump_fine_operator(l, threading);
+  dump_two_level(l, threading);
 }
