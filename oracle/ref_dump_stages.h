@@ -143,12 +143,17 @@ static void dump_two_level(level_struct *l, struct Thread *threading)
   to_lex_f(buf, f1, ord0, n0, 12);
   sprintf(sh, "%d,12,2", n0); dump("interpolate_out", "f8", buf, sizeof(double) * 2 * n0 * 12, sh);
 
-  /* coarse operator apply (src/coarse_operator_generic.c:383-394) */
-  from_lex_f(c1, 2003, ordc, nc, m, buf);
-  sprintf(sh, "%d,%d,2", nc, m); dump("coarse_apply_in", "f8", buf, sizeof(double) * 2 * nc * m, sh);
-  apply_coarse_operator_float(c2, c1, &(lc->s_float.op), lc, threading);
-  to_lex_f(buf, c2, ordc, nc, m);
-  dump("coarse_apply_out", "f8", buf, sizeof(double) * 2 * nc * m, sh);
+  /* coarse operator apply (src/coarse_operator_generic.c:383-394) with the lexicographically ordered
+     operator lc->op_float (its D, clover and neighbour table are all lexicographic; the gathered copy
+     lc->s_float.op holds even-odd ordered couplings and is only used through lc->oe_op_float) */
+  {
+    size_t i;
+    for (i = 0; i < (size_t)nc * m; i++) { double re = urand(2003, 2 * i), im = urand(2003, 2 * i + 1); c1[i] = (float)re + I * (float)im; buf[2 * i] = (float)re; buf[2 * i + 1] = (float)im; }
+    sprintf(sh, "%d,%d,2", nc, m); dump("coarse_apply_in", "f8", buf, sizeof(double) * 2 * nc * m, sh);
+    apply_coarse_operator_float(c2, c1, &(lc->op_float), lc, threading);
+    for (i = 0; i < (size_t)nc * m; i++) { buf[2 * i] = crealf(c2[i]); buf[2 * i + 1] = cimagf(c2[i]); }
+    dump("coarse_apply_out", "f8", buf, sizeof(double) * 2 * nc * m, sh);
+  }
 
   /* coarsest-level odd-even solve (src/coarse_oddeven_generic.c:1139-1159) */
   from_lex_f(lc->p_float.b, 2004, ordc, nc, m, buf);

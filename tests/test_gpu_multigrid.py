@@ -137,6 +137,15 @@ def test_coarse_apply(gold4, refop_ctx):
     assert relerr(y.download(), gold4["coarse_apply_out"]) < TOL_KERNEL
 
 
+def test_galerkin_identity(gold4, ref_ctx):
+    """reference self-check "( P* D P - D_c ) phi_c" (src/coarse_operator_generic.c:482-500)"""
+    c = ref_ctx.vector(1, 32).upload(gold4["coarse_apply_in"]); y = ref_ctx.vector(1, 32); y2 = ref_ctx.vector(1, 32)
+    f = ref_ctx.vector(0, 32); Df = ref_ctx.vector(0, 32)
+    ref_ctx.coarse_apply(y, c)
+    ref_ctx.interpolate(f, c, add=False); ref_ctx.dirac_apply(Df, f); ref_ctx.restrict(y2, Df)
+    assert relerr(y.download(), y2.download()) < 5e-6
+
+
 def test_coarse_solve(gold4, refop_ctx):
     b = refop_ctx.vector(1, 32).upload(gold4["coarse_solve_in"]); x = refop_ctx.vector(1, 32)
     it = refop_ctx.coarse_solve(x, b)
