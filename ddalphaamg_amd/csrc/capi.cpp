@@ -148,8 +148,8 @@ int ddamg_hip_set_operator(ddamg_hip_ctx* c, const double* D_lex, const double* 
   DDAMG_REQUIRE(c && D_lex && clover_lex, "null argument");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
   const Geometry& g = c->levels[0]->geom;
-  c->D_host.assign(D_lex, D_lex + (size_t)g.V * 72);
-  c->clover_host.assign(clover_lex, clover_lex + (size_t)g.V * 84);
+  if (D_lex != c->D_host.data()) c->D_host.assign(D_lex, D_lex + (size_t)g.V * 72);
+  if (clover_lex != c->clover_host.data()) c->clover_host.assign(clover_lex, clover_lex + (size_t)g.V * 84);
   upload_operator(c);
   DDAMG_API_END
 }

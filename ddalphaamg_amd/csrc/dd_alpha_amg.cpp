@@ -1,0 +1,336 @@
+// dd_alpha_amg.cpp -- the reference's library interface (include/dd_alpha_amg.h) as thin glue over the
+// C-ABI of the HIP path (include/ddamg_hip.h).  Reference: src/dd_alpha_amg.c:24-404 (entry points),
+// src/init.c:448-531 (.ini reader), :817-901 (parameter struct -> internal T,Z,Y,X order and the
+// hard-wired mixed_precision 1 / method 2 / odd-even 1 / K-cycle 5,2,0.1 of the struct path).
+#include "context.h"
+#include "../../include/dd_alpha_amg.h"
+#include "../../include/dd_alpha_amg_setup_status.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+extern "C" int ddamg_hip_preconditioner(ddamg_hip_ctx* c, double* out_lex, const double* in_lex);
+
+namespace {
+
+struct State {
+  bool inited = false;
+  ddamg_hip_ctx* ctx = nullptr;
+  dd_alpha_amg_par par;
+  ddamg_hip_params hp;
+  dd_alpha_amg_setup_status status{0, 0};
+  int discard_setup_after = 0, update_setup_after = 0;
+  double mass_for_next_solve = 0, current_mass = 0;
+  bool setup_done = false, conf_set = false, fields_dirty = false;
+  int V = 0;
+} S;
+
+// error0 of the reference prints and calls MPI_Abort (src/main.h:424-439): fatal, no error codes
+[[noreturn]] void fatal(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt);
+  fprintf(stderr, "\x1b[31merror: ");
+  vfprintf(stderr, fmt, ap);
+  fprintf(stderr, "\x1b[0m\n");
+  va_end(ap);
+  fflush(stderr);
+  abort();
+}
+void check(int rc, const char* what) { if (rc) fatal("%s: %s", what, ddamg_hip_last_error()); }
+
+// ---- .ini reader: first line containing the key, values after it (src/init.c:448-531) ---------------
+struct Ini {
+  std::vector<std::string> lines;
+  bool load(const char* path) {
+    FILE* f = fopen(path, "r");
+    if (!f) return false;
+    char buf[2048];
+    while (fgets(buf, sizeof buf, f)) lines.push_back(buf);
+    fclose(f);
+    return true;
+  }
+  const char* find(const std::string& key) const {
+    for (auto& l : lines) { size_t p = l.find(key); if (p != std::string::npos) return l.c_str() + p + key.size(); }
+    return nullptr;
+  }
+  bool geti(const std::string& key, int* v, int n = 1) const {
+    const char* s = find(key); if (!s) return false;
+    for (int i = 0; i < n; i++) { char* e; long x = strtol(s, &e, 10); if (e == s) return false; v[i] = (int)x; s = e; }
+    return true;
+  }
+  bool getd(const std::string& key, double* v) const {
+    const char* s = find(key); if (!s) return false;
+    char* e; double x = strtod(s, &e); if (e == s) return false; *v = x; return true;
+  }
+};
+
+void params_from_ini(const Ini& ini, ddamg_hip_params& hp, int* anti_pbc) {
+  ddamg_hip_default_params(&hp);
+  ini.geti("number of levels:", &hp.num_levels);
+  int glob[DDAMG_HIP_MAX_LEVELS][4] = {};
+  for (int d = 0; d < hp.num_levels; d++) {
+    char k[64];
+    snprintf(k, sizeof k, "d%d global lattice:", d);
+    if (!ini.geti(k, glob[d], 4)) fatal("parameter \"%s\" missing", k);
+    snprintf(k, sizeof k, "d%d local lattice:", d);
+    if (!ini.geti(k, hp.local_lattice[d], 4)) {
+      if (d == 0) fatal("parameter \"%s\" missing", k);
+      for (int mu = 0; mu < 4; mu++) hp.local_lattice[d][mu] = glob[d][mu] / (glob[0][mu] / hp.local_lattice[0][mu]);
+    }
+    for (int mu = 0; mu < 4; mu++)
+      if (glob[d][mu] != hp.local_lattice[d][mu]) fatal("global and local lattice differ: one process per GPU holds the whole lattice in this build");
+    snprintf(k, sizeof k, "d%d block lattice:", d); ini.geti(k, hp.block_lattice[d], 4);
+    snprintf(k, sizeof k, "d%d post smooth iter:", d); ini.geti(k, &hp.post_smooth_iter[d]);
+    snprintf(k, sizeof k, "d%d block iter:", d); ini.geti(k, &hp.block_iter[d]);
+    snprintf(k, sizeof k, "d%d test vectors:", d); ini.geti(k, &hp.num_vect[d]);
+    snprintf(k, sizeof k, "d%d setup iter:", d); ini.geti(k, &hp.setup_iter[d]);
+  }
+  ini.getd("m0:", &hp.m0); ini.getd("csw:", &hp.csw);
+  ini.getd("tolerance for relative residual:", &hp.tol);
+  ini.geti("iterations between restarts:", &hp.restart);
+  ini.geti("maximum of restarts:", &hp.max_restart);
+  ini.getd("coarse grid tolerance:", &hp.coarse_tol);
+  ini.geti("coarse grid iterations:", &hp.coarse_iter);
+  ini.geti("coarse grid restarts:", &hp.coarse_restart);
+  ini.geti("method:", &hp.method);
+  ini.geti("mixed precision:", &hp.mixed_precision);
+  ini.geti("odd even preconditioning:", &hp.odd_even);
+  ini.geti("kcycle:", &hp.kcycle); ini.geti("kcycle length:", &hp.kcycle_restart);
+  ini.geti("kcycle restarts:", &hp.kcycle_max_restart); ini.getd("kcycle tolerance:", &hp.kcycle_tol);
+  *anti_pbc = 0; ini.geti("antiperiodic boundary conditions:", anti_pbc);
+}
+
+void params_from_struct(const dd_alpha_amg_parameters& a, ddamg_hip_params& hp) {
+  ddamg_hip_default_params(&hp);
+  hp.num_levels = a.number_of_levels;
+  for (int d = 0; d < hp.num_levels && d < MAX_MG_LEVELS; d++) {
+    for (int mu = 0; mu < 4; mu++) {  // X,Y,Z,T -> T,Z,Y,X (src/init.c:821-823)
+      hp.local_lattice[d][mu] = a.local_lattice[d][3 - mu];
+      hp.block_lattice[d][mu] = a.block_lattice[d][3 - mu];
+      if (a.global_lattice[d][3 - mu] != a.local_lattice[d][3 - mu])
+        fatal("global and local lattice differ: one process per GPU holds the whole lattice in this build");
+    }
+    hp.num_vect[d] = a.mg_basis_vectors[d];
+    hp.setup_iter[d] = a.setup_iterations[d];
+    hp.post_smooth_iter[d] = a.post_smooth_iterations[d];
+    hp.block_iter[d] = a.post_smooth_block_iterations[d];
+  }
+  // set_solver_parameters (src/init.c:876-901); the reference disables its outer solver storage here
+  // (g.restart = -1): we keep a usable FGMRES(50) for dd_alpha_amg_wilson_solve
+  hp.mixed_precision = 1; hp.odd_even = 1; hp.method = 2;
+  hp.coarse_iter = a.coarse_grid_iterations; hp.coarse_restart = a.coarse_grid_maximum_number_of_restarts;
+  hp.coarse_tol = a.coarse_grid_tolerance;
+  hp.m0 = a.solver_mass; hp.csw = a.c_sw;
+  hp.restart = 50; hp.max_restart = 100; hp.tol = 1e-10;
+  hp.kcycle = 1; hp.kcycle_restart = 5; hp.kcycle_max_restart = 2; hp.kcycle_tol = 1e-1;
+}
+
+void common_init(const dd_alpha_amg_par& p) {
+  if (S.inited) fatal("dd_alpha_amg_init called twice (one solver instance per process, src/dd_alpha_amg.c:28-33)");
+  if (p.bc == 0) fatal("bc = 0 (Dirichlet/open boundaries) is not supported by the GPU path");
+  S.par = p;
+  S.hp.csw = p.csw;           // g.csw = p.csw (src/dd_alpha_amg.c:103)
+  S.hp.m0 = p.m0;             // l.real_shift = p.m0
+  S.current_mass = S.mass_for_next_solve = p.m0;
+  check(ddamg_hip_create(&S.hp, &S.ctx), "dd_alpha_amg_init");
+  S.V = 1; for (int mu = 0; mu < 4; mu++) S.V *= S.hp.local_lattice[0][mu];
+  S.inited = true;
+}
+
+void reupload_if_dirty() {
+  if (!S.fields_dirty) return;
+  // the caller wrote into the arrays handed out by dd_alpha_amg_get_gauge/clover_pointer
+  check(ddamg_hip_set_operator(S.ctx, S.ctx->D_host.data(), S.ctx->clover_host.data()), "operator update");
+  S.fields_dirty = false;
+}
+
+void shift_mass_if_needed() {
+  if (S.mass_for_next_solve == S.current_mass) return;
+  // shift_update (src/dirac.c:646-668): only the 12 diagonal clover entries change
+  const double diff = S.mass_for_next_solve - S.current_mass;
+  std::vector<double> D = S.ctx->D_host, cl = S.ctx->clover_host;
+  for (int s = 0; s < S.V; s++) for (int k = 0; k < 12; k++) cl[((size_t)s * 42 + k) * 2] += diff;
+  check(ddamg_hip_set_operator(S.ctx, D.data(), cl.data()), "shift update");
+  S.current_mass = S.mass_for_next_solve;
+}
+
+void run_setup(int iterations, int* status) {
+  if (!S.conf_set) fatal("dd_alpha_amg_setup: no configuration set");
+  reupload_if_dirty();
+  int ci = 0;
+  check(ddamg_hip_setup(S.ctx, iterations, &ci), "dd_alpha_amg_setup");
+  S.setup_done = true;
+  S.status.gauge_updates_since_last_setup = 0;
+  S.status.gauge_updates_since_last_setup_update = 0;
+  status[0] = 1; status[1] = ci;   // src/dd_alpha_amg.c:271-272
+}
+
+void run_setup_update(int iterations, int* status) {
+  if (!S.setup_done) fatal("dd_alpha_amg_setup_update: setup has not been run");
+  reupload_if_dirty();
+  int ci = 0;
+  check(ddamg_hip_setup_update(S.ctx, iterations, &ci), "dd_alpha_amg_setup_update");
+  S.status.gauge_updates_since_last_setup_update = 0;
+  status[0] = 1; status[1] = ci;
+}
+
+void gather_vector(std::vector<double>& lex, const double* user) {
+  const int* L = S.hp.local_lattice[0];
+  size_t j = 0;
+  for (int t = 0; t < L[0]; t++) for (int z = 0; z < L[1]; z++) for (int y = 0; y < L[2]; y++) for (int x = 0; x < L[3]; x++) {
+    const int i = S.par.vector_index_fct(t, z, y, x);
+    for (int k = 0; k < 24; k++, j++) lex[j] = user[i + k];
+  }
+}
+void scatter_vector(double* user, const std::vector<double>& lex) {
+  const int* L = S.hp.local_lattice[0];
+  size_t j = 0;
+  for (int t = 0; t < L[0]; t++) for (int z = 0; z < L[1]; z++) for (int y = 0; y < L[2]; y++) for (int x = 0; x < L[3]; x++) {
+    const int i = S.par.vector_index_fct(t, z, y, x);
+    for (int k = 0; k < 24; k++, j++) user[i + k] = lex[j];
+  }
+}
+
+// scale_clover (src/dirac.c:624-644) on a copy; returns true if anything was scaled
+bool scaled_operator(double se, double so, std::vector<double>& cl) {
+  if (se == 1.0 && so == 1.0) return false;
+  const int* L = S.hp.local_lattice[0];
+  cl = S.ctx->clover_host;
+  size_t s = 0;
+  for (int t = 0; t < L[0]; t++) for (int z = 0; z < L[1]; z++) for (int y = 0; y < L[2]; y++) for (int x = 0; x < L[3]; x++, s++) {
+    const double f = ((t + z + y + x) % 2 == 1) ? so : se;
+    for (int k = 0; k < 84; k++) cl[s * 84 + k] *= f;
+  }
+  return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+void dd_alpha_amg_init(dd_alpha_amg_par p) {
+  Ini ini;
+  if (!ini.load(p.param_file_path)) fatal("dd_alpha_amg_init: cannot open parameter file \"%s\"", p.param_file_path);
+  int anti = 0;
+  params_from_ini(ini, S.hp, &anti);
+  common_init(p);
+}
+
+void dd_alpha_amg_init_external_threading(dd_alpha_amg_par p, int n_core, int n_thread) {
+  (void)n_core; (void)n_thread;
+  params_from_struct(p.amg_params, S.hp);
+  S.discard_setup_after = p.amg_params.discard_setup_after;
+  S.update_setup_after = p.amg_params.update_setup_after;
+  S.status.gauge_updates_since_last_setup = p.amg_params.discard_setup_after;
+  S.status.gauge_updates_since_last_setup_update = p.amg_params.update_setup_after;
+  common_init(p);
+  S.mass_for_next_solve = p.amg_params.solver_mass;
+}
+
+double* dd_alpha_amg_get_gauge_pointer(void) {
+  if (!S.inited || !S.conf_set) fatal("dd_alpha_amg_get_gauge_pointer: no configuration set");
+  S.fields_dirty = true;   // the caller may write through this pointer
+  return S.ctx->D_host.data();
+}
+double* dd_alpha_amg_get_clover_pointer(void) {
+  if (!S.inited || !S.conf_set) fatal("dd_alpha_amg_get_clover_pointer: no configuration set");
+  S.fields_dirty = true;
+  return S.ctx->clover_host.data();
+}
+void dd_alpha_amg_fields_updated(void) {
+  S.status.gauge_updates_since_last_setup++;
+  S.status.gauge_updates_since_last_setup_update++;
+  S.fields_dirty = true;
+}
+
+double dd_alpha_amg_set_conf(double* gauge_field) {
+  if (!S.inited) fatal("dd_alpha_amg_set_conf: library not initialised");
+  const int* L = S.hp.local_lattice[0];
+  std::vector<double> U((size_t)S.V * 72);
+  size_t j = 0;
+  for (int t = 0; t < L[0]; t++) for (int z = 0; z < L[1]; z++) for (int y = 0; y < L[2]; y++) for (int x = 0; x < L[3]; x++)
+    for (int mu = 0; mu < 4; mu++) {
+      const int i = S.par.conf_index_fct(t, z, y, x, mu);
+      for (int k = 0; k < 18; k++, j++) U[j] = gauge_field[i + k];
+    }
+  double plaq = 0;
+  // as in the reference, the boundary condition is NOT applied here: the caller's links carry it
+  // (src/dd_alpha_amg.c:188-252 copies the field as it is)
+  check(ddamg_hip_set_gauge(S.ctx, U.data(), 0, &plaq), "dd_alpha_amg_set_conf");
+  S.conf_set = true; S.fields_dirty = false;
+  S.current_mass = S.hp.m0;
+  return plaq;
+}
+
+void dd_alpha_amg_update_parameters(const struct dd_alpha_amg_parameters* a) {
+  if (!S.inited) fatal("dd_alpha_amg_update_parameters: library not initialised");
+  // only parameters that may change after the initial setup (src/init.c:1136-1145)
+  for (int d = 0; d < S.hp.num_levels; d++) {
+    S.ctx->par.post_smooth_iter[d] = S.hp.post_smooth_iter[d] = a->post_smooth_iterations[d];
+    S.ctx->par.block_iter[d] = S.hp.block_iter[d] = a->post_smooth_block_iterations[d];
+    S.ctx->par.setup_iter[d] = S.hp.setup_iter[d] = a->setup_iterations[d];
+  }
+  S.mass_for_next_solve = a->solver_mass;
+}
+
+void dd_alpha_amg_setup(int iterations, int* status) { run_setup(iterations, status); }
+void dd_alpha_amg_setup_external_threading(int iterations, int* status, int core, int thread, void*, void (*)(void*, int)) {
+  if (core != 0 || thread != 0) { status[0] = 1; status[1] = 0; return; }
+  run_setup(iterations, status);
+}
+void dd_alpha_amg_setup_update(int iterations, int* status) { run_setup_update(iterations, status); }
+void dd_alpha_amg_setup_update_external_threading(int iterations, int* status, int core, int thread, void*, void (*)(void*, int)) {
+  if (core != 0 || thread != 0) { status[0] = 1; status[1] = 0; return; }
+  run_setup_update(iterations, status);
+}
+
+double dd_alpha_amg_wilson_solve(double* vector_out, double* vector_in, double tol, double scale_even, double scale_odd, int* status) {
+  if (!S.inited || !S.conf_set) fatal("dd_alpha_amg_wilson_solve: no configuration set");
+  reupload_if_dirty();
+  shift_mass_if_needed();
+  std::vector<double> src((size_t)S.V * 24), sol((size_t)S.V * 24), cl;
+  gather_vector(src, vector_in);
+  const bool scaled = scaled_operator(scale_even, scale_odd, cl);
+  std::vector<double> D_keep, cl_keep;
+  if (scaled) {
+    D_keep = S.ctx->D_host; cl_keep = S.ctx->clover_host;
+    check(ddamg_hip_set_operator(S.ctx, D_keep.data(), cl.data()), "scale_clover");
+  }
+  int it = 0, cit = 0; double rr = 0;
+  check(ddamg_hip_solve(S.ctx, sol.data(), src.data(), tol, &it, &cit, &rr), "dd_alpha_amg_wilson_solve");
+  if (scaled) check(ddamg_hip_set_operator(S.ctx, D_keep.data(), cl_keep.data()), "restore clover");
+  scatter_vector(vector_out, sol);
+  status[0] = it; status[1] = cit;
+  if (rr > tol) status[0] = -1;   // src/dd_alpha_amg.c:391-392
+  return rr;
+}
+
+void dd_alpha_amg_preconditioner(double* vector_out, double* vector_in, double scale_even, double scale_odd, int* status) {
+  if (!S.inited || !S.setup_done) fatal("dd_alpha_amg_preconditioner: setup has not been run");
+  reupload_if_dirty();
+  std::vector<double> src((size_t)S.V * 24), sol((size_t)S.V * 24), cl;
+  gather_vector(src, vector_in);
+  const bool scaled = scaled_operator(scale_even, scale_odd, cl);
+  std::vector<double> D_keep, cl_keep;
+  if (scaled) {
+    D_keep = S.ctx->D_host; cl_keep = S.ctx->clover_host;
+    check(ddamg_hip_set_operator(S.ctx, D_keep.data(), cl.data()), "scale_clover");
+  }
+  check(ddamg_hip_preconditioner(S.ctx, sol.data(), src.data()), "dd_alpha_amg_preconditioner");
+  if (scaled) check(ddamg_hip_set_operator(S.ctx, D_keep.data(), cl_keep.data()), "restore clover");
+  scatter_vector(vector_out, sol);
+  if (status) { status[0] = 1; status[1] = S.ctx->last_coarse_iter; }
+}
+void dd_alpha_amg_preconditioner_external_threading(double* vector_out, double* vector_in, int* status, int core, int thread, void*, void (*)(void*, int)) {
+  if (core != 0 || thread != 0) return;
+  dd_alpha_amg_preconditioner(vector_out, vector_in, 1.0, 1.0, status);
+}
+
+void dd_alpha_amg_free(void) {
+  if (!S.inited) return;
+  ddamg_hip_destroy(S.ctx);
+  S = State();
+}
+
+}  // extern "C"

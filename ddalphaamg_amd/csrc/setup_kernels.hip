@@ -93,7 +93,7 @@ template <typename T>
 void galerkin_column(CoarseOp<T>& cop, const Interpolation<T>& ip, const T* W, int col, T* work, hipStream_t st) {
   const size_t ws = (size_t)24 * ip.V;
   const int Vc = cop.V(), n = cop.n();
-  for (int part = 0; part < 5; part++) ip.restrict_to(work + (size_t)part * Vc * n * 2, W + (size_t)part * ws, st);
+  ip.restrict5(work, (size_t)Vc * n * 2, W, ws, st);
   const int total = 5 * Vc * n;
   hipLaunchKernelGGL(store_column_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, st, cop.matrices(), work, Vc, n, cop.nt(), cop.msize(), col);
   DDAMG_HIP_CHECK(hipGetLastError());

@@ -241,6 +241,27 @@ int ddamg_hip_solve(ddamg_hip_ctx* c, double* x_lex, const double* b_lex, double
   DDAMG_API_END
 }
 
+int ddamg_hip_preconditioner(ddamg_hip_ctx* c, double* out_lex, const double* in_lex) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && out_lex && in_lex, "null argument");
+  DDAMG_REQUIRE(c->setup_done && c->par.method > 0, "setup has not been run");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  ensure_outer(c);
+  const int V = c->levels[0]->geom.V;
+  const size_t nb = sizeof(double) * 24 * V;
+  double* st = c->stage(nb);
+  DDAMG_HIP_CHECK(hipMemcpyAsync(st, in_lex, nb, hipMemcpyHostToDevice, c->stream));
+  vec_from_lex<double>(c->outer.b, st, c->levels[0]->d_lex_of_site, V, 12, c->stream);
+  if (c->mg32) c->mg32->coarse_iter_count = 0;
+  if (c->mg64) c->mg64->coarse_iter_count = 0;
+  c->outer.prec(c->outer.x, nullptr, c->outer.b, NO_RES);
+  vec_to_lex<double>(st, c->outer.x, c->levels[0]->d_lex_of_site, V, 12, c->stream);
+  DDAMG_HIP_CHECK(hipMemcpyAsync(out_lex, st, nb, hipMemcpyDeviceToHost, c->stream));
+  DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
+  c->last_coarse_iter = c->mg32 ? c->mg32->coarse_iter_count : c->mg64->coarse_iter_count;
+  DDAMG_API_END
+}
+
 int ddamg_hip_residual_history(ddamg_hip_ctx* c, double* history, int max_len, int* len) {
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c && len, "null argument");

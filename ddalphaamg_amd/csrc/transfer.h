@@ -31,6 +31,8 @@ struct Interpolation {
   void orthonormalize(hipStream_t st);
   // phi_c = P^dagger phi          (coarse AoS, n = 2*nvec complex per coarse site = aggregate)
   void restrict_to(T* phi_c, const T* phi, hipStream_t st) const;
+  // five input vectors at once (the Galerkin construction restricts the self part and the four link parts together)
+  void restrict5(T* phi_c, size_t out_stride, const T* phi, size_t in_stride, hipStream_t st) const;
   // phi (+)= P phi_c
   void interpolate(T* phi, const T* phi_c, bool add, hipStream_t st) const;
 };

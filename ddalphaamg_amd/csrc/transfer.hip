@@ -35,54 +35,64 @@ void Interpolation<T>::release() {
 }
 
 // ---- restriction: phi_c[a][h*N + j] = sum_{x in a, d in chirality h} conj(P_j(x,d)) phi(x,d) ------
-template <typename T>
-__global__ void restrict_kernel(T* __restrict__ phi_c, const T* __restrict__ phi, const T* __restrict__ P, size_t pstride,
+// NIN input vectors (stride in_stride / out_stride) are restricted in one pass over P.
+template <typename T, int NIN>
+__global__ void restrict_kernel(T* __restrict__ phi_c, size_t out_stride, const T* __restrict__ phi, size_t in_stride,
+                                const T* __restrict__ P, size_t pstride,
                                 int nvec, int V, int agg_sites, const int* __restrict__ agg_csite) {
-  __shared__ double red[4 * TILE * 4];  // [value][wave]
+  constexpr int TL = NIN == 1 ? TILE : 4;  // interpolation vectors per register tile
+  __shared__ double red[4 * TL * NIN * 4];  // [value][wave]
   const int a = blockIdx.x, nt = blockDim.x;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = nt >> 6;
   const size_t s0 = (size_t)a * agg_sites;
-  for (int j0 = 0; j0 < nvec; j0 += TILE) {
-    const int jt = min(TILE, nvec - j0);
-    T acc[TILE][4];
+  for (int j0 = 0; j0 < nvec; j0 += TL) {
+    const int jt = min(TL, nvec - j0);
+    T acc[TL][NIN][4];
 #pragma unroll
-    for (int t = 0; t < TILE; t++) { acc[t][0] = acc[t][1] = acc[t][2] = acc[t][3] = 0; }
+    for (int t = 0; t < TL; t++)
+#pragma unroll
+      for (int m = 0; m < NIN; m++) { acc[t][m][0] = acc[t][m][1] = acc[t][m][2] = acc[t][m][3] = 0; }
     for (int i = threadIdx.x; i < agg_sites; i += nt) {
-      T f[24];
-      load_site<T, 24>(phi, V, s0 + i, f);
 #pragma unroll
-      for (int t = 0; t < TILE; t++) {
+      for (int t = 0; t < TL; t++) {
         if (t < jt) {
           T p[24];
           load_site<T, 24>(P + (size_t)(j0 + t) * pstride, V, s0 + i, p);
 #pragma unroll
-          for (int h = 0; h < 2; h++)
+          for (int m = 0; m < NIN; m++) {
+            T f[24];
+            load_site<T, 24>(phi + (size_t)m * in_stride, V, s0 + i, f);
 #pragma unroll
-            for (int d = 0; d < 6; d++) {
-              const int k = 2 * (6 * h + d);
-              acc[t][2 * h]     += p[k] * f[k] + p[k + 1] * f[k + 1];      // Re conj(p) f
-              acc[t][2 * h + 1] += p[k] * f[k + 1] - p[k + 1] * f[k];      // Im conj(p) f
-            }
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+              for (int d = 0; d < 6; d++) {
+                const int k = 2 * (6 * h + d);
+                acc[t][m][2 * h]     += p[k] * f[k] + p[k + 1] * f[k + 1];      // Re conj(p) f
+                acc[t][m][2 * h + 1] += p[k] * f[k + 1] - p[k + 1] * f[k];      // Im conj(p) f
+              }
+          }
         }
       }
     }
-    // block reduction of 4*TILE values
+    // block reduction of 4*TL*NIN values
 #pragma unroll
-    for (int t = 0; t < TILE; t++)
+    for (int t = 0; t < TL; t++)
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        double v = (double)acc[t][q];
+      for (int m = 0; m < NIN; m++)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if (lane == 0) red[(t * 4 + q) * 4 + wv] = v;
-      }
+        for (int q = 0; q < 4; q++) {
+          double v = (double)acc[t][m][q];
+#pragma unroll
+          for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+          if (lane == 0) red[((t * NIN + m) * 4 + q) * 4 + wv] = v;
+        }
     __syncthreads();
-    if (threadIdx.x < 4 * jt) {
-      const int t = threadIdx.x >> 2, q = threadIdx.x & 3;  // q: 0 re(h=0) 1 im(h=0) 2 re(h=1) 3 im(h=1)
+    for (int e = threadIdx.x; e < 4 * jt * NIN; e += nt) {
+      const int q = e & 3, m = (e >> 2) % NIN, t = (e >> 2) / NIN;  // q: 0 re(h=0) 1 im(h=0) 2 re(h=1) 3 im(h=1)
       double v = 0;
-      for (int w = 0; w < nw; w++) v += red[(t * 4 + q) * 4 + w];
+      for (int w = 0; w < nw; w++) v += red[((t * NIN + m) * 4 + q) * 4 + w];
       const int h = q >> 1, ri = q & 1;
-      phi_c[((size_t)agg_csite[a] * 2 * nvec + (size_t)h * nvec + j0 + t) * 2 + ri] = (T)v;
+      phi_c[(size_t)m * out_stride + ((size_t)agg_csite[a] * 2 * nvec + (size_t)h * nvec + j0 + t) * 2 + ri] = (T)v;
     }
     __syncthreads();
   }
@@ -90,7 +100,12 @@ __global__ void restrict_kernel(T* __restrict__ phi_c, const T* __restrict__ phi
 
 template <typename T>
 void Interpolation<T>::restrict_to(T* phi_c, const T* phi, hipStream_t st) const {
-  hipLaunchKernelGGL(restrict_kernel<T>, dim3(num_aggs), dim3(wg_threads(agg_sites)), 0, st, phi_c, phi, P, pstride, nvec, V, agg_sites, agg_csite);
+  hipLaunchKernelGGL((restrict_kernel<T, 1>), dim3(num_aggs), dim3(wg_threads(agg_sites)), 0, st, phi_c, (size_t)0, phi, (size_t)0, P, pstride, nvec, V, agg_sites, agg_csite);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+template <typename T>
+void Interpolation<T>::restrict5(T* phi_c, size_t out_stride, const T* phi, size_t in_stride, hipStream_t st) const {
+  hipLaunchKernelGGL((restrict_kernel<T, 5>), dim3(num_aggs), dim3(wg_threads(agg_sites)), 0, st, phi_c, out_stride, phi, in_stride, P, pstride, nvec, V, agg_sites, agg_csite);
   DDAMG_HIP_CHECK(hipGetLastError());
 }
 

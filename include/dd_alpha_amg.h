@@ -1,0 +1,77 @@
+/*
+ * dd_alpha_amg.h -- the DDalphaAMG library interface, served by the MI355X implementation.
+ *
+ * Same names, argument meaning, struct layout and error behaviour as the reference's
+ * src/dd_alpha_amg.h:29-83, so a host code that links libdd_alpha_amg.a can link
+ * libddamg_hip.so instead.  All entry points are thin glue over include/ddamg_hip.h.
+ *
+ * Differences that a caller can observe:
+ *  - one process drives one GPU; the lattice of that process is the whole lattice unless the
+ *    multi-GPU layer is initialised (global == local lattice is asserted otherwise);
+ *  - bc == 0 (open/Dirichlet boundaries, two gauge fields) is rejected with a fatal error;
+ *  - the *_external_threading variants ignore core/thread ids and barriers: there is no host
+ *    threading on the GPU path (every calling thread but thread 0 of core 0 returns at once).
+ */
+#ifndef DDalphaAMG_INTERFACE
+#define DDalphaAMG_INTERFACE
+
+#include "dd_alpha_amg_parameters.h"
+
+#define STRINGLENGTH 500
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct {
+  char param_file_path[STRINGLENGTH];
+  /* offsets, in doubles, of link (t,z,y,x,mu) / spinor site (t,z,y,x) inside the caller's arrays:
+     18 doubles per link (3x3 row major), 24 per site */
+  int (*conf_index_fct)(int t, int z, int y, int x, int mu);
+  int (*vector_index_fct)(int t, int z, int y, int x);
+  int (*global_time)(int t);
+  int bc; /* 0 dirichlet, 1 periodic, 2 anti-periodic */
+  double m0;
+  double csw;
+  double setup_m0;
+  struct dd_alpha_amg_parameters amg_params;
+} dd_alpha_amg_par;
+
+/* reads p.param_file_path (.ini, reference src/init.c:448-531) */
+void dd_alpha_amg_init(dd_alpha_amg_par p);
+/* takes p.amg_params instead of a parameter file */
+void dd_alpha_amg_init_external_threading(dd_alpha_amg_par p, int n_core, int n_thread);
+
+double* dd_alpha_amg_get_gauge_pointer(void);
+double* dd_alpha_amg_get_clover_pointer(void);
+void dd_alpha_amg_fields_updated(void);
+
+/* returns the average plaquette */
+double dd_alpha_amg_set_conf(double* gauge_field);
+
+void dd_alpha_amg_update_parameters(const struct dd_alpha_amg_parameters* amg_params);
+
+void dd_alpha_amg_setup(int iterations, int* status);
+void dd_alpha_amg_setup_external_threading(int iterations, int* status, int core, int thread,
+                                           void* thread_barrier_data, void (*thread_barrier)(void*, int));
+
+void dd_alpha_amg_setup_update(int iterations, int* status);
+void dd_alpha_amg_setup_update_external_threading(int iterations, int* status, int core, int thread,
+                                                  void* thread_barrier_data, void (*thread_barrier)(void*, int));
+
+/* status[0] = outer iterations (-1 if the final relative residual exceeds tol), status[1] = coarse-grid
+   iterations; returns the final relative residual.  Not designed for vector_in == 0. */
+double dd_alpha_amg_wilson_solve(double* vector_out, double* vector_in, double tol, double scale_even,
+                                 double scale_odd, int* status);
+
+/* one application of the multigrid preconditioner (declared by the reference, never defined there) */
+void dd_alpha_amg_preconditioner(double* vector_out, double* vector_in, double scale_even, double scale_odd, int* status);
+void dd_alpha_amg_preconditioner_external_threading(double* vector_out, double* vector_in, int* status, int core, int thread,
+                                                    void* thread_barrier_data, void (*thread_barrier)(void*, int));
+
+void dd_alpha_amg_free(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

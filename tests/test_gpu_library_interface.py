@@ -1,0 +1,69 @@
+"""GPU test (-m gpu): the reference's own library interface (include/dd_alpha_amg.h) end to end --
+init from a parameter struct, set_conf through the caller's index callbacks, setup, wilson_solve --
+on the reference's 4^4 sample configuration; iteration count against the reference run."""
+import ctypes
+import numpy as np
+import pytest
+from conftest import relerr
+from ddalphaamg_amd import libiface
+
+pytestmark = pytest.mark.gpu
+
+
+def test_library_interface_solve(gold4):
+    lib = libiface.bind()
+    L = [4, 4, 4, 4]  # T,Z,Y,X
+    par = libiface.Par()
+    a = par.amg_params
+    a.number_of_levels = 2
+    for mu in range(4):   # X,Y,Z,T order in the interface struct
+        a.global_lattice[0][mu] = a.local_lattice[0][mu] = 4
+        a.block_lattice[0][mu] = 2
+        a.global_lattice[1][mu] = a.local_lattice[1][mu] = 2
+    a.mg_basis_vectors[0] = 20; a.setup_iterations[0] = 4
+    a.post_smooth_iterations[0] = 2; a.post_smooth_block_iterations[0] = 4
+    a.coarse_grid_iterations, a.coarse_grid_maximum_number_of_restarts, a.coarse_grid_tolerance = 100, 5, 5e-2
+    a.solver_mass = a.setup_mass = -0.5; a.c_sw = 1.0
+    a.discard_setup_after = 1; a.update_setup_after = 1
+    # caller layout: plain lexicographic, 18 doubles per link / 24 per site
+    conf_idx = libiface.CONF_INDEX_FCT(lambda t, z, y, x, mu: ((((t * 4 + z) * 4 + y) * 4 + x) * 4 + mu) * 18)
+    vec_idx = libiface.VECTOR_INDEX_FCT(lambda t, z, y, x: (((t * 4 + z) * 4 + y) * 4 + x) * 24)
+    gtime = libiface.GLOBAL_TIME_FCT(lambda t: t)
+    par.conf_index_fct, par.vector_index_fct, par.global_time = conf_idx, vec_idx, gtime
+    par.bc, par.m0, par.csw, par.setup_m0 = 2, -0.5, 1.0, -0.5
+    lib.dd_alpha_amg_init_external_threading(par, 1, 1)
+    try:
+        # the library copies the links as they are: the anti-periodic sign is the caller's business
+        U = gold4["gauge"].copy()
+        U[-64:, 0] *= -1.0
+        dp = ctypes.POINTER(ctypes.c_double)
+        plaq = lib.dd_alpha_amg_set_conf(U.ctypes.data_as(dp))
+        assert abs(plaq - float(gold4["conf_plaq"][0])) < 1e-10
+        # the arrays handed out are the reference's own operator storage
+        D = np.ctypeslib.as_array(lib.dd_alpha_amg_get_gauge_pointer(), shape=(256, 36, 2))
+        cl = np.ctypeslib.as_array(lib.dd_alpha_amg_get_clover_pointer(), shape=(256, 42, 2))
+        assert np.array_equal(D, gold4["D"]) and relerr(cl, gold4["clover"]) < 1e-14
+        status = (ctypes.c_int * 2)()
+        lib.dd_alpha_amg_setup(4, status)
+        assert status[0] == 1 and status[1] > 0
+        b = np.zeros((256, 12, 2)); b[..., 0] = 1.0
+        x = np.zeros_like(b)
+        rr = lib.dd_alpha_amg_wilson_solve(x.ctypes.data_as(dp), b.ctypes.data_as(dp), 1e-10, 1.0, 1.0, status)
+        assert rr < 1e-10 and abs(status[0] - 11) <= 1 and status[1] > 0
+        from oracle import orc
+        assert relerr(orc.dirac_apply(L, gold4["D"], gold4["clover"], x, 64), b) < 1e-9
+        # unreachable tolerance -> status[0] = -1 (src/dd_alpha_amg.c:391-392)
+        rr = lib.dd_alpha_amg_wilson_solve(x.ctypes.data_as(dp), b.ctypes.data_as(dp), 1e-30, 1.0, 1.0, status)
+        assert status[0] == -1 and rr > 1e-30
+        # even/odd scaling of the clover term: solves (diag(s) C - hops) x = b
+        rr = lib.dd_alpha_amg_wilson_solve(x.ctypes.data_as(dp), b.ctypes.data_as(dp), 1e-9, 1.1, 0.9, status)
+        par_site = (np.indices((4, 4, 4, 4)).sum(0) % 2).reshape(-1)
+        cl2 = gold4["clover"] * np.where(par_site == 1, 0.9, 1.1)[:, None, None]
+        assert rr < 1e-9 and relerr(orc.dirac_apply(L, gold4["D"], cl2, x, 64), b) < 1e-8
+        # one preconditioner application = one V-cycle: reduces the residual
+        y = np.zeros_like(b)
+        lib.dd_alpha_amg_preconditioner(y.ctypes.data_as(dp), b.ctypes.data_as(dp), 1.0, 1.0, status)
+        r = b - orc.dirac_apply(L, gold4["D"], gold4["clover"], y, 64)
+        assert np.linalg.norm(r) < 0.3 * np.linalg.norm(b)
+    finally:
+        lib.dd_alpha_amg_free()

@@ -16,6 +16,22 @@ def test_library_exports_every_declared_symbol():
     assert not missing, f"symbols declared in include/ddamg_hip.h but not exported: {missing}"
 
 
+def test_library_exports_reference_interface():
+    """every function of the reference's dd_alpha_amg.h (src/dd_alpha_amg.h:42-83) is exported"""
+    from ddalphaamg_amd import libiface
+    lib = ctypes.CDLL(dd.library_path())
+    missing = [s for s in libiface.SYMBOLS if not hasattr(lib, s)]
+    assert not missing, missing
+    import re
+    hdr = open(os.path.join(os.path.dirname(dd.library_path()), "..", "include", "dd_alpha_amg.h")).read()
+    declared = set(re.findall(r"\b(dd_alpha_amg_[a-z_]+)\s*\(", re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)))
+    assert declared == set(libiface.SYMBOLS)
+    # struct layout: by-value dd_alpha_amg_par must match the C definition
+    # sizes as gcc lays out include/dd_alpha_amg.h on x86-64 (checked with a compiled sizeof probe)
+    assert ctypes.sizeof(libiface.AmgParameters) == 328
+    assert ctypes.sizeof(libiface.Par) == 888
+
+
 def test_default_params_match_reference_defaults():
     from ddalphaamg_amd import api
     p = api.default_params()

@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""tools/solve_bench.py -- set up a two-level hierarchy on a synthetic lattice and time the FGMRES+AMG solve.
+
+  python tools/solve_bench.py --lattice 16 16 16 16 --block 4 4 4 4 --nvec 24 --setup-iter 4
+"""
+import argparse, os, sys, time, json
+import numpy as np
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
+
+
+def near_unit_gauge(V, eps, seed):
+    """SU(3) links exp(i eps H) with Gaussian Hermitian traceless H (smooth, solvable at m0 ~ -0.1...-0.5)"""
+    rng = np.random.default_rng(seed)
+    n = V * 4
+    a = rng.standard_normal((n, 3, 3)) + 1j * rng.standard_normal((n, 3, 3))
+    h = (a + a.conj().transpose(0, 2, 1)) / 2
+    h -= np.trace(h, axis1=1, axis2=2)[:, None, None] * np.eye(3) / 3
+    w, v = np.linalg.eigh(h)
+    u = (v * np.exp(1j * eps * w)[:, None, :]) @ v.conj().transpose(0, 2, 1)
+    out = np.empty((n, 9, 2)); out[..., 0] = u.reshape(n, 9).real; out[..., 1] = u.reshape(n, 9).imag
+    return out.reshape(V, 4, 9, 2)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lattice", type=int, nargs=4, default=[16, 16, 16, 16])
+    ap.add_argument("--block", type=int, nargs=4, default=[4, 4, 4, 4])
+    ap.add_argument("--agg", type=int, nargs=4, default=[4, 4, 4, 4])
+    ap.add_argument("--nvec", type=int, default=24)
+    ap.add_argument("--setup-iter", type=int, default=4)
+    ap.add_argument("--m0", type=float, default=-0.3)
+    ap.add_argument("--csw", type=float, default=1.0)
+    ap.add_argument("--eps", type=float, default=0.35)
+    ap.add_argument("--solves", type=int, default=2)
+    args = ap.parse_args()
+    import ddalphaamg_amd as dd
+    from ddalphaamg_amd import api
+    L = args.lattice; V = int(np.prod(L))
+    p = api.default_params(); p.num_levels = 2
+    for mu in range(4):
+        p.local_lattice[0][mu] = L[mu]; p.block_lattice[0][mu] = args.block[mu]; p.local_lattice[1][mu] = L[mu] // args.agg[mu]
+    p.num_vect[0] = args.nvec; p.post_smooth_iter[0] = 2; p.block_iter[0] = 4; p.setup_iter[0] = args.setup_iter
+    p.restart, p.max_restart, p.tol = 50, 20, 1e-10
+    p.coarse_iter, p.coarse_restart, p.coarse_tol = 100, 5, 5e-2
+    p.mixed_precision, p.method, p.odd_even = 1, 2, 1
+    p.m0, p.csw = args.m0, args.csw
+    ctx = dd.Context(p)
+    t0 = time.time(); U = near_unit_gauge(V, args.eps, 20260101); t1 = time.time()
+    plaq = ctx.set_gauge(U, anti_pbc=True); t2 = time.time()
+    print(f"gauge gen {t1-t0:.1f}s  set_gauge {t2-t1:.1f}s  plaquette {plaq:.6f}", flush=True)
+    t0 = time.time(); ci = ctx.setup(args.setup_iter); ctx.sync(); t1 = time.time()
+    print(f"setup: {t1-t0:.2f}s (coarse its {ci})", flush=True)
+    b = np.zeros((V, 12, 2)); b[..., 0] = 1.0
+    for s in range(args.solves):
+        t0 = time.time(); x, it, cit, rr = ctx.solve(b, 1e-10); t1 = time.time()
+        print(json.dumps({"solve_s": t1 - t0, "iters": it, "coarse_iters": cit, "coarse_avg": cit / max(it, 1), "relres": rr}), flush=True)
+    print("history", " ".join(f"{h:.3e}" for h in ctx.residual_history()))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
