@@ -75,6 +75,9 @@ def load_library():
         "ddamg_hip_vec_upload": [vp, vp, dp],
         "ddamg_hip_vec_download": [vp, vp, dp],
         "ddamg_hip_dirac_apply": [vp, vp, vp],
+        "ddamg_hip_vec_copy": [vp, vp, vp],
+        "ddamg_hip_vec_axpy": [vp, vp, vp, vp, ctypes.c_double, ctypes.c_double],
+        "ddamg_hip_vec_dot": [vp, vp, vp, dp, dp, dp],
         "ddamg_hip_setup": [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
         "ddamg_hip_setup_update": [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
         "ddamg_hip_set_test_vectors": [vp, dp, ctypes.c_int],
@@ -186,6 +189,20 @@ class Context:
 
     def dirac_apply(self, out, inp):
         _check(self._lib.ddamg_hip_dirac_apply(self._h, out._h, inp._h))
+
+    # ---- BLAS-1 ----
+    def vec_copy(self, dst, src):
+        _check(self._lib.ddamg_hip_vec_copy(self._h, dst._h, src._h))
+
+    def vec_axpy(self, z, x, y, alpha):
+        alpha = complex(alpha)
+        _check(self._lib.ddamg_hip_vec_axpy(self._h, z._h, x._h, y._h, alpha.real, alpha.imag))
+
+    def vec_dot(self, x, y):
+        """returns (<x,y>, ||x||)"""
+        re = ctypes.c_double(0); im = ctypes.c_double(0); nx = ctypes.c_double(0)
+        _check(self._lib.ddamg_hip_vec_dot(self._h, x._h, y._h, ctypes.byref(re), ctypes.byref(im), ctypes.byref(nx)))
+        return complex(re.value, im.value), nx.value
 
     # ---- multigrid ----
     def vprec(self):

@@ -110,6 +110,7 @@ int ddamg_hip_destroy(ddamg_hip_ctx* c) {
   (void)hipStreamSynchronize(c->stream);
   c->mg32.reset(); c->mg64.reset();
   if (c->outer_ready) { c->outer.release(); c->rw_outer.destroy(); }
+  if (c->rw_blas_ready) c->rw_blas.destroy();
   if (c->p32_in) (void)hipFree(c->p32_in);
   if (c->p32_out) (void)hipFree(c->p32_out);
   for (auto& lv : c->levels) if (lv->d_lex_of_site) (void)hipFree(lv->d_lex_of_site);

@@ -56,6 +56,8 @@ struct ddamg_hip_ctx {
   ddamg::Gmres<double> outer;
   ddamg::ReduceWork rw_outer;
   bool outer_ready = false;
+  ddamg::ReduceWork rw_blas;
+  bool rw_blas_ready = false;
   float *p32_in = nullptr, *p32_out = nullptr;
   // results of the last solve
   int last_iter = 0, last_coarse_iter = 0;

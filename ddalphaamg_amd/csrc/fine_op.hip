@@ -54,11 +54,106 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : 3)) void dirac_apply_ker
   store_site<T, 24>(eta, V, s, e);
 }
 
+// ---- LDS-tiled variant ------------------------------------------------------------------------
+// One workgroup = one tile of 256 consecutive sites (= one 4^4 Schwarz block, or several smaller
+// blocks).  The tile's spinors are staged in LDS once; every link is loaded exactly once by the
+// thread that owns its site and used for both of its products: the forward term of the owner and
+// the backward term of the +mu neighbour, which travels through LDS as a projected half spinor
+// (the scatter form of the reference's phase 3, src/dirac_generic.c:196-217, but inside a tile).
+// Only couplings that leave the tile touch global memory for neighbour data.
+template <typename T, int MU>
+__device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOpDev<T>& op, size_t s, bool live, int tile0,
+                                         const T (&p)[24], T (&e)[24], T* __restrict__ sp, T* __restrict__ hb) {
+  const size_t V = op.V;
+  const int t = threadIdx.x;
+  T U[18];
+  if (live) load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, s, U);
+  // (a) backward product for my +mu neighbour:  U_mu(s)^dagger (1+gamma_mu) phi(s)
+  {
+    T h[12], g[12];
+    spin_project<T, MU, +1>(p, h);
+    su3_mul_dag<T>(U, h, g);
+#pragma unroll
+    for (int c = 0; c < 12; c++) hb[c * 256 + t] = g[c];
+  }
+  // (b) forward term with my own link
+  if (live) {
+    const int j = op.nb[(size_t)MU * V + s];
+    T pn[24];
+    if (j - tile0 >= 0 && j - tile0 < 256) {
+#pragma unroll
+      for (int c = 0; c < 24; c++) pn[c] = sp[c * 256 + (j - tile0)];
+    } else {
+      load_site<T, 24>(phi, V, j, pn);
+    }
+    hop_accumulate<T, MU, true>(U, pn, e);
+  }
+  __syncthreads();
+  // (c) backward term: product computed by site s-mu (in LDS) or, across the tile face, from global memory
+  if (live) {
+    const int j = op.nb[(size_t)(4 + MU) * V + s];
+    if (j - tile0 >= 0 && j - tile0 < 256) {
+      T g[12];
+#pragma unroll
+      for (int c = 0; c < 12; c++) g[c] = hb[c * 256 + (j - tile0)];
+      spin_reconstruct_sub<T, MU, +1>(g, e);
+    } else {
+      T pn[24], Un[18];
+      load_site<T, 24>(phi, V, j, pn);
+      load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, j, Un);
+      hop_accumulate<T, MU, false>(Un, pn, e);
+    }
+  }
+  __syncthreads();
+}
+
+template <typename T>
+__global__ __launch_bounds__(256, 3) void dirac_apply_lds_kernel(T* __restrict__ eta, const T* __restrict__ phi, FineOpDev<T> op, int ntiles) {
+  __shared__ T sp[24 * 256];
+  __shared__ T hb[12 * 256];
+  // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give XCD k the
+  // k-th contiguous eighth of the tiles (neighbouring tiles then share one L2)
+  int tile = blockIdx.x;
+  if ((ntiles & 7) == 0) tile = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
+  const size_t V = op.V;
+  const int tile0 = tile * 256;
+  const size_t s = (size_t)tile0 + threadIdx.x;
+  const bool live = s < V;
+  T p[24], e[24];
+  if (live) load_site<T, 24>(phi, V, s, p);
+  else {
+#pragma unroll
+    for (int k = 0; k < 24; k++) p[k] = 0;
+  }
+#pragma unroll
+  for (int c = 0; c < 24; c++) sp[c * 256 + threadIdx.x] = p[c];
+  if (live) {
+    T cl[36];
+    load_site<T, 36>(op.clover, V, s, cl);
+    herm6_mul<T>(cl, p, e);
+    load_site<T, 36>(op.clover + (size_t)36 * V, V, s, cl);
+    herm6_mul<T>(cl, p + 12, e + 12);
+  }
+  __syncthreads();
+  tile_dir<T, 0>(phi, op, s, live, tile0, p, e, sp, hb);
+  tile_dir<T, 1>(phi, op, s, live, tile0, p, e, sp, hb);
+  tile_dir<T, 2>(phi, op, s, live, tile0, p, e, sp, hb);
+  tile_dir<T, 3>(phi, op, s, live, tile0, p, e, sp, hb);
+  if (live) store_site<T, 24>(eta, V, s, e);
+}
+
+static int g_dirac_variant = -1;  // 0: gather/cache kernel, 1: LDS-tiled kernel (default)
+
 template <typename T>
 void FineOp<T>::apply(T* eta, const T* phi, hipStream_t st) const {
   DDAMG_REQUIRE(D_ != nullptr, "fine operator not uploaded");
+  if (g_dirac_variant < 0) {
+    const char* e = getenv("DDAMG_DIRAC_VARIANT");
+    g_dirac_variant = e ? atoi(e) : 1;
+  }
   int grid = (V_ + 255) / 256;
-  hipLaunchKernelGGL(dirac_apply_kernel<T>, dim3(grid), dim3(256), 0, st, eta, phi, dev());
+  if (g_dirac_variant == 0) hipLaunchKernelGGL(dirac_apply_kernel<T>, dim3(grid), dim3(256), 0, st, eta, phi, dev());
+  else hipLaunchKernelGGL(dirac_apply_lds_kernel<T>, dim3(grid), dim3(256), 0, st, eta, phi, dev(), grid);
   DDAMG_HIP_CHECK(hipGetLastError());
 }
 

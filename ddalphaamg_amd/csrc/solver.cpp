@@ -241,6 +241,47 @@ int ddamg_hip_solve(ddamg_hip_ctx* c, double* x_lex, const double* b_lex, double
   DDAMG_API_END
 }
 
+// ---- BLAS-1 on device vectors (src/linalg_generic.c:29-353) ---------------------------------------
+static ddamg::ReduceWork& blas_rw(ddamg_hip_ctx* c) {
+  if (!c->rw_blas_ready) { c->rw_blas.init(8); c->rw_blas_ready = true; }
+  return c->rw_blas;
+}
+static size_t vec_len(const ddamg_hip_vec* v) { return (size_t)v->V * v->ndof * 2; }
+static void same_shape(const ddamg_hip_vec* a, const ddamg_hip_vec* b) {
+  DDAMG_REQUIRE(a && b && a->level == b->level && a->precision == b->precision, "vectors differ in level or precision");
+}
+
+int ddamg_hip_vec_copy(ddamg_hip_ctx* c, ddamg_hip_vec* dst, const ddamg_hip_vec* src) {
+  DDAMG_API_BEGIN
+  same_shape(dst, src);
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  if (dst->precision == 32) vec_copy<float>((float*)dst->data, (const float*)src->data, whole(vec_len(dst)), c->stream);
+  else vec_copy<double>((double*)dst->data, (const double*)src->data, whole(vec_len(dst)), c->stream);
+  DDAMG_API_END
+}
+int ddamg_hip_vec_axpy(ddamg_hip_ctx* c, ddamg_hip_vec* z, const ddamg_hip_vec* x, const ddamg_hip_vec* y, double alpha_re, double alpha_im) {
+  DDAMG_API_BEGIN
+  same_shape(z, x); same_shape(z, y);
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  if (z->precision == 32) vec_axpy<float>((float*)z->data, (const float*)x->data, (const float*)y->data, alpha_re, alpha_im, whole(vec_len(z)), c->stream);
+  else vec_axpy<double>((double*)z->data, (const double*)x->data, (const double*)y->data, alpha_re, alpha_im, whole(vec_len(z)), c->stream);
+  DDAMG_API_END
+}
+int ddamg_hip_vec_dot(ddamg_hip_ctx* c, const ddamg_hip_vec* x, const ddamg_hip_vec* y, double* re, double* im, double* norm_x) {
+  DDAMG_API_BEGIN
+  same_shape(x, y);
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  ReduceWork& rw = blas_rw(c);
+  if (x->precision == 32) vec_dot_and_norm2<float>((const float*)x->data, (const float*)y->data, whole(vec_len(x)), rw, rw.d_result, c->stream);
+  else vec_dot_and_norm2<double>((const double*)x->data, (const double*)y->data, whole(vec_len(x)), rw, rw.d_result, c->stream);
+  DDAMG_HIP_CHECK(hipMemcpyAsync(rw.h_result, rw.d_result, sizeof(double) * 3, hipMemcpyDeviceToHost, c->stream));
+  DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (re) *re = rw.h_result[0];
+  if (im) *im = rw.h_result[1];
+  if (norm_x) *norm_x = sqrt(rw.h_result[2]);
+  DDAMG_API_END
+}
+
 int ddamg_hip_preconditioner(ddamg_hip_ctx* c, double* out_lex, const double* in_lex) {
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c && out_lex && in_lex, "null argument");

@@ -83,6 +83,13 @@ int ddamg_hip_vec_download(ddamg_hip_ctx* ctx, const ddamg_hip_vec* v, double* h
 /* replaces d_plus_clover_float / d_plus_clover_double (src/dirac_generic.c:159-277) */
 int ddamg_hip_dirac_apply(ddamg_hip_ctx* ctx, ddamg_hip_vec* out, const ddamg_hip_vec* in);
 
+/* BLAS-1 on device vectors: replaces vector_PRECISION_copy / vector_PRECISION_saxpy (z = x + alpha*y) and
+ * global_inner_product_PRECISION <x,y> = sum conj(x_i) y_i together with global_norm_PRECISION(x)
+ * (src/linalg_generic.c:29-353); reductions accumulate in fp64 */
+int ddamg_hip_vec_copy(ddamg_hip_ctx* ctx, ddamg_hip_vec* dst, const ddamg_hip_vec* src);
+int ddamg_hip_vec_axpy(ddamg_hip_ctx* ctx, ddamg_hip_vec* z, const ddamg_hip_vec* x, const ddamg_hip_vec* y, double alpha_re, double alpha_im);
+int ddamg_hip_vec_dot(ddamg_hip_ctx* ctx, const ddamg_hip_vec* x, const ddamg_hip_vec* y, double* re, double* im, double* norm_x);
+
 /* ---- multigrid hierarchy ------------------------------------------------------------------ */
 /* replaces method_setup + method_update (src/init.c:134-374; dd_alpha_amg_setup, src/dd_alpha_amg.c:254-273):
  * random test vectors (libc rand(), as vector_PRECISION_define_random) -> smoother passes -> aggregate-wise

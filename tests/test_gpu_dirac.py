@@ -111,6 +111,28 @@ def test_linearity_and_g5_hermiticity_32cube():
     ctx.close()
 
 
+@pytest.mark.parametrize("prec,tol", [(32, 1e-6), (64, 1e-14)])
+def test_blas1(prec, tol):
+    """vector_PRECISION_copy / saxpy / inner product / norm (src/linalg_generic.c:29-353)"""
+    ctx = make_ctx([4, 4, 8, 8], [2, 2, 2, 2])
+    n = 4 * 4 * 8 * 8 * 24
+    a = splitmix_uniform(n, 41).reshape(-1, 12, 2); b = splitmix_uniform(n, 42).reshape(-1, 12, 2)
+    if prec == 32:
+        a = a.astype(np.float32).astype(np.float64); b = b.astype(np.float32).astype(np.float64)
+    x = ctx.vector(0, prec).upload(a); y = ctx.vector(0, prec).upload(b); z = ctx.vector(0, prec)
+    ctx.vec_copy(z, x)
+    assert np.array_equal(z.download(), a)
+    al = 0.3 - 1.7j
+    ctx.vec_axpy(z, x, y, al)
+    cx = lambda v: v[..., 0] + 1j * v[..., 1]
+    ref = cx(a) + al * cx(b)
+    got = cx(z.download())
+    assert np.linalg.norm(got - ref) / np.linalg.norm(ref) < tol
+    d, nx = ctx.vec_dot(x, y)
+    assert abs(d - np.vdot(cx(a), cx(b))) / abs(d) < 1e-12 and abs(nx - np.linalg.norm(cx(a))) / nx < 1e-13
+    ctx.close()
+
+
 def test_error_paths():
     ctx = make_ctx([4, 4, 4, 4], [2, 2, 2, 2])
     x = ctx.vector(0, 32); y = ctx.vector(0, 64)
