@@ -88,6 +88,48 @@ __device__ __forceinline__ void store_site(T* __restrict__ base, size_t V, size_
     static_assert(TL == 0, "unsupported tail width");
   }
 }
+
+// ---- the same per-site accesses through a buffer descriptor -----------------------------------------
+// buffer_load takes base (SGPR descriptor) + one 32-bit VGPR offset (site*16 bytes, shared by every
+// chunk row of every field) + an SGPR offset (chunk row k*V*16): no 64-bit per-chunk address VGPRs,
+// which is what hipcc otherwise hoists out of loops and spills in the register-heavy block solver.
+struct SiteBuf {
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned row;  // bytes per chunk row = V * 16
+};
+__device__ __forceinline__ SiteBuf make_site_buf(const void* p, size_t V, size_t bytes) {
+  SiteBuf b;
+  b.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0x7fffffffull ? 0x7fffffffull : bytes), 0x00020000);
+  b.row = (unsigned)(V * 16);
+  return b;
+}
+// field of NR reals per site starting `base` bytes into the buffer; voff = site*16
+template <typename T, int NR>
+__device__ __forceinline__ void load_site_b(const SiteBuf& b, unsigned base, unsigned voff, T (&out)[NR]) {
+  constexpr int CH = Chunk<T>::CH;
+  constexpr int NF = NR / CH;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+  for (int k = 0; k < NF; k++) {
+    auto raw = __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, (int)voff, (int)(base + k * b.row), 0);
+    if constexpr (CH == 4) {
+      f4 v = __builtin_bit_cast(f4, raw);
+      out[4 * k] = v.x; out[4 * k + 1] = v.y; out[4 * k + 2] = v.z; out[4 * k + 3] = v.w;
+    } else {
+      d2 v = __builtin_bit_cast(d2, raw);
+      out[2 * k] = v.x; out[2 * k + 1] = v.y;
+    }
+  }
+  constexpr int TL = NR % CH;
+  if constexpr (TL == 2) {
+    f2 v = __builtin_bit_cast(f2, __builtin_amdgcn_raw_buffer_load_b64(b.rsrc, (int)(voff >> 1), (int)(base + NF * b.row), 0));
+    out[NF * CH] = v.x; out[NF * CH + 1] = v.y;
+  } else {
+    static_assert(TL == 0, "unsupported tail width");
+  }
+}
 #endif  // __HIPCC__
 
 // host-side index of real r of site s in a chunked-SoA field with NR reals/site

@@ -29,6 +29,7 @@ template <> struct Eps<double> { static constexpr double v = 1e-14; };  // EPS_d
 template <typename T, int MU>
 __device__ __forceinline__ void ext_hop_pair(const T* __restrict__ phi, const FineOpDev<T>& op, size_t site, unsigned mask, T (&acc)[24]) {
   const size_t V = op.V;
+  __builtin_amdgcn_sched_barrier(0);  // one direction at a time: bounds the live registers
   if (mask & (1u << MU)) {
     int j = op.nb[(size_t)MU * V + site];
     T pn[24], U[18];
@@ -36,6 +37,7 @@ __device__ __forceinline__ void ext_hop_pair(const T* __restrict__ phi, const Fi
     load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, site, U);
     hop_accumulate<T, MU, true>(U, pn, acc);
   }
+  __builtin_amdgcn_sched_barrier(0);
   if (mask & (1u << (4 + MU))) {
     int j = op.nb[(size_t)(4 + MU) * V + site];
     T pn[24], U[18];
@@ -90,10 +92,13 @@ __device__ __forceinline__ void blk_hops(const T* __restrict__ lds, const int (&
 template <typename T>
 __device__ __forceinline__ void clover_apply(const T* __restrict__ cl, size_t V, size_t site, const T (&in)[24], T (&out)[24]) {
   T c[36];
+  __builtin_amdgcn_sched_barrier(0);
   load_site<T, 36>(cl, V, site, c);
   herm6_mul<T>(c, in, out);
+  __builtin_amdgcn_sched_barrier(0);
   load_site<T, 36>(cl + (size_t)36 * V, V, site, c);
   herm6_mul<T>(c, in + 12, out + 12);
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // sum over the HS threads of one block (all of them get the result)
@@ -285,6 +290,264 @@ __global__ __launch_bounds__((HS < 64 ? 64 : HS)) void sap_block_kernel(SapArgs<
   }
 }
 
+
+template <typename T>
+struct OpBufs { SiteBuf D, cl, cli; unsigned voff; };   // voff = site * 16
+
+// =================================================================================================
+// Version 2 of the block-solve kernel: ONE THREAD PER SITE, THE BLOCK'S OPERATOR RESIDENT IN REGISTERS.
+// A block solve applies the block's links ten times and its clover terms ten times; with two to four
+// blocks per CU the working set of the blocks in flight on one XCD (14 MB) does not fit the 4 MB L2,
+// so re-reading the operator per hopping term made the kernel fabric-bound (2.2 GB per colour sweep
+// at 32^4, 430 us).  Here every thread loads the four forward links of ITS OWN site (72 reals) and
+// its own clover matrix (72 reals: D_ee on even sites, D_oo^-1 on odd sites) exactly once and keeps
+// them in VGPRs for the whole solve: 2 blocks x 256 threads x ~250 VGPRs fill the CU's 512 KB register
+// file, and HBM traffic per visit is the compulsory ~300 KB per block.
+//  * a hopping term parity p -> 1-p is a scatter/collect through LDS of projected half spinors
+//    (12 reals per direction): the source site sends U_mu(y)^dagger (1+gamma_mu) v(y) to y+mu and the
+//    bare projection (1-gamma_mu) v(y) to y-mu, whose owner multiplies with its own link -- the
+//    in-block version of the reference's prn/prp buffers (src/dirac_generic.c:181-217);
+//  * even and odd sites of a 4^4 block live in different wavefronts, so the even/odd phases are
+//    wavefront-uniform (no divergence); the MinRes iterate lives in LDS.
+template <typename T, int MU>
+__device__ __forceinline__ void emit_dir(const T (&v)[24], const T (&U)[18], const int (&nbl)[8], T* __restrict__ sl, int HS, int j) {
+  if (nbl[MU] >= 0) {   // my +mu neighbour is in the block: it needs U_mu(me)^dagger (1+gamma_mu) v
+    T h[12], g[12];
+    spin_project<T, MU, +1>(v, h);
+    su3_mul_dag<T>(U, h, g);
+#pragma unroll
+    for (int c = 0; c < 12; c++) sl[(MU * 12 + c) * HS + j] = g[c];
+  }
+  if (nbl[4 + MU] >= 0) {   // my -mu neighbour multiplies (1-gamma_mu) v with its own link
+    T h[12];
+    spin_project<T, MU, -1>(v, h);
+#pragma unroll
+    for (int c = 0; c < 12; c++) sl[((4 + MU) * 12 + c) * HS + j] = h[c];
+  }
+}
+template <typename T, int MU>
+__device__ __forceinline__ void collect_dir(T (&acc)[24], const T (&U)[18], const int (&nbl)[8], const T* __restrict__ sl, int HS) {
+  {
+    const int n = nbl[4 + MU];   // from x-mu: already multiplied by its link
+    if (n >= 0) {
+      T g[12];
+#pragma unroll
+      for (int c = 0; c < 12; c++) g[c] = sl[(MU * 12 + c) * HS + n];
+      spin_reconstruct_sub<T, MU, +1>(g, acc);
+    }
+  }
+  {
+    const int n = nbl[MU];       // from x+mu: multiply with my own link
+    if (n >= 0) {
+      T h[12], g[12];
+#pragma unroll
+      for (int c = 0; c < 12; c++) h[c] = sl[((4 + MU) * 12 + c) * HS + n];
+      su3_mul<T>(U, h, g);
+      spin_reconstruct_sub<T, MU, -1>(g, acc);
+    }
+  }
+}
+#define DDAMG_EMIT(v)                                   \
+  do {                                                  \
+    emit_dir<T, 0>(v, U0, nbl, sl, HS, j);              \
+    emit_dir<T, 1>(v, U1, nbl, sl, HS, j);              \
+    emit_dir<T, 2>(v, U2, nbl, sl, HS, j);              \
+    emit_dir<T, 3>(v, U3, nbl, sl, HS, j);              \
+  } while (0)
+#define DDAMG_COLLECT(acc)                              \
+  do {                                                  \
+    collect_dir<T, 0>(acc, U0, nbl, sl, HS);            \
+    collect_dir<T, 1>(acc, U1, nbl, sl, HS);            \
+    collect_dir<T, 2>(acc, U2, nbl, sl, HS);            \
+    collect_dir<T, 3>(acc, U3, nbl, sl, HS);            \
+  } while (0)
+
+// sum over the BS threads of one block (all of them get the result)
+template <typename T, int BS, int NT>
+__device__ __forceinline__ void site_allreduce3(T& a, T& b, T& c, T* red) {
+  constexpr int W = BS < 64 ? BS : 64;
+#pragma unroll
+  for (int o = W / 2; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); c += __shfl_xor(c, o, 64);
+  }
+  if constexpr (BS > 64) {
+    constexpr int NW = NT / 64;
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[w] = a; red[NW + w] = b; red[2 * NW + w] = c; }
+    __syncthreads();
+    a = 0; b = 0; c = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) { a += red[k]; b += red[NW + k]; c += red[2 * NW + k]; }
+  }
+}
+
+// out = C in with the resident clover matrix (two Hermitian 6x6 blocks, 72 reals)
+template <typename T>
+__device__ __forceinline__ void clover_reg(const T (&C)[72], const T (&in)[24], T (&out)[24]) {
+  herm6_mul<T>(C, in, out);
+  herm6_mul<T>(C + 36, in + 12, out + 12);
+}
+
+template <typename T, int BS>
+__global__ __launch_bounds__((BS < 64 ? 64 : BS), (sizeof(T) == 4 ? 2 : 1)) void sap_site_kernel(SapArgs<T> a) {
+  constexpr int HS = BS / 2;
+  constexpr int NT = BS < 64 ? 64 : BS;
+  constexpr int BPW = NT / BS;
+  __shared__ T slots[BPW * 8 * 12 * HS];
+  __shared__ T lphi_s[BPW * 24 * HS];   // MinRes iterate of the even sites
+  __shared__ T red[3 * (NT / 64) + 1];
+  const FineOpDev<T>& op = a.s.op;
+  const size_t V = op.V;
+  const int bw = threadIdx.x / BS, i = threadIdx.x % BS;
+  const bool odd = i >= HS;
+  const int j = odd ? i - HS : i;
+  const int bslot = blockIdx.x * BPW + bw;
+  const bool active = bslot < a.nblocks;
+  const int blk = active ? a.blocks[bslot] : a.blocks[0];
+  const size_t s = (size_t)blk * BS + i;
+  T* sl = slots + bw * 8 * 12 * HS;
+  T* lp = lphi_s + bw * 24 * HS;
+
+  int nbl[8];
+  unsigned ext = 0;
+#pragma unroll
+  for (int d = 0; d < 8; d++) {
+    const int v = a.s.blk_nb[d * BS + i];
+    nbl[d] = v < 0 ? -1 : (odd ? v : v - HS);
+    if (v < 0) ext |= 1u << d;
+  }
+
+  // ---- prologue: residual of my site ----------------------------------------------------------
+  int mode = a.mode;
+  if ((a.skip_mask >> a.s.block_list[blk]) & 1u) mode = MODE_NONE;
+  T v0[24];   // r, then (even) the MinRes residual rm
+  if (mode == MODE_FULLRES) {
+    T xs[24], e[24], et[24];
+    load_site<T, 24>(a.x, V, s, xs);
+    clover_apply<T>(op.clover, V, s, xs, e);
+    ext_hops<T>(a.x, op, s, 0xffu, e);
+    load_site<T, 24>(a.eta, V, s, et);
+#pragma unroll
+    for (int k = 0; k < 24; k++) v0[k] = et[k] - e[k];
+  } else {
+    load_site<T, 24>(a.r, V, s, v0);
+    if (mode == MODE_NBOUNDARY && ext) {
+      T acc[24];
+#pragma unroll
+      for (int k = 0; k < 24; k++) acc[k] = 0;
+      ext_hops<T>(a.latest, op, s, ext, acc);
+#pragma unroll
+      for (int k = 0; k < 24; k++) v0[k] -= acc[k];
+    }
+  }
+  if (!a.solve) {
+    if (active) store_site<T, 24>(a.r, V, s, v0);
+    return;
+  }
+
+  // ---- the block's operator, resident for the whole solve -------------------------------------
+  T U0[18], U1[18], U2[18], U3[18], C[72];
+  {
+    OpBufs<T> ob;
+    ob.D = make_site_buf(op.D, V, sizeof(T) * 72 * V);
+    ob.cl = make_site_buf(odd ? op.clover_inv : op.clover, V, sizeof(T) * 72 * V);
+    ob.voff = (unsigned)(s * 16);
+    const unsigned lrow = (unsigned)(18 * sizeof(T)) * (ob.D.row / 16);   // bytes between two directions' links
+    load_site_b<T, 18>(ob.D, 0, ob.voff, U0);
+    load_site_b<T, 18>(ob.D, lrow, ob.voff, U1);
+    load_site_b<T, 18>(ob.D, 2 * lrow, ob.voff, U2);
+    load_site_b<T, 18>(ob.D, 3 * lrow, ob.voff, U3);
+    load_site_b<T, 72>(ob.cl, 0, ob.voff, C);
+  }
+
+  T v1[24];   // odd: D_oo^-1 (...) ; even: D_ee rm / Dr
+  // t_o = D_oo^-1 r_o ; r_e <- r_e - D_eo t_o
+  if (odd) { clover_reg<T>(C, v0, v1); DDAMG_EMIT(v1); }
+  __syncthreads();
+  if (!odd) {
+    T acc[24];
+#pragma unroll
+    for (int k = 0; k < 24; k++) acc[k] = 0;
+    DDAMG_COLLECT(acc);
+#pragma unroll
+    for (int k = 0; k < 24; k++) { v0[k] -= acc[k]; lp[k * HS + j] = 0; }
+  }
+  __syncthreads();
+  for (int it = 0; it < a.s.block_iter; it++) {
+    if (!odd) DDAMG_EMIT(v0);
+    __syncthreads();
+    if (odd) {
+      T acc[24];
+#pragma unroll
+      for (int k = 0; k < 24; k++) acc[k] = 0;
+      DDAMG_COLLECT(acc);                 // D_oe rm
+      clover_reg<T>(C, acc, v1);          // D_oo^-1 D_oe rm
+    }
+    __syncthreads();
+    if (odd) DDAMG_EMIT(v1);
+    __syncthreads();
+    T nr = 0, ni = 0, dn = 0;
+    if (!odd) {
+      clover_reg<T>(C, v0, v1);           // D_ee rm
+#pragma unroll
+      for (int k = 0; k < 24; k++) v1[k] = -v1[k];
+      DDAMG_COLLECT(v1);                  // v1 = -(D_ee rm) - H_e(..) = -Dr
+#pragma unroll
+      for (int k = 0; k < 24; k++) v1[k] = -v1[k];
+#pragma unroll
+      for (int k = 0; k < 12; k++) {
+        nr += v1[2 * k] * v0[2 * k] + v1[2 * k + 1] * v0[2 * k + 1];
+        ni += v1[2 * k] * v0[2 * k + 1] - v1[2 * k + 1] * v0[2 * k];
+        dn += v1[2 * k] * v1[2 * k] + v1[2 * k + 1] * v1[2 * k + 1];
+      }
+    }
+    site_allreduce3<T, BS, NT>(nr, ni, dn, red);
+    if (!odd) {
+      T ar = 0, ai = 0;
+      if (fabs(dn) >= Eps<T>::v) { ar = nr / dn; ai = ni / dn; }
+#pragma unroll
+      for (int k = 0; k < 12; k++) {
+        lp[(2 * k) * HS + j]     += ar * v0[2 * k] - ai * v0[2 * k + 1];
+        lp[(2 * k + 1) * HS + j] += ar * v0[2 * k + 1] + ai * v0[2 * k];
+        v0[2 * k]     -= ar * v1[2 * k] - ai * v1[2 * k + 1];
+        v0[2 * k + 1] -= ar * v1[2 * k + 1] + ai * v1[2 * k];
+      }
+    }
+    __syncthreads();
+  }
+  // even to odd: delta_o = D_oo^-1 ( r_o - D_oe delta_e )
+  if (!odd) {
+#pragma unroll
+    for (int k = 0; k < 24; k++) v1[k] = lp[k * HS + j];
+    DDAMG_EMIT(v1);
+  }
+  __syncthreads();
+  if (odd) {
+    T acc[24];
+#pragma unroll
+    for (int k = 0; k < 24; k++) acc[k] = 0;
+    DDAMG_COLLECT(acc);
+#pragma unroll
+    for (int k = 0; k < 24; k++) v0[k] -= acc[k];
+    clover_reg<T>(C, v0, v1);
+#pragma unroll
+    for (int k = 0; k < 24; k++) v0[k] = 0;     // r_o = 0
+  }
+  if (active) {
+    // x += delta ; latest_iter = delta ; r_e = MinRes residual, r_o = 0
+    T xs[24];
+    load_site<T, 24>(a.x, V, s, xs);
+#pragma unroll
+    for (int k = 0; k < 24; k++) xs[k] += v1[k];
+    store_site<T, 24>(a.x, V, s, xs);
+    store_site<T, 24>(a.latest, V, s, v1);
+    store_site<T, 24>(a.r, V, s, v0);
+  }
+}
+#undef DDAMG_EMIT
+#undef DDAMG_COLLECT
+
 template <typename T>
 SapSmoother<T>::~SapSmoother() {
   if (r) (void)hipFree(r);
@@ -325,12 +588,23 @@ void SapSmoother<T>::setup(const Geometry& g, const FineOp<T>* op, int block_ite
   DDAMG_HIP_CHECK(hipStreamSynchronize(st));
 }
 
+static int g_sap_variant = -1;  // 1: site-pair kernel (v1), 2: thread-per-site kernel with resident links (default)
+
 template <typename T, int HS>
 static void launch_hs(const SapArgs<T>& a, hipStream_t st) {
-  constexpr int NT = HS < 64 ? 64 : HS;
-  constexpr int BPW = NT / HS;
-  const int grid = (a.nblocks + BPW - 1) / BPW;
-  hipLaunchKernelGGL((sap_block_kernel<T, HS>), dim3(grid), dim3(NT), 0, st, a);
+  if (g_sap_variant < 0) { const char* e = getenv("DDAMG_SAP_VARIANT"); g_sap_variant = e ? atoi(e) : 2; }
+  if (g_sap_variant == 1 || 2 * HS > 256) {
+    constexpr int NT = HS < 64 ? 64 : HS;
+    constexpr int BPW = NT / HS;
+    const int grid = (a.nblocks + BPW - 1) / BPW;
+    hipLaunchKernelGGL((sap_block_kernel<T, HS>), dim3(grid), dim3(NT), 0, st, a);
+  } else {
+    constexpr int BS = 2 * HS > 256 ? 256 : 2 * HS;
+    constexpr int NT = BS < 64 ? 64 : BS;
+    constexpr int BPW = NT / BS;
+    const int grid = (a.nblocks + BPW - 1) / BPW;
+    hipLaunchKernelGGL((sap_site_kernel<T, BS>), dim3(grid), dim3(NT), 0, st, a);
+  }
   DDAMG_HIP_CHECK(hipGetLastError());
 }
 
