@@ -48,14 +48,22 @@ template <typename T> __host__ __device__ inline size_t field_elems(int NR, size
 
 #ifdef __HIPCC__
 // ---- chunked-SoA per-site load / store of NR reals --------------------------------------
-template <typename T, int NR>
+template <typename T, int NR, bool NT = false>
 __device__ __forceinline__ void load_site(const T* __restrict__ base, size_t V, size_t s, T (&out)[NR]) {
   constexpr int CH = Chunk<T>::CH;
   constexpr int NF = NR / CH;
   using vec = typename Chunk<T>::vec;
+  typedef T vecn __attribute__((ext_vector_type(CH)));
 #pragma unroll
   for (int k = 0; k < NF; k++) {
-    vec v = *reinterpret_cast<const vec*>(base + ((size_t)k * V + s) * CH);
+    vec v;
+    if constexpr (NT) {  // read-once stream: keep it from displacing reusable lines in L2
+      vecn w = __builtin_nontemporal_load(reinterpret_cast<const vecn*>(base + ((size_t)k * V + s) * CH));
+      v.x = w[0]; v.y = w[1];
+      if constexpr (CH == 4) { v.z = w[2]; v.w = w[3]; }
+    } else {
+      v = *reinterpret_cast<const vec*>(base + ((size_t)k * V + s) * CH);
+    }
     if constexpr (CH == 4) { out[4 * k] = v.x; out[4 * k + 1] = v.y; out[4 * k + 2] = v.z; out[4 * k + 3] = v.w; }
     else { out[2 * k] = v.x; out[2 * k + 1] = v.y; }
   }
@@ -68,17 +76,25 @@ __device__ __forceinline__ void load_site(const T* __restrict__ base, size_t V, 
   }
 }
 
-template <typename T, int NR>
+template <typename T, int NR, bool NT = false>
 __device__ __forceinline__ void store_site(T* __restrict__ base, size_t V, size_t s, const T (&in)[NR]) {
   constexpr int CH = Chunk<T>::CH;
   constexpr int NF = NR / CH;
   using vec = typename Chunk<T>::vec;
+  typedef T vecn __attribute__((ext_vector_type(CH)));
 #pragma unroll
   for (int k = 0; k < NF; k++) {
-    vec v;
-    if constexpr (CH == 4) { v.x = in[4 * k]; v.y = in[4 * k + 1]; v.z = in[4 * k + 2]; v.w = in[4 * k + 3]; }
-    else { v.x = in[2 * k]; v.y = in[2 * k + 1]; }
-    *reinterpret_cast<vec*>(base + ((size_t)k * V + s) * CH) = v;
+    if constexpr (NT) {
+      vecn w;
+      w[0] = in[CH * k]; w[1] = in[CH * k + 1];
+      if constexpr (CH == 4) { w[2] = in[4 * k + 2]; w[3] = in[4 * k + 3]; }
+      __builtin_nontemporal_store(w, reinterpret_cast<vecn*>(base + ((size_t)k * V + s) * CH));
+    } else {
+      vec v;
+      if constexpr (CH == 4) { v.x = in[4 * k]; v.y = in[4 * k + 1]; v.z = in[4 * k + 2]; v.w = in[4 * k + 3]; }
+      else { v.x = in[2 * k]; v.y = in[2 * k + 1]; }
+      *reinterpret_cast<vec*>(base + ((size_t)k * V + s) * CH) = v;
+    }
   }
   constexpr int TL = NR % CH;
   if constexpr (TL == 2) {
@@ -104,7 +120,7 @@ __device__ __forceinline__ SiteBuf make_site_buf(const void* p, size_t V, size_t
   return b;
 }
 // field of NR reals per site starting `base` bytes into the buffer; voff = site*16
-template <typename T, int NR>
+template <typename T, int NR, int AUX = 0>   // AUX = 2: non-temporal (read-once stream)
 __device__ __forceinline__ void load_site_b(const SiteBuf& b, unsigned base, unsigned voff, T (&out)[NR]) {
   constexpr int CH = Chunk<T>::CH;
   constexpr int NF = NR / CH;
@@ -113,7 +129,7 @@ __device__ __forceinline__ void load_site_b(const SiteBuf& b, unsigned base, uns
   typedef float f2 __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int k = 0; k < NF; k++) {
-    auto raw = __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, (int)voff, (int)(base + k * b.row), 0);
+    auto raw = __builtin_amdgcn_raw_buffer_load_b128(b.rsrc, (int)voff, (int)(base + k * b.row), AUX);
     if constexpr (CH == 4) {
       f4 v = __builtin_bit_cast(f4, raw);
       out[4 * k] = v.x; out[4 * k + 1] = v.y; out[4 * k + 2] = v.z; out[4 * k + 3] = v.w;

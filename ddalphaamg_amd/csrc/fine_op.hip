@@ -7,6 +7,12 @@
 #include <complex>
 #include <cstring>
 
+#ifndef DDAMG_NT_CLOVER
+#define DDAMG_NT_CLOVER true
+#endif
+#ifndef DDAMG_NT_STORE
+#define DDAMG_NT_STORE true
+#endif
 namespace ddamg {
 
 template <typename T, int MU>
@@ -129,9 +135,9 @@ __global__ __launch_bounds__(256, 3) void dirac_apply_lds_kernel(T* __restrict__
   for (int c = 0; c < 24; c++) sp[c * 256 + threadIdx.x] = p[c];
   if (live) {
     T cl[36];
-    load_site<T, 36>(op.clover, V, s, cl);
+    load_site<T, 36, DDAMG_NT_CLOVER>(op.clover, V, s, cl);
     herm6_mul<T>(cl, p, e);
-    load_site<T, 36>(op.clover + (size_t)36 * V, V, s, cl);
+    load_site<T, 36, DDAMG_NT_CLOVER>(op.clover + (size_t)36 * V, V, s, cl);
     herm6_mul<T>(cl, p + 12, e + 12);
   }
   __syncthreads();
@@ -139,7 +145,7 @@ __global__ __launch_bounds__(256, 3) void dirac_apply_lds_kernel(T* __restrict__
   tile_dir<T, 1>(phi, op, s, live, tile0, p, e, sp, hb);
   tile_dir<T, 2>(phi, op, s, live, tile0, p, e, sp, hb);
   tile_dir<T, 3>(phi, op, s, live, tile0, p, e, sp, hb);
-  if (live) store_site<T, 24>(eta, V, s, e);
+  if (live) store_site<T, 24, DDAMG_NT_STORE>(eta, V, s, e);
 }
 
 static int g_dirac_variant = -1;  // 0: gather/cache kernel, 1: LDS-tiled kernel (default)

@@ -458,7 +458,7 @@ __global__ __launch_bounds__((BS < 64 ? 64 : BS), (sizeof(T) == 4 ? 2 : 1)) void
     load_site_b<T, 18>(ob.D, lrow, ob.voff, U1);
     load_site_b<T, 18>(ob.D, 2 * lrow, ob.voff, U2);
     load_site_b<T, 18>(ob.D, 3 * lrow, ob.voff, U3);
-    load_site_b<T, 72>(ob.cl, 0, ob.voff, C);
+    load_site_b<T, 72, 2>(ob.cl, 0, ob.voff, C);
   }
 
   T v1[24];   // odd: D_oo^-1 (...) ; even: D_ee rm / Dr
