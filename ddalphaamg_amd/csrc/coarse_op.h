@@ -53,6 +53,9 @@ class CoarseOp {
   // out[s0,s1) (+)= sign * sum over the 8 neighbours of the hopping terms of `in`
   //   accumulate=false: out = sign*H(in) ; accumulate=true: out += sign*H(in)
   void hop(T* out, const T* in, int s0, int s1, double sign, bool accumulate, hipStream_t st) const;
+  // masked / listed form used by the coarse Schwarz smoother and the coarse Galerkin construction
+  void apply_masked(T* out, const T* in, const int* site_list, int nsites, const unsigned char* dir_mask, bool mask_invert,
+                    double sign_self, double sign_hop, bool accumulate, hipStream_t st) const;
   // out[s0,s1) = M0 in   or   M0^-1 in
   void self_mul(T* out, const T* in, int s0, int s1, bool inverse, hipStream_t st) const;
 

@@ -65,9 +65,13 @@ __device__ __forceinline__ void wave_mv(const T* __restrict__ Mbase, const T* __
 
 template <typename T, int NT>
 __global__ void coarse_site_kernel(T* __restrict__ out, const T* __restrict__ in, CoarseOpDev<T> op, int s0, int mode,
-                                   T sign_self, T sign_hop, int accumulate) {
+                                   T sign_self, T sign_hop, int accumulate,
+                                   const int* __restrict__ site_list, const unsigned char* __restrict__ dir_mask, int mask_invert) {
   __shared__ T res[9 * 2 * 8 * NT];
-  const int x = s0 + blockIdx.x;
+  const int x = site_list ? site_list[blockIdx.x] : s0 + blockIdx.x;
+  // directions (bit d: +T,+Z,+Y,+X,-T,-Z,-Y,-X) whose hopping term is included for this site
+  unsigned dmask = 0xffu;
+  if (dir_mask) dmask = mask_invert ? (~(unsigned)dir_mask[x]) & 0xffu : (unsigned)dir_mask[x];
   const int w = threadIdx.x >> 6;
   const int n = op.n, np = 8 * NT;
   const size_t V = op.V;
@@ -79,6 +83,8 @@ __global__ void coarse_site_kernel(T* __restrict__ out, const T* __restrict__ in
     wave_mv<T, NT, false>(Mx, in + (size_t)x * n * 2, n, r);
   } else if (mode == MODE_SELFINV) {
     wave_mv<T, NT, false>(op.Minv + (size_t)x * op.msize * 2, in + (size_t)x * n * 2, n, r);
+  } else if (!((dmask >> (prod - 1)) & 1u)) {
+    for (int k = threadIdx.x & 63; k < 2 * np; k += 64) r[k] = 0;   // direction masked out
   } else if (prod <= 4) {
     const int mu = prod - 1;
     const int y = op.nb[(size_t)mu * V + x];
@@ -107,11 +113,12 @@ __global__ void coarse_site_kernel(T* __restrict__ out, const T* __restrict__ in
 }
 
 template <typename T>
-static void launch_site(const CoarseOpDev<T>& op, T* out, const T* in, int s0, int s1, int mode, double ss, double sh, bool acc, hipStream_t st) {
+static void launch_site(const CoarseOpDev<T>& op, T* out, const T* in, int s0, int s1, int mode, double ss, double sh, bool acc, hipStream_t st,
+                        const int* site_list = nullptr, const unsigned char* dir_mask = nullptr, bool mask_invert = false) {
   if (s1 <= s0) return;
   const int waves = mode == MODE_FULL ? 9 : (mode == MODE_HOP ? 8 : 1);
   dim3 grid(s1 - s0), block(64 * waves);
-#define DDAMG_CASE(NTV) case NTV: hipLaunchKernelGGL((coarse_site_kernel<T, NTV>), grid, block, 0, st, out, in, op, s0, mode, (T)ss, (T)sh, acc ? 1 : 0); break;
+#define DDAMG_CASE(NTV) case NTV: hipLaunchKernelGGL((coarse_site_kernel<T, NTV>), grid, block, 0, st, out, in, op, s0, mode, (T)ss, (T)sh, acc ? 1 : 0, site_list, dir_mask, mask_invert ? 1 : 0); break;
   switch (op.nt) {
     DDAMG_CASE(1) DDAMG_CASE(2) DDAMG_CASE(3) DDAMG_CASE(4) DDAMG_CASE(5) DDAMG_CASE(6) DDAMG_CASE(7) DDAMG_CASE(8)
     default: DDAMG_REQUIRE(false, "coarse operator: more than 64 dof per site are not supported");
@@ -131,6 +138,15 @@ template <typename T> void CoarseOp<T>::hop(T* out, const T* in, int s0, int s1,
 template <typename T> void CoarseOp<T>::self_mul(T* out, const T* in, int s0, int s1, bool inverse, hipStream_t st) const {
   DDAMG_REQUIRE(out != in, "coarse self coupling cannot run in place");
   launch_site<T>(dev(), out, in, s0, s1, inverse ? MODE_SELFINV : MODE_SELF, 1.0, 0.0, false, st);
+}
+
+// masked / listed variants (Schwarz blocks and aggregates on coarse levels):
+//   out(x) = [accumulate ? out(x) : 0] + sign_self * M0 in(x) + sign_hop * sum_{d in mask(x)} hop_d(in)   for x in list
+template <typename T> void CoarseOp<T>::apply_masked(T* out, const T* in, const int* site_list, int nsites, const unsigned char* dir_mask,
+                                                     bool mask_invert, double sign_self, double sign_hop, bool accumulate, hipStream_t st) const {
+  DDAMG_REQUIRE(out != in, "coarse apply cannot run in place");
+  if (sign_self != 0.0) launch_site<T>(dev(), out, in, 0, nsites, MODE_FULL, sign_self, sign_hop, accumulate, st, site_list, dir_mask, mask_invert);
+  else launch_site<T>(dev(), out, in, 0, nsites, MODE_HOP, 0.0, sign_hop, accumulate, st, site_list, dir_mask, mask_invert);
 }
 
 // ---- batched in-place Gauss-Jordan inverse of the self couplings (fp64 in LDS) ------------------

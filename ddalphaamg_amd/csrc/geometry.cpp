@@ -82,11 +82,15 @@ void Geometry::build(const int L_[4], const int B_[4], const int A_[4]) {
   // aggregate faces (geometric: a wrap-around into the same aggregate still counts as leaving it,
   // as the reference's agg_boundary_index tables do, src/coarsening_generic.c:39-111)
   agg_face.assign(V, 0);
+  blk_face.assign(V, 0);
   for (int st = 0; st < V; st++)
     for (int mu = 0; mu < 4; mu++) {
       const int r = coord[(size_t)st * 4 + mu] % A[mu];
       if (r == A[mu] - 1) agg_face[st] |= (unsigned char)(1u << mu);
       if (r == 0) agg_face[st] |= (unsigned char)(1u << (4 + mu));
+      const int rb = coord[(size_t)st * 4 + mu] % B[mu];
+      if (rb == B[mu] - 1) blk_face[st] |= (unsigned char)(1u << mu);
+      if (rb == 0) blk_face[st] |= (unsigned char)(1u << (4 + mu));
     }
 
   // block-local neighbour table (same for every block): index inside the block or -1

@@ -33,6 +33,7 @@ struct Geometry {
   std::vector<int> block_color;  // [num_blocks] red-black colour (src/schwarz_generic.c:383-395)
   std::vector<int> block_list;   // [num_blocks] 0..7: red-black list of the reference (:415-428)
   int block_even_sites = 0;      // number of block-local even sites (first in the block)
+  std::vector<unsigned char> blk_face;  // [V] bit d set: the neighbour in direction d lies outside the site's Schwarz block
   std::vector<unsigned char> agg_face;  // [V] bit d set: the neighbour in direction d lies outside the site's aggregate
 
   void build(const int L_[4], const int B_[4], const int A_[4]);

@@ -1,226 +1,376 @@
 // mg.cpp -- see mg.h
 #include "mg.h"
 #include "setup_kernels.h"
+#include <cmath>
 #include <cstdlib>
 #include <vector>
 
 namespace ddamg {
 
 template <typename T>
-Multigrid<T>::Multigrid(const ddamg_hip_params& par, const Geometry& g0, const Geometry& g1, const FineOp<T>* fop, hipStream_t st)
-    : par_(par), g0_(g0), g1_(g1), fop_(fop), st_(st) {
-  nvec_ = par.num_vect[0];
-  n1_ = 2 * nvec_;
-  DDAMG_REQUIRE(par.num_levels == 2, "this build drives a two-level hierarchy (fine SAP level + odd-even coarsest level)");
-  sap_.setup(g0_, fop_, par.block_iter[0], st_);
-  ip_.alloc(g0_, g1_, nvec_);
-  cop_.alloc(g1_, n1_);
-  rw_c_.init(std::max(par.coarse_iter, 8) + 4);
-  rw_f_.init(nvec_ + 8);
-  // coarsest-level GMRES: fgmres_PRECISION_struct_alloc( g.coarse_iter, g.coarse_restart, ..., g.coarse_tol )
-  // (src/init_generic.c:148-154), restricted to the even sites (v_end, src/coarse_oddeven_generic.c)
-  const size_t cel = (size_t)g1_.V * n1_ * 2;
-  cg_.alloc(cel, par.coarse_iter, false);
-  cg_.num_restart = par.coarse_restart;
-  cg_.tol = par.coarse_tol;
-  cg_.initial_guess_zero = true;
-  cg_.st = st_; cg_.rw = &rw_c_;
-  int n_even = 0;
-  for (int s = 0; s < g1_.V; s++) if (g1_.parity[s] == 0) n_even++;
-  DDAMG_REQUIRE(n_even * 2 == g1_.V, "coarsest lattice needs as many even as odd sites");
-  for (int s = 0; s < n_even; s++) DDAMG_REQUIRE(g1_.parity[s] == 0, "coarsest level must be parity ordered");
-  cg_.view = View{1, 0, 0, (size_t)n_even * n1_ * 2};
-  cg_.op = [this](T* out, const T* in) { this->schur(out, in); };
-  for (int i = 0; i < 2; i++) { DDAMG_HIP_CHECK(hipMalloc(&ctmp_[i], sizeof(T) * cel)); DDAMG_HIP_CHECK(hipMemset(ctmp_[i], 0, sizeof(T) * cel)); }
-  const size_t fel = (size_t)24 * g0_.V;
-  for (int i = 0; i < 3; i++) { DDAMG_HIP_CHECK(hipMalloc(&fbuf_[i], sizeof(T) * fel)); DDAMG_HIP_CHECK(hipMemset(fbuf_[i], 0, sizeof(T) * fel)); }
-  DDAMG_HIP_CHECK(hipMalloc(&W_, sizeof(T) * fel * 5));
-  DDAMG_HIP_CHECK(hipMalloc(&cwork_, sizeof(T) * cel * 5));
-  DDAMG_HIP_CHECK(hipMalloc(&d_agg_face_, g0_.V));
-  DDAMG_HIP_CHECK(hipMemcpy(d_agg_face_, g0_.agg_face.data(), g0_.V, hipMemcpyHostToDevice));
-  std::vector<int> id(g0_.V);
-  for (int i = 0; i < g0_.V; i++) id[i] = i;
-  DDAMG_HIP_CHECK(hipMalloc(&d_identity_, sizeof(int) * g0_.V));
-  DDAMG_HIP_CHECK(hipMemcpy(d_identity_, id.data(), sizeof(int) * g0_.V, hipMemcpyHostToDevice));
-  DDAMG_HIP_CHECK(hipMalloc(&d_stage_, sizeof(double) * fel));
+Multigrid<T>::Multigrid(const ddamg_hip_params& par, const std::vector<const Geometry*>& geoms, const FineOp<T>* fop, hipStream_t st)
+    : par_(par), st_(st) {
+  const int L = par.num_levels;
+  DDAMG_REQUIRE(L >= 2 && L <= DDAMG_HIP_MAX_LEVELS && (int)geoms.size() == L, "multigrid needs 2..4 levels");
+  size_t max_coarse = 0;
+  for (int d = 0; d < L; d++) {
+    std::unique_ptr<MGLevel<T>> lv(new MGLevel<T>);
+    lv->depth = d; lv->g = geoms[d];
+    lv->n = d == 0 ? 12 : 2 * par.num_vect[d - 1];
+    lv->coarsest = d == L - 1;
+    lv->nvec = lv->coarsest ? 0 : par.num_vect[d];
+    lv->nel = (size_t)lv->g->V * lv->n * 2;
+    if (d > 0) max_coarse = std::max(max_coarse, lv->nel);
+    lv_.push_back(std::move(lv));
+  }
+  for (int d = 0; d < L; d++) {
+    MGLevel<T>& lv = *lv_[d];
+    const Geometry& g = *lv.g;
+    for (int i = 0; i < 4; i++) { DDAMG_HIP_CHECK(hipMalloc(&lv.buf[i], sizeof(T) * lv.nel)); DDAMG_HIP_CHECK(hipMemset(lv.buf[i], 0, sizeof(T) * lv.nel)); }
+    if (d == 0) lv.fop = fop;
+    else lv.cop.alloc(g, lv.n);
+    if (!lv.coarsest) {
+      if (d == 0) { lv.fsap.setup(g, fop, par.block_iter[0], st_); lv.fip.alloc(g, *geoms[1], lv.nvec); }
+      else { lv.csap.setup(g, &lv.cop, par.block_iter[d], st_); lv.cip.alloc(g, *geoms[d + 1], lv.n, lv.nvec); }
+      DDAMG_HIP_CHECK(hipMalloc(&lv.d_agg_face, g.V));
+      DDAMG_HIP_CHECK(hipMemcpy(lv.d_agg_face, g.agg_face.data(), g.V, hipMemcpyHostToDevice));
+      for (int mu = 0; mu < 4; mu++) {
+        std::vector<unsigned char> m(g.V);
+        for (int s = 0; s < g.V; s++) m[s] = g.agg_face[s] & (unsigned char)(1u << mu);
+        DDAMG_HIP_CHECK(hipMalloc(&lv.d_dir_mask[mu], g.V));
+        DDAMG_HIP_CHECK(hipMemcpy(lv.d_dir_mask[mu], m.data(), g.V, hipMemcpyHostToDevice));
+      }
+    }
+    if (d > 0 && !lv.coarsest) {
+      // K-cycle FGMRES of this level (src/init_generic.c:155-160): restart kcycle_restart, kcycle_max_restart cycles
+      lv.rw.init(std::max(par.kcycle_restart, lv.nvec) + 8);
+      lv.gm.alloc(lv.nel, par.kcycle_restart, true);
+      lv.gm.num_restart = par.kcycle_max_restart;
+      lv.gm.tol = par.kcycle_tol;
+      lv.gm.view = whole(lv.nel);
+      lv.gm.st = st_; lv.gm.rw = &lv.rw;
+      lv.gm.op = [this, d](T* out, const T* in) { this->apply_op(d, out, in); };
+      lv.gm.prec = [this, d](T* phi, T* Dphi, const T* eta, int res) { this->vcycle(d, phi, Dphi, eta, res); };
+      // the reference's vector loops visit this level aggregate -> block -> lexicographic inside the block
+      // (src/gathering_generic.c:126-157); ours orders block sites by parity first
+      lv.ref_order.reserve(g.V);
+      int bpa[4], a[4], b[4], r[4], c[4];
+      for (int mu = 0; mu < 4; mu++) bpa[mu] = g.A[mu] / g.B[mu];
+      for (a[0] = 0; a[0] < g.nagg[0]; a[0]++) for (a[1] = 0; a[1] < g.nagg[1]; a[1]++)
+      for (a[2] = 0; a[2] < g.nagg[2]; a[2]++) for (a[3] = 0; a[3] < g.nagg[3]; a[3]++)
+        for (b[0] = 0; b[0] < bpa[0]; b[0]++) for (b[1] = 0; b[1] < bpa[1]; b[1]++)
+        for (b[2] = 0; b[2] < bpa[2]; b[2]++) for (b[3] = 0; b[3] < bpa[3]; b[3]++)
+          for (r[0] = 0; r[0] < g.B[0]; r[0]++) for (r[1] = 0; r[1] < g.B[1]; r[1]++)
+          for (r[2] = 0; r[2] < g.B[2]; r[2]++) for (r[3] = 0; r[3] < g.B[3]; r[3]++) {
+            for (int mu = 0; mu < 4; mu++) c[mu] = (a[mu] * bpa[mu] + b[mu]) * g.B[mu] + r[mu];
+            lv.ref_order.push_back(g.site_of_lex[g.lex(c)]);
+          }
+    } else if (d == 0) {
+      lv.rw.init(lv.nvec + 8);
+    }
+    if (lv.coarsest) {
+      // coarsest-level GMRES on the even-site Schur complement (src/init_generic.c:148-154)
+      lv.rw.init(std::max(par.coarse_iter, 8) + 4);
+      lv.gm.alloc(lv.nel, par.coarse_iter, false);
+      lv.gm.num_restart = par.coarse_restart;
+      lv.gm.tol = par.coarse_tol;
+      lv.gm.st = st_; lv.gm.rw = &lv.rw;
+      int n_even = 0;
+      for (int s = 0; s < g.V; s++) if (g.parity[s] == 0) n_even++;
+      DDAMG_REQUIRE(n_even * 2 == g.V, "coarsest lattice needs as many even as odd sites");
+      for (int s = 0; s < n_even; s++) DDAMG_REQUIRE(g.parity[s] == 0, "coarsest level must be parity ordered");
+      lv.gm.view = View{1, 0, 0, (size_t)n_even * lv.n * 2};
+      lv.gm.op = [this](T* out, const T* in) { this->schur(out, in); };
+    }
+  }
+  const Geometry& g0 = *geoms[0];
+  std::vector<int> id(g0.V);
+  for (int i = 0; i < g0.V; i++) id[i] = i;
+  DDAMG_HIP_CHECK(hipMalloc(&d_identity0_, sizeof(int) * g0.V));
+  DDAMG_HIP_CHECK(hipMemcpy(d_identity0_, id.data(), sizeof(int) * g0.V, hipMemcpyHostToDevice));
+  DDAMG_HIP_CHECK(hipMalloc(&d_lex0_, sizeof(int) * g0.V));
+  DDAMG_HIP_CHECK(hipMemcpy(d_lex0_, g0.lex_of_site.data(), sizeof(int) * g0.V, hipMemcpyHostToDevice));
+  DDAMG_HIP_CHECK(hipMalloc(&d_stage_, sizeof(double) * std::max(lv_[0]->nel, max_coarse)));
+  DDAMG_HIP_CHECK(hipMalloc(&W_, sizeof(T) * lv_[0]->nel * 5));
+  DDAMG_HIP_CHECK(hipMalloc(&cwork_, sizeof(T) * max_coarse * 5));
 }
 
 template <typename T>
 Multigrid<T>::~Multigrid() {
   (void)hipStreamSynchronize(st_);
-  ip_.release();
-  cg_.release();
-  rw_c_.destroy(); rw_f_.destroy();
-  for (int i = 0; i < 2; i++) if (ctmp_[i]) (void)hipFree(ctmp_[i]);
-  for (int i = 0; i < 3; i++) if (fbuf_[i]) (void)hipFree(fbuf_[i]);
+  for (auto& p : lv_) {
+    MGLevel<T>& lv = *p;
+    for (int i = 0; i < 4; i++) if (lv.buf[i]) (void)hipFree(lv.buf[i]);
+    if (!lv.coarsest) { if (lv.depth == 0) lv.fip.release(); else lv.cip.release(); }
+    if (lv.gm.slab) lv.gm.release();
+    lv.rw.destroy();
+    if (lv.d_agg_face) (void)hipFree(lv.d_agg_face);
+    for (int mu = 0; mu < 4; mu++) if (lv.d_dir_mask[mu]) (void)hipFree(lv.d_dir_mask[mu]);
+  }
+  if (d_identity0_) (void)hipFree(d_identity0_);
+  if (d_lex0_) (void)hipFree(d_lex0_);
+  if (d_stage_) (void)hipFree(d_stage_);
   if (W_) (void)hipFree(W_);
   if (cwork_) (void)hipFree(cwork_);
-  if (d_agg_face_) (void)hipFree(d_agg_face_);
-  if (d_identity_) (void)hipFree(d_identity_);
-  if (d_stage_) (void)hipFree(d_stage_);
+}
+
+// ---- level-generic pieces ---------------------------------------------------------------------------
+template <typename T> void Multigrid<T>::apply_op(int l, T* out, const T* in) {
+  if (l == 0) lv_[0]->fop->apply(out, in, st_);
+  else lv_[l]->cop.apply(out, in, st_);
+}
+template <typename T> void Multigrid<T>::smoother(int l, T* phi, T* Dphi, const T* eta, int cycles, int res) {
+  if (l == 0) lv_[0]->fsap.smooth(phi, Dphi, eta, cycles, res, st_);
+  else lv_[l]->csap.smooth(phi, Dphi, eta, cycles, res, st_);
+}
+template <typename T> void Multigrid<T>::restrict_to(int l, T* phi_c, const T* phi) {
+  if (l == 0) lv_[0]->fip.restrict_to(phi_c, phi, st_);
+  else lv_[l]->cip.restrict_to(phi_c, phi, st_);
+}
+template <typename T> void Multigrid<T>::interpolate(int l, T* phi, const T* phi_c, bool add) {
+  if (l == 0) lv_[0]->fip.interpolate(phi, phi_c, add, st_);
+  else lv_[l]->cip.interpolate(phi, phi_c, add, st_);
+}
+template <typename T> void Multigrid<T>::set_kcycle_tol(double tol) {
+  for (auto& p : lv_) if (p->depth > 0 && !p->coarsest) p->gm.tol = tol;
 }
 
 // ---- coarsest level: odd-even Schur complement solve ----------------------------------------------
 // S = D_ee - D_eo D_oo^-1 D_oe  on the even sites (coarse_apply_schur_complement_PRECISION)
 template <typename T>
 void Multigrid<T>::schur(T* out, const T* in) {
-  const int Ve = g1_.V / 2, V = g1_.V;
-  cop_.self_mul(out, in, 0, Ve, false, st_);                 // out_e = D_ee in_e
-  cop_.hop(ctmp_[0], in, Ve, V, -1.0, false, st_);           // tmp0_o = -H_oe in_e   (= D_oe in_e)
-  cop_.self_mul(ctmp_[1], ctmp_[0], Ve, V, true, st_);       // tmp1_o = D_oo^-1 tmp0_o
-  cop_.hop(out, ctmp_[1], 0, Ve, +1.0, true, st_);           // out_e += H_eo tmp1_o  (= -D_eo tmp1_o)
+  MGLevel<T>& lv = *lv_.back();
+  const int V = lv.g->V, Ve = V / 2;
+  lv.cop.self_mul(out, in, 0, Ve, false, st_);                 // out_e = D_ee in_e
+  lv.cop.hop(lv.buf[0], in, Ve, V, -1.0, false, st_);          // tmp0_o = -H_oe in_e   (= D_oe in_e)
+  lv.cop.self_mul(lv.buf[1], lv.buf[0], Ve, V, true, st_);     // tmp1_o = D_oo^-1 tmp0_o
+  lv.cop.hop(out, lv.buf[1], 0, Ve, +1.0, true, st_);          // out_e += H_eo tmp1_o  (= -D_eo tmp1_o)
 }
 
 template <typename T>
 int Multigrid<T>::coarse_solve() {
-  const int Ve = g1_.V / 2, V = g1_.V;
-  T *x = cg_.x, *b = cg_.b;
-  cop_.self_mul(x, b, Ve, V, true, st_);          // x_o = D_oo^-1 b_o
-  cop_.hop(b, x, 0, Ve, +1.0, true, st_);         // b_e <- b_e - D_eo x_o
-  int it = cg_.solve();                           // S x_e = b_e  to coarse_tol
-  cop_.hop(b, x, Ve, V, +1.0, true, st_);         // b_o <- b_o - D_oe x_e
-  cop_.self_mul(x, b, Ve, V, true, st_);          // x_o = D_oo^-1 b_o
+  MGLevel<T>& lv = *lv_.back();
+  const int V = lv.g->V, Ve = V / 2;
+  T *x = lv.gm.x, *b = lv.gm.b;
+  lv.cop.self_mul(x, b, Ve, V, true, st_);          // x_o = D_oo^-1 b_o
+  lv.cop.hop(b, x, 0, Ve, +1.0, true, st_);         // b_e <- b_e - D_eo x_o
+  int it = lv.gm.solve();                           // S x_e = b_e  to coarse_tol
+  lv.cop.hop(b, x, Ve, V, +1.0, true, st_);         // b_o <- b_o - D_oe x_e
+  lv.cop.self_mul(x, b, Ve, V, true, st_);          // x_o = D_oo^-1 b_o
   coarse_iter_count += it;
   return it;
 }
 
-// ---- V-cycle (post-smoothing only; two levels) ---------------------------------------------------
+// ---- V-cycle / K-cycle (post-smoothing only) --------------------------------------------------------
 template <typename T>
-void Multigrid<T>::vcycle(T* phi, T* Dphi, const T* eta, int res) {
-  const View all = whole((size_t)24 * g0_.V);
+void Multigrid<T>::vcycle(int l, T* phi, T* Dphi, const T* eta, int res) {
+  MGLevel<T>& lv = *lv_[l];
+  MGLevel<T>& nx = *lv_[l + 1];
   if (res == NO_RES) {
-    ip_.restrict_to(cg_.b, eta, st_);
+    restrict_to(l, nx.gm.b, eta);
   } else {
-    fop_->apply(fbuf_[0], phi, st_);
-    vec_minus<T>(fbuf_[1], eta, fbuf_[0], all, st_);
-    ip_.restrict_to(cg_.b, fbuf_[1], st_);
+    apply_op(l, lv.buf[0], phi);
+    vec_minus<T>(lv.buf[1], eta, lv.buf[0], whole(lv.nel), st_);
+    restrict_to(l, nx.gm.b, lv.buf[1]);
   }
-  coarse_solve();
-  ip_.interpolate(phi, cg_.x, res != NO_RES, st_);
-  sap_.smooth(phi, Dphi, eta, par_.post_smooth_iter[0], RES, st_);
+  if (nx.coarsest) {
+    coarse_solve();
+  } else if (par_.kcycle) {
+    nx.gm.initial_guess_zero = true;
+    nx.gm.solve();     // FGMRES on level l+1, preconditioned by vcycle(l+1)
+  } else {
+    vcycle(l + 1, nx.gm.x, nullptr, nx.gm.b, NO_RES);
+  }
+  interpolate(l, phi, nx.gm.x, res != NO_RES);
+  smoother(l, phi, Dphi, eta, par_.post_smooth_iter[l], RES);
 }
 
 // ---- setup ------------------------------------------------------------------------------------------
 template <typename T>
-double Multigrid<T>::norm_of(const T* v) {
-  vec_norm<T>(v, whole((size_t)24 * g0_.V), rw_f_, rw_f_.d_result, st_);
-  DDAMG_HIP_CHECK(hipMemcpyAsync(rw_f_.h_result, rw_f_.d_result, sizeof(double), hipMemcpyDeviceToHost, st_));
+double Multigrid<T>::norm_of(int l, const T* v) {
+  MGLevel<T>& lv = *lv_[l];
+  ReduceWork& rw = lv_[l]->rw;
+  vec_norm<T>(v, whole(lv.nel), rw, rw.d_result, st_);
+  DDAMG_HIP_CHECK(hipMemcpyAsync(rw.h_result, rw.d_result, sizeof(double), hipMemcpyDeviceToHost, st_));
   DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
-  return rw_f_.h_result[0];
+  return rw.h_result[0];
 }
 
+// vector_PRECISION_define_random (src/data_generic.c:42-56): libc rand(), in the order of the reference's
+// vector loop on this level; gcc evaluates the imaginary operand's rand() first (fixture rng_probe)
 template <typename T>
-void Multigrid<T>::upload_site_major(T* dst, const std::vector<double>& h) {
-  DDAMG_HIP_CHECK(hipMemcpyAsync(d_stage_, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, st_));
-  vec_from_lex<T>(dst, d_stage_, d_identity_, g0_.V, 12, st_);
-  DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
-}
-
-template <typename T>
-void Multigrid<T>::initial_setup() {
-  const View all = whole((size_t)24 * g0_.V);
-  const size_t nel = (size_t)24 * g0_.V;
-  std::vector<double> h(nel);
-  for (int k = 0; k < nvec_; k++) {
-    // vector_PRECISION_define_random (src/data_generic.c:42-56): libc rand(), site-major in the
-    // Schwarz ordering (= our fine ordering); gcc evaluates the imaginary operand's rand() first
-    // (pinned by tests/golden rng_probe)
-    for (size_t i = 0; i < nel / 2; i++) {
+void Multigrid<T>::random_vector(int l, T* dst) {
+  MGLevel<T>& lv = *lv_[l];
+  const int n = lv.n, V = lv.g->V;
+  std::vector<double> h((size_t)V * n * 2);
+  for (int pos = 0; pos < V; pos++) {
+    const size_t site = l == 0 ? (size_t)pos : (size_t)lv.ref_order[pos];
+    for (int d = 0; d < n; d++) {
       const double im = (double)(T)(((double)rand() / (double)RAND_MAX)) - 0.5;
       const double re = (double)(T)(((double)rand() / (double)RAND_MAX)) - 0.5;
-      h[2 * i] = re; h[2 * i + 1] = im;
-    }
-    T* tv = ip_.test_vector(k);
-    upload_site_major(tv, h);
-    // three smoother passes with 1, 2, 3 cycles (src/setup_generic.c:215-231)
-    for (int c = 1; c <= 3; c++) {
-      sap_.smooth(fbuf_[0], nullptr, tv, c, NO_RES, st_);
-      vec_copy<T>(tv, fbuf_[0], all, st_);
+      h[(site * n + d) * 2] = re; h[(site * n + d) * 2 + 1] = im;
     }
   }
-  for (int k = 0; k < nvec_; k++) {
-    T* tv = ip_.test_vector(k);
-    const double nrm = norm_of(tv);
-    vec_scale<T>(tv, tv, 1.0 / nrm, 0.0, all, st_);
-  }
-  re_setup();
-}
-
-template <typename T>
-void Multigrid<T>::re_setup() {
-  ip_.orthonormalize(st_);
-  build_coarse_operator();
-}
-
-template <typename T>
-void Multigrid<T>::build_coarse_operator() {
-  for (int chir = 0; chir < 2; chir++)
-    for (int j = 0; j < nvec_; j++) {
-      aggregate_dirac<T>(W_, ip_.interp_vector(j), chir, *fop_, d_agg_face_, st_);
-      galerkin_column<T>(cop_, ip_, W_, chir * nvec_ + j, cwork_, st_);
-    }
-  cop_.compute_self_inverse(st_);
+  DDAMG_HIP_CHECK(hipMemcpyAsync(d_stage_, h.data(), sizeof(double) * h.size(), hipMemcpyHostToDevice, st_));
+  if (l == 0) vec_from_lex<T>(dst, d_stage_, d_identity0_, V, 12, st_);
+  else aos_from_lex<T>(dst, d_stage_, d_identity0_, V, n, st_);   // identity order: the host array is already site-major
   DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
 }
 
 template <typename T>
-void Multigrid<T>::operator_changed() { build_coarse_operator(); }
+void Multigrid<T>::define_interpolation(int l) {
+  MGLevel<T>& lv = *lv_[l];
+  const View all = whole(lv.nel);
+  for (int k = 0; k < lv.nvec; k++) {
+    T* tv = test_vector(l, k);
+    random_vector(l, tv);
+    // three smoother passes with 1, 2, 3 cycles (src/setup_generic.c:215-231)
+    for (int c = 1; c <= 3; c++) {
+      smoother(l, lv.buf[2], nullptr, tv, c, NO_RES);
+      vec_copy<T>(tv, lv.buf[2], all, st_);
+    }
+  }
+  for (int k = 0; k < lv.nvec; k++) {
+    T* tv = test_vector(l, k);
+    vec_scale<T>(tv, tv, 1.0 / norm_of(l, tv), 0.0, all, st_);
+  }
+}
+
+template <typename T>
+void Multigrid<T>::orthonormalize(int l) {
+  // interpolation <- test vectors, Gram-Schmidt on aggregates; done twice on depth > 0 in re_setup (src/setup_generic.c:291-292)
+  if (l == 0) lv_[0]->fip.orthonormalize(st_);
+  else lv_[l]->cip.orthonormalize(2, st_);
+}
+
+template <typename T>
+void Multigrid<T>::build_coarse_operator(int l) {
+  MGLevel<T>& lv = *lv_[l];
+  MGLevel<T>& nx = *lv_[l + 1];
+  const int N = lv.nvec;
+  if (l == 0) {
+    for (int chir = 0; chir < 2; chir++)
+      for (int j = 0; j < N; j++) {
+        aggregate_dirac<T>(W_, lv.fip.interp_vector(j), chir, *lv.fop, lv.d_agg_face, st_);
+        galerkin_column<T>(nx.cop, lv.fip, W_, chir * N + j, cwork_, st_);
+      }
+  } else {
+    // coarse_aggregate_self_couplings / coarse_aggregate_neighbor_couplings (src/coarse_operator_generic.c:238-285):
+    // the same masked gather kernel as the operator itself, restricted with this level's P
+    const int V = lv.g->V;
+    for (int chir = 0; chir < 2; chir++)
+      for (int j = 0; j < N; j++) {
+        aos_chirality_copy<T>(lv.buf[2], lv.cip.interp_vector(j), V, lv.n, chir, st_);
+        lv.cop.apply_masked(lv.buf[3], lv.buf[2], nullptr, V, lv.d_agg_face, true, 1.0, -1.0, false, st_);
+        lv.cip.restrict_to(cwork_, lv.buf[3], st_);
+        store_matrix_column<T>(nx.cop, cwork_, 0, chir * N + j, st_);
+        for (int mu = 0; mu < 4; mu++) {
+          lv.cop.apply_masked(lv.buf[3], lv.buf[2], nullptr, V, lv.d_dir_mask[mu], false, 0.0, +1.0, false, st_);
+          lv.cip.restrict_to(cwork_, lv.buf[3], st_);
+          store_matrix_column<T>(nx.cop, cwork_, 1 + mu, chir * N + j, st_);
+        }
+      }
+  }
+  if (nx.coarsest) nx.cop.compute_self_inverse(st_);
+  DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
+}
+
+template <typename T>
+void Multigrid<T>::re_setup(int l) {
+  if (lv_[l]->coarsest) return;
+  orthonormalize(l);
+  build_coarse_operator(l);
+  re_setup(l + 1);
+}
+
+template <typename T>
+void Multigrid<T>::initial_setup() { initial_setup_from(0); }
+
+template <typename T>
+void Multigrid<T>::initial_setup_from(int l0) {
+  // method_setup -> next_level_setup -> interpolation_PRECISION_define -> coarse_grid_correction_PRECISION_setup
+  const int L = num_levels();
+  for (int l = l0; l + 1 < L; l++) {
+    MGLevel<T>& lv = *lv_[l];
+    if (l > 0) {
+      // the reference first fills the extra test vectors of this level with random numbers
+      // (src/setup_generic.c:96-101) and then redefines ALL of them at random (:212-214): same rand() stream
+      const int nprev = lv_[l - 1]->nvec;
+      for (int i = std::min(lv.nvec, nprev); i < lv.nvec; i++) random_vector(l, test_vector(l, i));
+    }
+    define_interpolation(l);
+    if (l == 0) lv.fip.orthonormalize(st_); else lv.cip.orthonormalize(1, st_);
+    build_coarse_operator(l);
+  }
+}
+
+template <typename T>
+void Multigrid<T>::bootstrap(int l, int iters) {
+  MGLevel<T>& lv = *lv_[l];
+  const View all = whole(lv.nel);
+  const size_t stride = tv_stride(l);
+  for (int j = 0; j < iters; j++) {
+    // gram_schmidt_PRECISION on the test vectors (classical, src/linalg_generic.c:483-528)
+    for (int i = 0; i < lv.nvec; i++) {
+      T* vi = test_vector(l, i);
+      if (i > 0) {
+        vec_multi_dot<T>(tv_base(l), stride, i, vi, all, lv.rw, lv.rw.d_result, st_);
+        vec_multi_axpy_dev<T>(vi, tv_base(l), stride, i, lv.rw.d_result, -1.0, all, st_);
+      }
+      vec_scale<T>(vi, vi, 1.0 / norm_of(l, vi), 0.0, all, st_);
+    }
+    for (int i = 0; i < lv.nvec; i++) {
+      T* out = l == 0 ? lv.buf[2] : lv.gm.x;   // the reference writes into l->p_PRECISION.x
+      vcycle(l, out, nullptr, test_vector(l, i), NO_RES);
+      // test_vector_PRECISION_update: deeper intermediate levels first, from their K-cycle iterate
+      for (int d = num_levels() - 2; d > l; d--) {
+        MGLevel<T>& dl = *lv_[d];
+        if (i < dl.nvec) vec_scale<T>(test_vector(d, i), dl.gm.x, 1.0 / norm_of(d, dl.gm.x), 0.0, whole(dl.nel), st_);
+      }
+      vec_scale<T>(test_vector(l, i), out, 1.0 / norm_of(l, out), 0.0, all, st_);
+    }
+    re_setup(l);
+    if (l == 0 && !lv_[1]->coarsest)
+      bootstrap(1, std::max(1, (int)std::lround((double)((j + 1) * par_.setup_iter[1]) / (double)iters)));
+  }
+  if (l > 0 && !lv_[l + 1]->coarsest)
+    bootstrap(l + 1, std::max(1, (int)std::lround((double)(par_.setup_iter[l + 1] * iters) / (double)par_.setup_iter[l])));
+}
 
 template <typename T>
 void Multigrid<T>::iterative_setup(int iters) {
-  // inv_iter_inv_fcycle_PRECISION (src/setup_generic.c:441-503), two-level case
-  const View all = whole((size_t)24 * g0_.V);
-  const size_t stride = ip_.pstride;
-  for (int j = 0; j < iters; j++) {
-    // gram_schmidt_PRECISION on the test vectors (classical, src/linalg_generic.c:483-528)
-    for (int i = 0; i < nvec_; i++) {
-      T* vi = ip_.test_vector(i);
-      if (i > 0) {
-        vec_multi_dot<T>(ip_.tv, stride, i, vi, all, rw_f_, rw_f_.d_result, st_);
-        vec_multi_axpy_dev<T>(vi, ip_.tv, stride, i, rw_f_.d_result, -1.0, all, st_);
-      }
-      const double beta = norm_of(vi);
-      vec_scale<T>(vi, vi, 1.0 / beta, 0.0, all, st_);
-    }
-    for (int i = 0; i < nvec_; i++) {
-      T* vi = ip_.test_vector(i);
-      vcycle(fbuf_[2], nullptr, vi, NO_RES);
-      const double nrm = norm_of(fbuf_[2]);
-      vec_scale<T>(vi, fbuf_[2], 1.0 / nrm, 0.0, all, st_);
-    }
-    re_setup();
-  }
+  if (iters <= 0) return;
+  set_kcycle_tol(par_.coarse_tol);   // src/setup_generic.c:447-449
+  bootstrap(0, iters);
+  set_kcycle_tol(par_.kcycle_tol);
+}
+
+template <typename T>
+void Multigrid<T>::operator_changed() {
+  for (int l = 0; l + 1 < num_levels(); l++) build_coarse_operator(l);
 }
 
 template <typename T>
 void Multigrid<T>::import_test_vectors(const double* tv_lex_host) {
-  // lexicographic host vectors -> device test vectors (needs the level-0 lex table: rebuild it here)
-  int* d_lex = nullptr;
-  DDAMG_HIP_CHECK(hipMalloc(&d_lex, sizeof(int) * g0_.V));
-  DDAMG_HIP_CHECK(hipMemcpy(d_lex, g0_.lex_of_site.data(), sizeof(int) * g0_.V, hipMemcpyHostToDevice));
-  const size_t nel = (size_t)24 * g0_.V;
-  for (int k = 0; k < nvec_; k++) {
-    DDAMG_HIP_CHECK(hipMemcpyAsync(d_stage_, tv_lex_host + (size_t)k * nel, sizeof(double) * nel, hipMemcpyHostToDevice, st_));
-    vec_from_lex<T>(ip_.test_vector(k), d_stage_, d_lex, g0_.V, 12, st_);
+  MGLevel<T>& lv = *lv_[0];
+  for (int k = 0; k < lv.nvec; k++) {
+    DDAMG_HIP_CHECK(hipMemcpyAsync(d_stage_, tv_lex_host + (size_t)k * lv.nel, sizeof(double) * lv.nel, hipMemcpyHostToDevice, st_));
+    vec_from_lex<T>(lv.fip.test_vector(k), d_stage_, d_lex0_, lv.g->V, 12, st_);
     DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
   }
-  (void)hipFree(d_lex);
-  re_setup();
+  re_setup(0);
 }
 
 template <typename T>
 void Multigrid<T>::import_interpolation(const double* P_lex_host) {
-  int* d_lex = nullptr;
-  DDAMG_HIP_CHECK(hipMalloc(&d_lex, sizeof(int) * g0_.V));
-  DDAMG_HIP_CHECK(hipMemcpy(d_lex, g0_.lex_of_site.data(), sizeof(int) * g0_.V, hipMemcpyHostToDevice));
-  const size_t nel = (size_t)24 * g0_.V;
-  for (int k = 0; k < nvec_; k++) {
-    DDAMG_HIP_CHECK(hipMemcpyAsync(d_stage_, P_lex_host + (size_t)k * nel, sizeof(double) * nel, hipMemcpyHostToDevice, st_));
-    vec_from_lex<T>(ip_.interp_vector(k), d_stage_, d_lex, g0_.V, 12, st_);
+  MGLevel<T>& lv = *lv_[0];
+  for (int k = 0; k < lv.nvec; k++) {
+    DDAMG_HIP_CHECK(hipMemcpyAsync(d_stage_, P_lex_host + (size_t)k * lv.nel, sizeof(double) * lv.nel, hipMemcpyHostToDevice, st_));
+    vec_from_lex<T>(lv.fip.interp_vector(k), d_stage_, d_lex0_, lv.g->V, 12, st_);
     DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
   }
-  (void)hipFree(d_lex);
-  build_coarse_operator();
+  build_coarse_operator(0);
+  initial_setup_from(1);   // deeper levels get their own initial setup on the new level-1 operator
 }
 
 template class Multigrid<float>;

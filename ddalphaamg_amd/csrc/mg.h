@@ -1,8 +1,10 @@
-// mg.h -- the multigrid hierarchy, V-cycle and setup (host orchestration of the HIP kernels).
-// Reference: vcycle_PRECISION / smoother_PRECISION src/vcycle_generic.c:25-141,
-//   coarse_solve_odd_even_PRECISION / coarse_apply_schur_complement_PRECISION
-//   src/coarse_oddeven_generic.c:1139-1189, interpolation_PRECISION_define src/setup_generic.c:191-275,
-//   re_setup_PRECISION :278-321, inv_iter_inv_fcycle_PRECISION :441-503,
+// mg.h -- the multigrid hierarchy (2 to 4 levels), V/K-cycle and setup: host orchestration of the HIP kernels.
+// Reference: vcycle_PRECISION / smoother_PRECISION src/vcycle_generic.c:25-141 (post-smoothing only; K-cycle =
+//   FGMRES(kcycle_restart, kcycle_max_restart, kcycle_tol) on every intermediate level, :110-114),
+//   coarse_solve_odd_even_PRECISION / coarse_apply_schur_complement_PRECISION src/coarse_oddeven_generic.c:1139-1189,
+//   next_level_setup src/init.c:32-120, interpolation_PRECISION_define src/setup_generic.c:191-275,
+//   coarse_grid_correction_PRECISION_setup :29-108, re_setup_PRECISION :278-321,
+//   inv_iter_inv_fcycle_PRECISION / test_vector_PRECISION_update :418-503,
 //   coarse_operator_PRECISION_setup src/coarse_operator_generic.c:53-100.
 #pragma once
 #include "common.h"
@@ -11,66 +13,89 @@
 #include "sap.h"
 #include "transfer.h"
 #include "coarse_op.h"
+#include "coarse_mg.h"
 #include "krylov.h"
 #include "../../include/ddamg_hip.h"
+#include <memory>
+#include <vector>
 
 namespace ddamg {
 
 template <typename T>
+struct MGLevel {
+  int depth = 0;
+  const Geometry* g = nullptr;
+  int n = 12;            // complex dof per site
+  int nvec = 0;          // test vectors on this level (0 on the coarsest)
+  bool coarsest = false;
+  size_t nel = 0;        // reals per vector
+  // operators
+  const FineOp<T>* fop = nullptr;   // depth 0
+  CoarseOp<T> cop;                  // depth > 0
+  // smoother + transfer to the next level (not on the coarsest level)
+  SapSmoother<T> fsap; Interpolation<T> fip;     // depth 0
+  CoarseSap<T> csap; CoarseTransfer<T> cip;      // depth > 0
+  // Krylov solver of this level: K-cycle FGMRES (intermediate) or even-site Schur GMRES (coarsest)
+  Gmres<T> gm;
+  ReduceWork rw;
+  T* buf[4] = {nullptr, nullptr, nullptr, nullptr};
+  // setup helpers
+  unsigned char* d_agg_face = nullptr;
+  unsigned char* d_dir_mask[4] = {nullptr, nullptr, nullptr, nullptr};
+  std::vector<int> ref_order;   // site visited i-th by the reference's vector loops on this level
+};
+
+template <typename T>
 class Multigrid {
  public:
-  Multigrid(const ddamg_hip_params& par, const Geometry& g0, const Geometry& g1, const FineOp<T>* fop, hipStream_t st);
+  Multigrid(const ddamg_hip_params& par, const std::vector<const Geometry*>& geoms, const FineOp<T>* fop, hipStream_t st);
   ~Multigrid();
 
   // ---- setup -------------------------------------------------------------------------------
-  void initial_setup();                 // random test vectors -> smoother -> P -> D_c   (method_setup)
-  void iterative_setup(int iters);      // bootstrap V-cycles on the test vectors       (method_update)
-  void import_test_vectors(const double* tv_lex_host);  // [nvec][V][12] complex, lexicographic; then re_setup()
-  void import_interpolation(const double* P_lex_host);  // already orthonormalised vectors (no Gram-Schmidt)
-  void re_setup();                      // P = GS_aggregates(test vectors), D_c = P^H D P
-  void build_coarse_operator();         // D_c = P^H D P from the current P
-  void operator_changed();              // fine operator was re-uploaded: refresh what depends on it
+  void initial_setup();                 // method_setup
+  void initial_setup_from(int l0);
+  void iterative_setup(int iters);      // method_update
+  void import_test_vectors(const double* tv_lex_host);   // level-0 test vectors, then re_setup(0)
+  void import_interpolation(const double* P_lex_host);   // level-0 interpolation vectors as they are
+  void operator_changed();              // fine operator re-uploaded: rebuild the coarse operators
+  void set_kcycle_tol(double tol);
 
   // ---- hot path -----------------------------------------------------------------------------
-  void smoother(T* phi, T* Dphi, const T* eta, int cycles, int res) { sap_.smooth(phi, Dphi, eta, cycles, res, st_); }
-  void restrict_to(T* phi_c, const T* phi) { ip_.restrict_to(phi_c, phi, st_); }
-  void interpolate(T* phi, const T* phi_c, bool add) { ip_.interpolate(phi, phi_c, add, st_); }
-  void coarse_apply(T* out, const T* in) { cop_.apply(out, in, st_); }
-  // solves D_c x = b on the coarsest level: x, b are the solver's own vectors (coarse_x()/coarse_b())
-  int coarse_solve();
-  void vcycle(T* phi, T* Dphi, const T* eta, int res);
+  void apply_op(int l, T* out, const T* in);
+  void smoother(int l, T* phi, T* Dphi, const T* eta, int cycles, int res);
+  void restrict_to(int l, T* phi_c, const T* phi);               // level l -> l+1
+  void interpolate(int l, T* phi, const T* phi_c, bool add);     // level l+1 -> l
+  int coarse_solve();                                            // coarsest level, vectors coarse_x()/coarse_b()
+  void vcycle(int l, T* phi, T* Dphi, const T* eta, int res);
 
-  T* coarse_x() { return cg_.x; }
-  T* coarse_b() { return cg_.b; }
-  CoarseOp<T>& coarse_op() { return cop_; }
-  Interpolation<T>& interpolation() { return ip_; }
-  SapSmoother<T>& sap() { return sap_; }
+  int num_levels() const { return (int)lv_.size(); }
+  MGLevel<T>& level(int l) { return *lv_[l]; }
+  T* coarse_x() { return lv_.back()->gm.x; }
+  T* coarse_b() { return lv_.back()->gm.b; }
   int coarse_iter_count = 0;
-  int nvec() const { return nvec_; }
-  int Vc() const { return g1_.V; }
 
  private:
   ddamg_hip_params par_;
-  const Geometry& g0_;
-  const Geometry& g1_;
-  const FineOp<T>* fop_;
   hipStream_t st_;
-  int nvec_, n1_;
-  SapSmoother<T> sap_;
-  Interpolation<T> ip_;
-  CoarseOp<T> cop_;
-  Gmres<T> cg_;        // coarsest-level GMRES on the even-site Schur complement
-  ReduceWork rw_c_, rw_f_;
-  T* ctmp_[2] = {nullptr, nullptr};   // coarse temporaries (Schur complement)
-  T* fbuf_[3] = {nullptr, nullptr, nullptr};  // fine work vectors
-  T* W_ = nullptr;       // 5 fine vectors for the Galerkin construction
-  T* cwork_ = nullptr;   // 5 coarse vectors
-  unsigned char* d_agg_face_ = nullptr;
-  int* d_identity_ = nullptr;
+  std::vector<std::unique_ptr<MGLevel<T>>> lv_;
+  int* d_lex0_ = nullptr;
+  int* d_identity0_ = nullptr;
   double* d_stage_ = nullptr;
+  T* W_ = nullptr;        // 5 level-0 vectors (Galerkin)
+  T* cwork_ = nullptr;    // coarse work space (5 vectors of the largest coarse level)
+
   void schur(T* out, const T* in);
-  void upload_site_major(T* dst, const std::vector<double>& host_site_major);
-  double norm_of(const T* v);
+  double norm_of(int l, const T* v);
+  void random_vector(int l, T* dst);
+  void define_interpolation(int l);     // interpolation_PRECISION_define(NULL, level l)
+  void re_setup(int l);                 // recursive re_setup_PRECISION
+  void build_coarse_operator(int l);    // D_{l+1} = P_l^H D_l P_l
+  void orthonormalize(int l);
+  void bootstrap(int l, int iters);     // inv_iter_inv_fcycle_PRECISION
+  T* test_vector(int l, int j) { return l == 0 ? lv_[0]->fip.test_vector(j) : lv_[l]->cip.test_vector(j); }
+  T* interp_vector(int l, int j) { return l == 0 ? lv_[0]->fip.interp_vector(j) : lv_[l]->cip.interp_vector(j); }
+  T* tv_base(int l) { return l == 0 ? lv_[0]->fip.tv : lv_[l]->cip.tv; }
+  size_t tv_stride(int l) { return l == 0 ? lv_[0]->fip.pstride : lv_[l]->cip.pstride; }
 };
 
 }  // namespace ddamg

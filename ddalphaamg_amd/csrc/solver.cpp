@@ -24,12 +24,14 @@ extern thread_local std::string g_ddamg_last_error;
 
 static void ensure_mg(ddamg_hip_ctx* c) {
   DDAMG_REQUIRE(c->have_operator, "no operator set (call ddamg_hip_set_gauge / ddamg_hip_set_operator first)");
-  DDAMG_REQUIRE(c->par.num_levels == 2, "multigrid needs num_levels == 2 in this build");
+  DDAMG_REQUIRE(c->par.num_levels >= 2, "multigrid needs at least two levels");
   DDAMG_REQUIRE(c->par.method == 2, "multigrid preconditioner needs method == 2 (red-black SAP)");
+  std::vector<const Geometry*> geoms;
+  for (auto& lv : c->levels) geoms.push_back(&lv->geom);
   if (c->par.mixed_precision == 0) {
-    if (!c->mg64) c->mg64.reset(new Multigrid<double>(c->par, c->levels[0]->geom, c->levels[1]->geom, &c->fop64, c->stream));
+    if (!c->mg64) c->mg64.reset(new Multigrid<double>(c->par, geoms, &c->fop64, c->stream));
   } else {
-    if (!c->mg32) c->mg32.reset(new Multigrid<float>(c->par, c->levels[0]->geom, c->levels[1]->geom, &c->fop32, c->stream));
+    if (!c->mg32) c->mg32.reset(new Multigrid<float>(c->par, geoms, &c->fop32, c->stream));
   }
 }
 
@@ -46,7 +48,7 @@ static void ensure_outer(ddamg_hip_ctx* c) {
   c->outer.op = [c](double* out, const double* in) { c->fop64.apply(out, in, c->stream); };
   if (c->par.method > 0) {
     if (c->par.mixed_precision == 0) {
-      c->outer.prec = [c](double* phi, double* Dphi, const double* eta, int res) { c->mg64->vcycle(phi, Dphi, eta, res); };
+      c->outer.prec = [c](double* phi, double* Dphi, const double* eta, int res) { c->mg64->vcycle(0, phi, Dphi, eta, res); };
     } else {
       DDAMG_HIP_CHECK(hipMalloc(&c->p32_in, sizeof(float) * n));
       DDAMG_HIP_CHECK(hipMalloc(&c->p32_out, sizeof(float) * n));
@@ -54,7 +56,7 @@ static void ensure_outer(ddamg_hip_ctx* c) {
       c->outer.prec = [c](double* phi, double* Dphi, const double* eta, int res) {
         const size_t V = c->levels[0]->geom.V;
         vec_convert<float, double>(c->p32_in, eta, V, 24, c->stream);
-        c->mg32->vcycle(c->p32_out, nullptr, c->p32_in, res);
+        c->mg32->vcycle(0, c->p32_out, nullptr, c->p32_in, res);
         vec_convert<double, float>(phi, c->p32_out, V, 24, c->stream);
       };
     }
@@ -104,8 +106,8 @@ int ddamg_hip_get_interpolation(ddamg_hip_ctx* c, double* P_lex) {
   const int nvec = c->par.num_vect[0];
   double* st = c->stage(sizeof(double) * nel);
   for (int k = 0; k < nvec; k++) {
-    if (c->mg32) vec_to_lex<float>(st, c->mg32->interpolation().interp_vector(k), c->levels[0]->d_lex_of_site, (int)V, 12, c->stream);
-    else vec_to_lex<double>(st, c->mg64->interpolation().interp_vector(k), c->levels[0]->d_lex_of_site, (int)V, 12, c->stream);
+    if (c->mg32) vec_to_lex<float>(st, c->mg32->level(0).fip.interp_vector(k), c->levels[0]->d_lex_of_site, (int)V, 12, c->stream);
+    else vec_to_lex<double>(st, c->mg64->level(0).fip.interp_vector(k), c->levels[0]->d_lex_of_site, (int)V, 12, c->stream);
     DDAMG_HIP_CHECK(hipMemcpyAsync(P_lex + (size_t)k * nel, st, sizeof(double) * nel, hipMemcpyDeviceToHost, c->stream));
     DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
   }
@@ -116,8 +118,8 @@ int ddamg_hip_get_coarse_operator(ddamg_hip_ctx* c, double* D_lex, double* clove
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c && c->setup_done, "setup has not been run");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
-  if (c->mg32) c->mg32->coarse_op().export_reference(c->levels[1]->geom, D_lex, clover_lex, c->stream);
-  else c->mg64->coarse_op().export_reference(c->levels[1]->geom, D_lex, clover_lex, c->stream);
+  if (c->mg32) c->mg32->level(1).cop.export_reference(c->levels[1]->geom, D_lex, clover_lex, c->stream);
+  else c->mg64->level(1).cop.export_reference(c->levels[1]->geom, D_lex, clover_lex, c->stream);
   DDAMG_API_END
 }
 
@@ -126,8 +128,8 @@ int ddamg_hip_set_coarse_operator(ddamg_hip_ctx* c, const double* D_lex, const d
   DDAMG_REQUIRE(c && D_lex && clover_lex, "null argument");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
   ensure_mg(c);
-  if (c->mg32) c->mg32->coarse_op().import_reference(c->levels[1]->geom, D_lex, clover_lex, c->stream);
-  else c->mg64->coarse_op().import_reference(c->levels[1]->geom, D_lex, clover_lex, c->stream);
+  if (c->mg32) c->mg32->level(1).cop.import_reference(c->levels[1]->geom, D_lex, clover_lex, c->stream);
+  else c->mg64->level(1).cop.import_reference(c->levels[1]->geom, D_lex, clover_lex, c->stream);
   DDAMG_API_END
 }
 
@@ -144,8 +146,8 @@ int ddamg_hip_smoother(ddamg_hip_ctx* c, ddamg_hip_vec* phi, const ddamg_hip_vec
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
   ensure_mg(c);
   check_vec(c, phi, 0); check_vec(c, eta, 0);
-  if (c->mg32) c->mg32->smoother((float*)phi->data, nullptr, (const float*)eta->data, cycles, initial_guess_zero ? NO_RES : RES);
-  else c->mg64->smoother((double*)phi->data, nullptr, (const double*)eta->data, cycles, initial_guess_zero ? NO_RES : RES);
+  if (c->mg32) c->mg32->smoother(0, (float*)phi->data, nullptr, (const float*)eta->data, cycles, initial_guess_zero ? NO_RES : RES);
+  else c->mg64->smoother(0, (double*)phi->data, nullptr, (const double*)eta->data, cycles, initial_guess_zero ? NO_RES : RES);
   DDAMG_API_END
 }
 
@@ -154,8 +156,8 @@ int ddamg_hip_restrict(ddamg_hip_ctx* c, ddamg_hip_vec* coarse, const ddamg_hip_
   DDAMG_REQUIRE(c && c->setup_done, "setup has not been run");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
   check_vec(c, coarse, 1); check_vec(c, fine, 0);
-  if (c->mg32) c->mg32->restrict_to((float*)coarse->data, (const float*)fine->data);
-  else c->mg64->restrict_to((double*)coarse->data, (const double*)fine->data);
+  if (c->mg32) c->mg32->restrict_to(0, (float*)coarse->data, (const float*)fine->data);
+  else c->mg64->restrict_to(0, (double*)coarse->data, (const double*)fine->data);
   DDAMG_API_END
 }
 
@@ -164,8 +166,8 @@ int ddamg_hip_interpolate(ddamg_hip_ctx* c, ddamg_hip_vec* fine, const ddamg_hip
   DDAMG_REQUIRE(c && c->setup_done, "setup has not been run");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
   check_vec(c, coarse, 1); check_vec(c, fine, 0);
-  if (c->mg32) c->mg32->interpolate((float*)fine->data, (const float*)coarse->data, add != 0);
-  else c->mg64->interpolate((double*)fine->data, (const double*)coarse->data, add != 0);
+  if (c->mg32) c->mg32->interpolate(0, (float*)fine->data, (const float*)coarse->data, add != 0);
+  else c->mg64->interpolate(0, (double*)fine->data, (const double*)coarse->data, add != 0);
   DDAMG_API_END
 }
 
@@ -173,9 +175,10 @@ int ddamg_hip_coarse_apply(ddamg_hip_ctx* c, ddamg_hip_vec* out, const ddamg_hip
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c && (c->mg32 || c->mg64), "no coarse operator");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
-  check_vec(c, out, 1); check_vec(c, in, 1);
-  if (c->mg32) c->mg32->coarse_apply((float*)out->data, (const float*)in->data);
-  else c->mg64->coarse_apply((double*)out->data, (const double*)in->data);
+  DDAMG_REQUIRE(out && in && out->level >= 1 && out->level == in->level, "coarse vectors of one level expected");
+  check_vec(c, out, out->level); check_vec(c, in, in->level);
+  if (c->mg32) c->mg32->apply_op(out->level, (float*)out->data, (const float*)in->data);
+  else c->mg64->apply_op(out->level, (double*)out->data, (const double*)in->data);
   DDAMG_API_END
 }
 
@@ -183,7 +186,8 @@ int ddamg_hip_coarse_solve(ddamg_hip_ctx* c, ddamg_hip_vec* x, const ddamg_hip_v
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c && (c->mg32 || c->mg64), "no coarse operator");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
-  check_vec(c, x, 1); check_vec(c, b, 1);
+  const int lc = c->par.num_levels - 1;   // the coarsest level
+  check_vec(c, x, lc); check_vec(c, b, lc);
   int it;
   if (c->mg32) {
     DDAMG_HIP_CHECK(hipMemcpyAsync(c->mg32->coarse_b(), b->data, b->bytes, hipMemcpyDeviceToDevice, c->stream));
@@ -203,8 +207,8 @@ int ddamg_hip_vcycle(ddamg_hip_ctx* c, ddamg_hip_vec* phi, const ddamg_hip_vec* 
   DDAMG_REQUIRE(c && c->setup_done, "setup has not been run");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
   check_vec(c, phi, 0); check_vec(c, eta, 0);
-  if (c->mg32) c->mg32->vcycle((float*)phi->data, nullptr, (const float*)eta->data, NO_RES);
-  else c->mg64->vcycle((double*)phi->data, nullptr, (const double*)eta->data, NO_RES);
+  if (c->mg32) c->mg32->vcycle(0, (float*)phi->data, nullptr, (const float*)eta->data, NO_RES);
+  else c->mg64->vcycle(0, (double*)phi->data, nullptr, (const double*)eta->data, NO_RES);
   DDAMG_API_END
 }
 

@@ -52,6 +52,11 @@ CASES = {
     "8x8_dirac": dict(conf="conf/8x8x8x8b6.0000id3n1", levels=2, L="8 8 8 8", B="4 4 4 4", nvec=4, setup=0,
                       extra="d1 global lattice: 2 2 2 2", method=2, mp=1, keep=["meta_int", "meta_f64", "dirac_in",
                       "dirac_out_f64", "dirac_out_f32_as_f64", "clover_sample", "gauge", "conf_dims", "conf_plaq"]),
+    # the reference's sample.ini: 8^4, 3 levels (8^4 -> 4^4 -> 2^4), Nvec 28/28, K-cycle; only iteration counts and the
+    # residual history of the rhs=ones solve are kept (the gauge field is in ref_8x8_dirac.npz)
+    "8x8_3lvl": dict(conf="conf/8x8x8x8b6.0000id3n1", levels=3, L="8 8 8 8", B="2 2 2 2", nvec=28, setup=4,
+                     extra="d1 global lattice: 4 4 4 4\nd1 post smooth iter: 2\nd1 block iter: 4\nd1 test vectors: 28\nd1 setup iter: 3",
+                     method=2, mp=1, keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),
 }
 
 def run_case(name):
@@ -72,8 +77,10 @@ def run_case(name):
             shape = tuple(int(x) for x in shape.split(","))
             a = np.fromfile(os.path.join(tmp, nm + ".bin"), dtype=np.dtype("<" + dt)).reshape(shape)
             arrays[nm] = a
+        if keep is not None and "gauge" not in keep:
+            arrays.pop("gauge", None); arrays.pop("conf_dims", None)
         if keep is not None:
-            if "clover" in arrays:  # a few sites of the reference clover term, to pin set_gauge at 8^4
+            if "clover" in arrays and "clover_sample" in keep:  # a few sites of the reference clover term, to pin set_gauge at 8^4
                 arrays["clover_sample"] = arrays["clover"][::97].copy()
                 arrays["D_sample"] = arrays["D"][::97].copy()
                 keep = keep + ["D_sample"]
@@ -87,8 +94,12 @@ def run_case(name):
         arrays["conf_plaq"] = np.frombuffer(raw[16:24], dtype="<f8").copy()
         arrays["gauge"] = np.frombuffer(raw[24:], dtype="<f8").reshape(int(np.prod(dims)), 4, 9, 2).copy()
         # the text log holds the reference's residual history / iteration count
-        hist = [float(l.split(":")[1].split("|")[0]) for l in log.stdout.splitlines() if "approx. rel. res. after" in l]
+        lines = log.stdout.splitlines()
+        hist = [float(l.split(":")[1].split("|")[0]) for l in lines if "approx. rel. res. after" in l]
         arrays["ref_log_residual_history"] = np.array(hist)
+        if "BEGIN_ONES_SOLVE" in lines:
+            seg = lines[lines.index("BEGIN_ONES_SOLVE"):lines.index("END_ONES_SOLVE")]
+            arrays["ref_log_ones_history"] = np.array([float(l.split(":")[1].split("|")[0]) for l in seg if "approx. rel. res. after" in l])
         if keep is not None:
             arrays = {k: v for k, v in arrays.items() if k in keep_now or k.startswith("ref_log")}
         # arrays whose values are exactly representable in fp32 (dumps of float data) are stored as fp32

@@ -215,8 +215,23 @@ static void dump_two_level(level_struct *l, struct Thread *threading)
   free(buf); free(buf2); free(ord0); free(ordc);
 }
 
+/* ---- stage 3: full solve with rhs = ones on any hierarchy (src/top_level.c:31-104) --------- */
+static void dump_solve_ones(level_struct *l, struct Thread *threading)
+{
+  if (!(g.method > 0 && g.mixed_precision == 1)) return;
+  for (int i = 0; i < l->inner_vector_size; i++) g.p.b[i] = 1.0;
+  g.coarse_iter_count = 0;
+  printf0("BEGIN_ONES_SOLVE\n");
+  int it = fgmres_double(&(g.p), l, threading);
+  printf0("END_ONES_SOLVE\n");
+  int meta[2] = { it, g.coarse_iter_count };
+  dump("ones_solve_iters", "i4", meta, sizeof meta, "2");
+  double nr[1] = { g.norm_res }; dump("ones_solve_norm_res", "f8", nr, sizeof nr, "1");
+}
+
 static void dump_all(level_struct *l, struct Thread *threading)
 {
   dump_fine_operator(l, threading);
   dump_two_level(l, threading);
+  dump_solve_ones(l, threading);
 }

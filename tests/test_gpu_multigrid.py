@@ -178,8 +178,9 @@ def test_full_setup_and_solve_iteration_parity(gold4):
     ctx.setup(4)
     b = np.zeros((256, 12, 2)); b[..., 0] = 1.0
     x, it, cit, rr = ctx.solve(b, 1e-10)
-    ref_hist = gold4["ref_log_residual_history"]
-    assert abs(it - len(ref_hist)) <= 1
+    ref_hist = gold4["ref_log_ones_history"]
+    assert it == int(gold4["ones_solve_iters"][0]) == len(ref_hist)
+    assert abs(cit - int(gold4["ones_solve_iters"][1])) <= 8
     assert rr < 1e-10
     hist = ctx.residual_history()
     # same convergence rate as the reference (history agrees within a factor 2 per step)
@@ -216,4 +217,43 @@ def test_pure_gmres_method0(gold4):
     assert rr < 1.2e-10 and it > 20
     from oracle import orc
     assert relerr(orc.dirac_apply(L, gold4["D"], gold4["clover"], x, 64), gold4["solve_rhs"]) < 2e-10
+    ctx.close()
+
+
+def test_three_level_kcycle_solve(gold8):
+    """BASELINE config: the reference's sample.ini on conf/8x8x8x8b6.0000id3n1 -- 3 levels (8^4 -> 4^4 -> 2^4),
+    Nvec 28/28, 2^4 blocks, K-cycle(5,2,0.1), setup 4 (+3 on level 1), rhs = ones.
+    Reference: 11 FGMRES iterations, true residual 1.3e-11 (tests/golden/ref_8x8_3lvl.npz)."""
+    from conftest import load_golden
+    g3 = load_golden("ref_8x8_3lvl.npz")
+    p = api.default_params()
+    p.num_levels = 3
+    for mu in range(4):
+        p.local_lattice[0][mu] = 8; p.block_lattice[0][mu] = 2
+        p.local_lattice[1][mu] = 4; p.block_lattice[1][mu] = 2
+        p.local_lattice[2][mu] = 2
+    p.num_vect[0] = 28; p.num_vect[1] = 28
+    p.post_smooth_iter[0] = p.post_smooth_iter[1] = 2; p.block_iter[0] = p.block_iter[1] = 4
+    p.setup_iter[0] = 4; p.setup_iter[1] = 3
+    p.restart, p.max_restart, p.tol = 50, 20, 1e-10
+    p.coarse_iter, p.coarse_restart, p.coarse_tol = 100, 5, 5e-2
+    p.kcycle, p.kcycle_restart, p.kcycle_max_restart, p.kcycle_tol = 1, 5, 2, 1e-1
+    p.mixed_precision, p.method, p.odd_even = 1, 2, 1
+    p.m0, p.csw = float(g3["meta_f64"][0]), float(g3["meta_f64"][1])
+    ctx = dd.Context(p)
+    plaq = ctx.set_gauge(gold8["gauge"], anti_pbc=True)
+    assert abs(plaq - float(g3["meta_f64"][2])) < 1e-9
+    ctx.setup(4)
+    b = np.zeros((8 ** 4, 12, 2)); b[..., 0] = 1.0
+    x, it, cit, rr = ctx.solve(b, 1e-10)
+    ref_it = int(g3["ones_solve_iters"][0]); ref_hist = g3["ref_log_ones_history"]
+    assert abs(it - ref_it) <= 1 and rr < 1e-10
+    hist = ctx.residual_history()
+    m = min(len(hist), len(ref_hist))
+    assert np.all(hist[:m] < 3.0 * ref_hist[:m]) and np.all(hist[:m] > ref_hist[:m] / 3.0)
+    # coarsest-level work per outer iteration comparable to the reference (192 coarse iterations / 11)
+    assert cit < 2 * int(g3["ones_solve_iters"][1])
+    from oracle import orc
+    D, cl, _ = orc.gauge_to_operator([8, 8, 8, 8], gold8["gauge"], 1, p.m0, p.csw)
+    assert relerr(orc.dirac_apply([8, 8, 8, 8], D, cl, x, 64), b) < 1e-9
     ctx.close()
