@@ -111,6 +111,7 @@ int ddamg_hip_destroy(ddamg_hip_ctx* c) {
   c->mg32.reset(); c->mg64.reset();
   if (c->outer_ready) { c->outer.release(); c->rw_outer.destroy(); }
   if (c->rw_blas_ready) c->rw_blas.destroy();
+  if (c->mp_ready) { c->mp_inner.release(); c->rw_mp.destroy(); (void)hipFree(c->mp_x); (void)hipFree(c->mp_b); (void)hipFree(c->mp_r); }
   if (c->p32_in) (void)hipFree(c->p32_in);
   if (c->p32_out) (void)hipFree(c->p32_out);
   for (auto& lv : c->levels) if (lv->d_lex_of_site) (void)hipFree(lv->d_lex_of_site);

@@ -59,6 +59,11 @@ struct ddamg_hip_ctx {
   ddamg::ReduceWork rw_blas;
   bool rw_blas_ready = false;
   float *p32_in = nullptr, *p32_out = nullptr;
+  // fgmres_MP (mixed_precision 2): fp32 Krylov basis, fp64 residual/solution (src/linsolve.c:153-424)
+  ddamg::Gmres<float> mp_inner;
+  ddamg::ReduceWork rw_mp;
+  bool mp_ready = false;
+  double *mp_x = nullptr, *mp_b = nullptr, *mp_r = nullptr;
   // results of the last solve
   int last_iter = 0, last_coarse_iter = 0;
   double last_relres = 0;

@@ -51,6 +51,7 @@ Multigrid<T>::Multigrid(const ddamg_hip_params& par, const std::vector<const Geo
       lv.gm.st = st_; lv.gm.rw = &lv.rw;
       lv.gm.op = [this, d](T* out, const T* in) { this->apply_op(d, out, in); };
       lv.gm.prec = [this, d](T* phi, T* Dphi, const T* eta, int res) { this->vcycle(d, phi, Dphi, eta, res); };
+      lv.gm.prec_gives_Dphi = par.mixed_precision == 2;   // src/linsolve_generic.c:832-835
       // the reference's vector loops visit this level aggregate -> block -> lexicographic inside the block
       // (src/gathering_generic.c:126-157); ours orders block sites by parity first
       lv.ref_order.reserve(g.V);

@@ -64,6 +64,71 @@ static void ensure_outer(ddamg_hip_ctx* c) {
   c->outer_ready = true;
 }
 
+// fgmres_MP (src/linsolve.c:153-300): outer loop in fp64 (true residual, solution update), one restart
+// cycle of right-preconditioned FGMRES in fp32 per outer step; the cycle stops when the fp64 target is
+// met (gamma/||r0|| < tol) or when it has gained max(tol,1e-5) on its own start residual.
+static void ensure_mp(ddamg_hip_ctx* c) {
+  if (c->mp_ready) return;
+  const size_t n = (size_t)24 * c->levels[0]->geom.V;
+  c->rw_mp.init(c->par.restart + 4);
+  c->mp_inner.alloc(n, c->par.restart, c->par.method > 0);
+  c->mp_inner.num_restart = 1;
+  c->mp_inner.view = whole(n);
+  c->mp_inner.st = c->stream;
+  c->mp_inner.rw = &c->rw_mp;
+  c->mp_inner.breakdown_tol = 1e-15;
+  c->mp_inner.track_history = true;
+  c->mp_inner.op = [c](float* out, const float* in) { c->fop32.apply(out, in, c->stream); };
+  if (c->par.method > 0) {
+    // arnoldi_step_MP: prec( Z[j], w, V[j], _NO_RES ) -- the smoother hands back w = D Z[j] (src/linsolve.c:338-343)
+    c->mp_inner.prec = [c](float* phi, float* Dphi, const float* eta, int res) { c->mg32->vcycle(0, phi, Dphi, eta, res); };
+    c->mp_inner.prec_gives_Dphi = true;
+  }
+  for (double** p : {&c->mp_x, &c->mp_b, &c->mp_r}) DDAMG_HIP_CHECK(hipMalloc(p, sizeof(double) * n));
+  if (!c->rw_blas_ready) { c->rw_blas.init(8); c->rw_blas_ready = true; }
+  c->mp_ready = true;
+}
+
+static int solve_mp(ddamg_hip_ctx* c, double tol, double* relres) {
+  const size_t V = c->levels[0]->geom.V, n = 24 * V;
+  const View all = whole(n);
+  ReduceWork& rw = c->rw_blas;
+  Gmres<float>& in = c->mp_inner;
+  int iter = 0, finish = 0;
+  double norm_r0 = 1, gamma_jp1 = 1;
+  c->last_history.clear();
+  auto dnorm = [&](const double* v) {
+    vec_norm<double>(v, all, rw, rw.d_result, c->stream);
+    DDAMG_HIP_CHECK(hipMemcpyAsync(rw.h_result, rw.d_result, sizeof(double), hipMemcpyDeviceToHost, c->stream));
+    DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
+    return rw.h_result[0];
+  };
+  for (int ol = 0; ol < c->par.max_restart && !finish; ol++) {
+    if (ol == 0) vec_copy<double>(c->mp_r, c->mp_b, all, c->stream);
+    else { c->fop64.apply(c->mp_r, c->mp_x, c->stream); vec_minus<double>(c->mp_r, c->mp_b, c->mp_r, all, c->stream); }
+    const double gamma0 = dnorm(c->mp_r);
+    if (ol == 0) norm_r0 = gamma0;
+    if (!(gamma0 > 0)) { gamma_jp1 = 0; break; }
+    vec_convert<float, double>(in.b, c->mp_r, V, 24, c->stream);
+    in.initial_guess_zero = true;
+    in.tol = std::max(tol * norm_r0 / gamma0, std::max(tol, 1e-5));
+    const int it = in.solve();
+    iter += it;
+    gamma_jp1 = in.gamma_jp1 * (gamma0 / in.norm_r0);
+    for (double h : in.history) c->last_history.push_back(h * gamma0 / norm_r0);
+    if (gamma_jp1 / norm_r0 < tol || gamma_jp1 / norm_r0 > 1e5 || it == 0) finish = 1;
+    // x += (correction of this cycle), accumulated in fp64
+    vec_convert<double, float>(c->mp_r, in.x, V, 24, c->stream);
+    if (ol == 0) vec_copy<double>(c->mp_x, c->mp_r, all, c->stream);
+    else vec_plus<double>(c->mp_x, c->mp_x, c->mp_r, all, c->stream);
+  }
+  // FGMRES_RESTEST
+  c->fop64.apply(c->mp_r, c->mp_x, c->stream);
+  vec_minus<double>(c->mp_r, c->mp_b, c->mp_r, all, c->stream);
+  *relres = norm_r0 > 0 ? dnorm(c->mp_r) / norm_r0 : 0.0;
+  return iter;
+}
+
 extern "C" {
 
 int ddamg_hip_setup(ddamg_hip_ctx* c, int setup_iterations, int* coarse_iterations) {
@@ -217,12 +282,27 @@ int ddamg_hip_solve(ddamg_hip_ctx* c, double* x_lex, const double* b_lex, double
   DDAMG_REQUIRE(c && x_lex && b_lex, "null argument");
   DDAMG_REQUIRE(c->have_operator, "no operator set");
   DDAMG_REQUIRE(c->par.method == 0 || c->setup_done, "setup has not been run");
-  DDAMG_REQUIRE(c->par.mixed_precision <= 1, "mixed_precision 2 (fgmres_MP) is not available in this build");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
-  ensure_outer(c);
   const int V = c->levels[0]->geom.V;
   const size_t nb = sizeof(double) * 24 * V;
   double* st = c->stage(nb);
+  if (c->par.mixed_precision == 2) {
+    ensure_mp(c);
+    DDAMG_HIP_CHECK(hipMemcpyAsync(st, b_lex, nb, hipMemcpyHostToDevice, c->stream));
+    vec_from_lex<double>(c->mp_b, st, c->levels[0]->d_lex_of_site, V, 12, c->stream);
+    if (c->mg32) c->mg32->coarse_iter_count = 0;
+    double rr = 0;
+    const int it = solve_mp(c, tol > 0 ? tol : c->par.tol, &rr);
+    vec_to_lex<double>(st, c->mp_x, c->levels[0]->d_lex_of_site, V, 12, c->stream);
+    DDAMG_HIP_CHECK(hipMemcpyAsync(x_lex, st, nb, hipMemcpyDeviceToHost, c->stream));
+    DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
+    c->last_iter = it; c->last_coarse_iter = c->mg32 ? c->mg32->coarse_iter_count : 0; c->last_relres = rr;
+    if (iterations) *iterations = it;
+    if (coarse_iterations) *coarse_iterations = c->last_coarse_iter;
+    if (relres) *relres = rr;
+    return 0;
+  }
+  ensure_outer(c);
   DDAMG_HIP_CHECK(hipMemcpyAsync(st, b_lex, nb, hipMemcpyHostToDevice, c->stream));
   vec_from_lex<double>(c->outer.b, st, c->levels[0]->d_lex_of_site, V, 12, c->stream);
   c->outer.tol = tol > 0 ? tol : c->par.tol;

@@ -218,11 +218,12 @@ static void dump_two_level(level_struct *l, struct Thread *threading)
 /* ---- stage 3: full solve with rhs = ones on any hierarchy (src/top_level.c:31-104) --------- */
 static void dump_solve_ones(level_struct *l, struct Thread *threading)
 {
-  if (!(g.method > 0 && g.mixed_precision == 1)) return;
-  for (int i = 0; i < l->inner_vector_size; i++) g.p.b[i] = 1.0;
+  if (g.method < 0 || g.mixed_precision == 0) return;
+  vector_double rhs = g.mixed_precision == 2 ? g.p_MP.dp.b : g.p.b;
+  for (int i = 0; i < l->inner_vector_size; i++) rhs[i] = 1.0;
   g.coarse_iter_count = 0;
   printf0("BEGIN_ONES_SOLVE\n");
-  int it = fgmres_double(&(g.p), l, threading);
+  int it = g.mixed_precision == 2 ? fgmres_MP(&(g.p_MP), l, threading) : fgmres_double(&(g.p), l, threading);
   printf0("END_ONES_SOLVE\n");
   int meta[2] = { it, g.coarse_iter_count };
   dump("ones_solve_iters", "i4", meta, sizeof meta, "2");

@@ -184,8 +184,7 @@ def test_full_setup_and_solve_iteration_parity(gold4):
     assert rr < 1e-10
     hist = ctx.residual_history()
     # same convergence rate as the reference (history agrees within a factor 2 per step)
-    m = min(len(hist), len(ref_hist))
-    assert np.all(hist[:m] < 2.0 * ref_hist[:m]) and np.all(hist[:m] > 0.5 * ref_hist[:m])
+    assert len(hist) == len(ref_hist) and np.all(np.abs(hist / ref_hist - 1.0) < 0.05)
     # true solution: D x = b
     from oracle import orc
     Dx = orc.dirac_apply([4, 4, 4, 4], gold4["D"], gold4["clover"], x, 64)
@@ -247,13 +246,53 @@ def test_three_level_kcycle_solve(gold8):
     b = np.zeros((8 ** 4, 12, 2)); b[..., 0] = 1.0
     x, it, cit, rr = ctx.solve(b, 1e-10)
     ref_it = int(g3["ones_solve_iters"][0]); ref_hist = g3["ref_log_ones_history"]
-    assert abs(it - ref_it) <= 1 and rr < 1e-10
+    # measured: identical to the reference -- 11 iterations, 192 coarse iterations, same history to 3 digits
+    assert it == ref_it and rr < 1e-10
     hist = ctx.residual_history()
-    m = min(len(hist), len(ref_hist))
-    assert np.all(hist[:m] < 3.0 * ref_hist[:m]) and np.all(hist[:m] > ref_hist[:m] / 3.0)
-    # coarsest-level work per outer iteration comparable to the reference (192 coarse iterations / 11)
-    assert cit < 2 * int(g3["ones_solve_iters"][1])
+    assert len(hist) == len(ref_hist) and np.all(np.abs(hist / ref_hist - 1.0) < 0.05)
+    assert abs(cit - int(g3["ones_solve_iters"][1])) <= 10
+    assert abs(rr / float(g3["ones_solve_norm_res"][0]) - 1.0) < 0.05
     from oracle import orc
     D, cl, _ = orc.gauge_to_operator([8, 8, 8, 8], gold8["gauge"], 1, p.m0, p.csw)
     assert relerr(orc.dirac_apply([8, 8, 8, 8], D, cl, x, 64), b) < 1e-9
+    ctx.close()
+
+
+def test_mixed_precision_2_amg(gold4):
+    """fgmres_MP (fp32 Krylov basis + V-cycle returning D*phi from the smoother residual, fp64 outer updates):
+    reference 4^4 run: 11 iterations, 73 coarse iterations, 3.34e-11 (tests/golden/ref_4x4_mp2.npz)"""
+    from conftest import load_golden
+    gm = load_golden("ref_4x4_mp2.npz")
+    ctx = make_ctx(gold4, mixed_precision=2)
+    ctx.setup(4)
+    b = np.zeros((256, 12, 2)); b[..., 0] = 1.0
+    x, it, cit, rr = ctx.solve(b, 1e-10)
+    assert it == int(gm["ones_solve_iters"][0]) and abs(cit - int(gm["ones_solve_iters"][1])) <= 8
+    assert rr < 1e-10 and abs(rr / float(gm["ones_solve_norm_res"][0]) - 1.0) < 0.2
+    hist = ctx.residual_history(); ref = gm["ref_log_ones_history"]
+    assert len(hist) == len(ref) and np.all(np.abs(hist / ref - 1.0) < 0.05)
+    from oracle import orc
+    assert relerr(orc.dirac_apply([4, 4, 4, 4], gold4["D"], gold4["clover"], x, 64), b) < 1e-9
+    ctx.close()
+
+
+def test_pure_gmres_mixed_precision_2(gold8):
+    """method 0, mixed precision 2 on the 8^4 sample configuration: reference 356 iterations of GMRES(50)
+    (tests/golden/ref_8x8_gmres_mp2.npz; printed every 10th iteration)"""
+    from conftest import load_golden
+    gm = load_golden("ref_8x8_gmres_mp2.npz")
+    p = api.default_params(); p.num_levels = 1
+    for mu in range(4):
+        p.local_lattice[0][mu] = 8; p.block_lattice[0][mu] = 2
+    p.method, p.mixed_precision, p.restart, p.max_restart, p.tol = 0, 2, 50, 20, 1e-10
+    p.m0, p.csw = -0.5, 1.0
+    ctx = dd.Context(p)
+    ctx.set_gauge(gold8["gauge"], anti_pbc=True)
+    b = np.zeros((4096, 12, 2)); b[..., 0] = 1.0
+    x, it, cit, rr = ctx.solve(b, 1e-10)
+    assert abs(it - int(gm["ones_solve_iters"][0])) <= 10 and rr < 1.5e-10
+    hist = ctx.residual_history(); ref = gm["ref_log_ones_history"]
+    k = np.arange(10, 10 * (len(ref) + 1), 10) - 1
+    k = k[k < len(hist)]
+    assert np.all(np.abs(np.log10(hist[k] / ref[:len(k)])) < 0.3)
     ctx.close()
