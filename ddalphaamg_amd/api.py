@@ -33,7 +33,20 @@ class Params(ctypes.Structure):
         ("method", ctypes.c_int),
         ("m0", ctypes.c_double), ("csw", ctypes.c_double),
         ("device", ctypes.c_int),
+        ("process_grid", ctypes.c_int * 4),
+        ("process_coords", ctypes.c_int * 4),
     ]
+
+
+class HaloMsg(ctypes.Structure):
+    """struct ddamg_hip_halo_msg"""
+    _fields_ = [
+        ("send_peer", ctypes.c_int), ("recv_peer", ctypes.c_int), ("tag", ctypes.c_int),
+        ("send", ctypes.c_void_p), ("recv", ctypes.c_void_p), ("bytes", ctypes.c_ulonglong),
+    ]
+
+
+EXCHANGE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(HaloMsg))
 
 
 _lib = None
@@ -94,6 +107,10 @@ def load_library():
         "ddamg_hip_preconditioner": [vp, dp, dp],
         "ddamg_hip_residual_history": [vp, dp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
         "ddamg_hip_get_site_order": [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
+        "ddamg_hip_rccl_unique_id": [vp],
+        "ddamg_hip_comm_init_rccl": [vp, vp],
+        "ddamg_hip_comm_init_host": [vp, EXCHANGE_FN, vp],
+        "ddamg_hip_halo_plan": [ctypes.POINTER(ctypes.c_int)] * 3 + [ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 3,
         "ddamg_hip_timer_begin": [vp],
         "ddamg_hip_timer_end": [vp, ctypes.POINTER(ctypes.c_float)],
         "ddamg_hip_sync": [vp],
@@ -289,6 +306,25 @@ class Context:
         _check(self._lib.ddamg_hip_get_site_order(self._h, level, out.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
         return out
 
+    # ---- multi-GPU halo exchange ----
+    def comm_init_rccl(self, unique_id):
+        buf = ctypes.create_string_buffer(bytes(unique_id), 128)
+        _check(self._lib.ddamg_hip_comm_init_rccl(self._h, ctypes.cast(buf, ctypes.c_void_p)))
+
+    def comm_init_host(self, exchange):
+        """exchange(list of (send_peer, recv_peer, tag, send: np.uint8 array, recv: np.uint8 array))"""
+        def trampoline(_user, n, msgs):
+            items = []
+            for i in range(n):
+                m = msgs[i]
+                nb = int(m.bytes)
+                snd = np.ctypeslib.as_array(ctypes.cast(m.send, ctypes.POINTER(ctypes.c_uint8)), shape=(nb,))
+                rcv = np.ctypeslib.as_array(ctypes.cast(m.recv, ctypes.POINTER(ctypes.c_uint8)), shape=(nb,))
+                items.append((m.send_peer, m.recv_peer, m.tag, snd, rcv))
+            exchange(items)
+        self._exchange_cb = EXCHANGE_FN(trampoline)   # keep the callback object alive
+        _check(self._lib.ddamg_hip_comm_init_host(self._h, self._exchange_cb, None))
+
     def timer_begin(self):
         _check(self._lib.ddamg_hip_timer_begin(self._h))
 
@@ -304,3 +340,23 @@ class Context:
         if self._h:
             self._lib.ddamg_hip_destroy(self._h)
             self._h = ctypes.c_void_p()
+
+
+def rccl_unique_id():
+    buf = ctypes.create_string_buffer(128)
+    _check(load_library().ddamg_hip_rccl_unique_id(ctypes.cast(buf, ctypes.c_void_p)))
+    return buf.raw
+
+
+def halo_plan(local_lattice, process_grid, process_coords, face):
+    """host-only: (neighbour rank, local lexicographic indices of the face sites in message order)"""
+    lib = load_library()
+    I4 = ctypes.c_int * 4
+    nb = ctypes.c_int(0); cnt = ctypes.c_int(0)
+    L, P, C = I4(*local_lattice), I4(*process_grid), I4(*process_coords)
+    _check(lib.ddamg_hip_halo_plan(L, P, C, int(face), ctypes.byref(nb), ctypes.byref(cnt), None))
+    sites = np.empty(cnt.value, dtype=np.int32)
+    if cnt.value:
+        _check(lib.ddamg_hip_halo_plan(L, P, C, int(face), ctypes.byref(nb), ctypes.byref(cnt),
+                                       sites.ctypes.data_as(ctypes.POINTER(ctypes.c_int))))
+    return nb.value, sites

@@ -51,6 +51,7 @@ void ddamg_hip_default_params(ddamg_hip_params* p) {
   p->kcycle = 1; p->kcycle_restart = 5; p->kcycle_max_restart = 2; p->kcycle_tol = 1e-1;
   p->mixed_precision = 2; p->odd_even = 1; p->method = 2;
   p->m0 = 0; p->csw = 0; p->device = 0;
+  for (int mu = 0; mu < 4; mu++) { p->process_grid[mu] = 1; p->process_coords[mu] = 0; }
 }
 
 int ddamg_hip_create(const ddamg_hip_params* p, ddamg_hip_ctx** out) {
@@ -64,6 +65,7 @@ int ddamg_hip_create(const ddamg_hip_params* p, ddamg_hip_ctx** out) {
   DDAMG_HIP_CHECK(hipSetDevice(p->device));
   std::unique_ptr<ddamg_hip_ctx> c(new ddamg_hip_ctx);
   c->par = *p;
+  for (int mu = 0; mu < 4; mu++) if (c->par.process_grid[mu] < 1) { c->par.process_grid[mu] = 1; c->par.process_coords[mu] = 0; }
   c->device = p->device;
   DDAMG_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   DDAMG_HIP_CHECK(hipEventCreate(&c->ev0));
@@ -93,7 +95,7 @@ int ddamg_hip_create(const ddamg_hip_params* p, ddamg_hip_ctx** out) {
         A[mu] = B[mu];
       }
     }
-    lv->geom.build(p->local_lattice[d], B, A);
+    lv->geom.build(p->local_lattice[d], B, A, c->par.process_grid, c->par.process_coords);
     DDAMG_HIP_CHECK(hipMalloc(&lv->d_lex_of_site, sizeof(int) * lv->geom.V));
     DDAMG_HIP_CHECK(hipMemcpy(lv->d_lex_of_site, lv->geom.lex_of_site.data(), sizeof(int) * lv->geom.V, hipMemcpyHostToDevice));
     c->levels.push_back(std::move(lv));
@@ -109,6 +111,7 @@ int ddamg_hip_destroy(ddamg_hip_ctx* c) {
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
   (void)hipStreamSynchronize(c->stream);
   c->mg32.reset(); c->mg64.reset();
+  if (c->comm) { comm_destroy(c->comm); c->comm = nullptr; }
   if (c->outer_ready) { c->outer.release(); c->rw_outer.destroy(); }
   if (c->rw_blas_ready) c->rw_blas.destroy();
   if (c->mp_ready) { c->mp_inner.release(); c->rw_mp.destroy(); (void)hipFree(c->mp_x); (void)hipFree(c->mp_b); (void)hipFree(c->mp_r); }
@@ -137,6 +140,8 @@ int ddamg_hip_set_gauge(ddamg_hip_ctx* c, const double* gauge_lex, int anti_pbc,
   DDAMG_REQUIRE(c && gauge_lex, "null argument");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
   const Geometry& g = c->levels[0]->geom;
+  DDAMG_REQUIRE(!g.distributed(), "set_gauge needs the links of neighbouring processes for the clover term: with a process grid, "
+                                  "build the operator globally and hand each process its part through ddamg_hip_set_operator");
   c->D_host.resize((size_t)g.V * 72);
   c->clover_host.resize((size_t)g.V * 84);
   double pl = gauge_to_operator(g.L, gauge_lex, anti_pbc, c->par.m0, c->par.csw, c->D_host.data(), c->clover_host.data());
@@ -153,6 +158,49 @@ int ddamg_hip_set_operator(ddamg_hip_ctx* c, const double* D_lex, const double* 
   if (D_lex != c->D_host.data()) c->D_host.assign(D_lex, D_lex + (size_t)g.V * 72);
   if (clover_lex != c->clover_host.data()) c->clover_host.assign(clover_lex, clover_lex + (size_t)g.V * 84);
   upload_operator(c);
+  DDAMG_API_END
+}
+
+int ddamg_hip_rccl_unique_id(void* id128) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(id128, "null argument");
+  rccl_unique_id(id128);
+  DDAMG_API_END
+}
+
+static void install_comm(ddamg_hip_ctx* c, Comm* comm) {
+  if (c->comm) comm_destroy(c->comm);
+  c->comm = comm;
+  c->fop32.set_comm(comm);
+  c->fop64.set_comm(comm);
+}
+
+int ddamg_hip_comm_init_rccl(ddamg_hip_ctx* c, const void* id128) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && id128, "null argument");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  install_comm(c, comm_create_rccl(c->levels[0]->geom, id128));
+  DDAMG_API_END
+}
+
+int ddamg_hip_comm_init_host(ddamg_hip_ctx* c, ddamg_hip_exchange_fn fn, void* user) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c, "null argument");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  install_comm(c, comm_create_host(c->levels[0]->geom, fn, user));
+  DDAMG_API_END
+}
+
+int ddamg_hip_halo_plan(const int local_lattice[4], const int process_grid[4], const int process_coords[4],
+                        int face, int* neighbor_rank, int* count, int* lex_sites) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(local_lattice && process_grid && process_coords, "null argument");
+  DDAMG_REQUIRE(face >= 0 && face < 8, "face must be 0..7");
+  Geometry g;
+  g.build(local_lattice, local_lattice, local_lattice, process_grid, process_coords);
+  if (neighbor_rank) *neighbor_rank = g.neighbor_rank[face];
+  if (count) *count = (int)g.face_sites[face].size();
+  if (lex_sites) for (size_t i = 0; i < g.face_sites[face].size(); i++) lex_sites[i] = g.lex_of_site[g.face_sites[face][i]];
   DDAMG_API_END
 }
 

@@ -42,6 +42,7 @@ struct ddamg_hip_ctx {
   bool have_operator = false;
   ddamg::FineOp<float> fop32;
   ddamg::FineOp<double> fop64;
+  ddamg::Comm* comm = nullptr;  // halo transport of a decomposed lattice (halo.h)
   // staging buffer for host<->device vector transfers (lexicographic fp64)
   double* d_stage = nullptr;
   size_t stage_bytes = 0;

@@ -12,6 +12,7 @@
 #pragma once
 #include "common.h"
 #include "geometry.h"
+#include "halo.h"
 
 namespace ddamg {
 
@@ -20,8 +21,10 @@ struct FineOpDev {
   const T* D;
   const T* clover;
   const T* clover_inv;  // explicit inverse of both 6x6 blocks (same packing), for odd-even SAP
-  const int* nb;
+  const int* nb;     // neighbour site, or -1 - slot for a neighbour on another GPU (halo.h)
   int V;
+  const T* halo;     // received boundary half spinors (null on a single GPU)
+  HaloDev hd;
 };
 
 template <typename T>
@@ -35,9 +38,12 @@ class FineOp {
   // D_ref: [V][4][9] complex (lexicographic sites), clover_ref: [V][42] complex, both fp64 as the
   // reference holds them in g.op_double (src/dirac.c:60-168)
   void upload(const Geometry& g, const double* D_ref, const double* clover_ref, hipStream_t st);
-  void apply(T* eta, const T* phi, hipStream_t st) const;  // eta = D_W phi
-  FineOpDev<T> dev() const { return FineOpDev<T>{D_, clover_, clover_inv_, nb_, V_}; }
+  // eta = D_W phi; with a process grid: pack -> exchange (overlapped with the interior tiles) -> boundary tiles
+  void apply(T* eta, const T* phi, hipStream_t st) const;
+  FineOpDev<T> dev() const { return FineOpDev<T>{D_, clover_, clover_inv_, nb_, V_, halo_.recv(), halo_.dev()}; }
   int V() const { return V_; }
+  void set_comm(Comm* c) { comm_ = c; }
+  bool distributed() const { return halo_.active(); }
 
  private:
   T* D_ = nullptr;
@@ -45,6 +51,8 @@ class FineOp {
   T* clover_inv_ = nullptr;
   int* nb_ = nullptr;
   int V_ = 0;
+  mutable Halo<T> halo_;
+  Comm* comm_ = nullptr;
 };
 
 // layout converters between the reference's lexicographic AoS fp64 vectors

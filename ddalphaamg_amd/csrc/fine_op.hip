@@ -15,28 +15,52 @@
 #endif
 namespace ddamg {
 
+// couplings to a site on another GPU: the neighbour sent the projected half spinor (halo.h)
+template <typename T, int MU>
+__device__ __forceinline__ void halo_forward(const FineOpDev<T>& op, int slot, const T (&U)[18], T (&eta)[24]) {
+  T h[12], g[12];
+  load_site<T, 12>(op.halo + op.hd.off[MU], (size_t)op.hd.F[MU], (size_t)slot, h);       // (1-gamma_mu) phi(x+mu)
+  su3_mul<T>(U, h, g);
+  spin_reconstruct_sub<T, MU, -1>(g, eta);
+}
+template <typename T, int MU>
+__device__ __forceinline__ void halo_backward(const FineOpDev<T>& op, int slot, T (&eta)[24]) {
+  T g[12];
+  load_site<T, 12>(op.halo + op.hd.off[4 + MU], (size_t)op.hd.F[MU], (size_t)slot, g);   // D_mu(x-mu)^dagger (1+gamma_mu) phi(x-mu)
+  spin_reconstruct_sub<T, MU, +1>(g, eta);
+}
+
 template <typename T, int MU>
 __device__ __forceinline__ void hop_pair(const T* __restrict__ phi, const FineOpDev<T>& op, size_t s, T (&eta)[24]) {
   const size_t V = op.V;
   {
     int j = op.nb[(size_t)MU * V + s];
-    T pn[24], U[18];
-    load_site<T, 24>(phi, V, j, pn);
+    T U[18];
     load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, s, U);
-    hop_accumulate<T, MU, true>(U, pn, eta);
+    if (j >= 0) {
+      T pn[24];
+      load_site<T, 24>(phi, V, j, pn);
+      hop_accumulate<T, MU, true>(U, pn, eta);
+    } else {
+      halo_forward<T, MU>(op, -1 - j, U, eta);
+    }
   }
   {
     int j = op.nb[(size_t)(4 + MU) * V + s];
-    T pn[24], U[18];
-    load_site<T, 24>(phi, V, j, pn);
-    load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, j, U);
-    hop_accumulate<T, MU, false>(U, pn, eta);
+    if (j >= 0) {
+      T pn[24], U[18];
+      load_site<T, 24>(phi, V, j, pn);
+      load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, j, U);
+      hop_accumulate<T, MU, false>(U, pn, eta);
+    } else {
+      halo_backward<T, MU>(op, -1 - j, eta);
+    }
   }
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : 3)) void dirac_apply_kernel(T* __restrict__ eta, const T* __restrict__ phi, FineOpDev<T> op) {
-  const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : 3)) void dirac_apply_kernel(T* __restrict__ eta, const T* __restrict__ phi, FineOpDev<T> op, const int* __restrict__ tile_list) {
+  const size_t s = (size_t)(tile_list ? tile_list[blockIdx.x] : blockIdx.x) * 256 + threadIdx.x;
   const size_t V = op.V;
   if (s >= V) return;
   T e[24];
@@ -85,20 +109,26 @@ __device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOp
   // (b) forward term with my own link
   if (live) {
     const int j = op.nb[(size_t)MU * V + s];
-    T pn[24];
-    if (j - tile0 >= 0 && j - tile0 < 256) {
+    if (j >= 0) {
+      T pn[24];
+      if (j - tile0 >= 0 && j - tile0 < 256) {
 #pragma unroll
-      for (int c = 0; c < 24; c++) pn[c] = sp[c * 256 + (j - tile0)];
+        for (int c = 0; c < 24; c++) pn[c] = sp[c * 256 + (j - tile0)];
+      } else {
+        load_site<T, 24>(phi, V, j, pn);
+      }
+      hop_accumulate<T, MU, true>(U, pn, e);
     } else {
-      load_site<T, 24>(phi, V, j, pn);
+      halo_forward<T, MU>(op, -1 - j, U, e);
     }
-    hop_accumulate<T, MU, true>(U, pn, e);
   }
   __syncthreads();
   // (c) backward term: product computed by site s-mu (in LDS) or, across the tile face, from global memory
   if (live) {
     const int j = op.nb[(size_t)(4 + MU) * V + s];
-    if (j - tile0 >= 0 && j - tile0 < 256) {
+    if (j < 0) {
+      halo_backward<T, MU>(op, -1 - j, e);
+    } else if (j - tile0 >= 0 && j - tile0 < 256) {
       T g[12];
 #pragma unroll
       for (int c = 0; c < 12; c++) g[c] = hb[c * 256 + (j - tile0)];
@@ -114,13 +144,15 @@ __device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOp
 }
 
 template <typename T>
-__global__ __launch_bounds__(256, 3) void dirac_apply_lds_kernel(T* __restrict__ eta, const T* __restrict__ phi, FineOpDev<T> op, int ntiles) {
+__global__ __launch_bounds__(256, 3) void dirac_apply_lds_kernel(T* __restrict__ eta, const T* __restrict__ phi, FineOpDev<T> op, int ntiles,
+                                                                  const int* __restrict__ tile_list) {
   __shared__ T sp[24 * 256];
   __shared__ T hb[12 * 256];
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give XCD k the
   // k-th contiguous eighth of the tiles (neighbouring tiles then share one L2)
   int tile = blockIdx.x;
   if ((ntiles & 7) == 0) tile = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
+  if (tile_list) tile = tile_list[tile];   // interior / boundary subsets of a decomposed lattice
   const size_t V = op.V;
   const int tile0 = tile * 256;
   const size_t s = (size_t)tile0 + threadIdx.x;
@@ -157,10 +189,22 @@ void FineOp<T>::apply(T* eta, const T* phi, hipStream_t st) const {
     const char* e = getenv("DDAMG_DIRAC_VARIANT");
     g_dirac_variant = e ? atoi(e) : 1;
   }
-  int grid = (V_ + 255) / 256;
-  if (g_dirac_variant == 0) hipLaunchKernelGGL(dirac_apply_kernel<T>, dim3(grid), dim3(256), 0, st, eta, phi, dev());
-  else hipLaunchKernelGGL(dirac_apply_lds_kernel<T>, dim3(grid), dim3(256), 0, st, eta, phi, dev(), grid);
-  DDAMG_HIP_CHECK(hipGetLastError());
+  auto launch = [&](int ntiles, const int* tile_list) {
+    if (ntiles == 0) return;
+    if (g_dirac_variant == 0) hipLaunchKernelGGL(dirac_apply_kernel<T>, dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), tile_list);
+    else hipLaunchKernelGGL(dirac_apply_lds_kernel<T>, dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, tile_list);
+    DDAMG_HIP_CHECK(hipGetLastError());
+  };
+  if (!halo_.active()) {
+    launch((V_ + 255) / 256, nullptr);
+    return;
+  }
+  // reference order of events: src/dirac_generic.c:178-262 (project+send, interior work, wait, boundary)
+  halo_.pack(phi, D_, V_, st);
+  halo_.exchange_begin(comm_, st);
+  launch(halo_.n_interior(), halo_.interior_tiles());
+  halo_.exchange_finish(comm_, st);
+  launch(halo_.n_boundary(), halo_.boundary_tiles());
 }
 
 template <typename T>
@@ -238,6 +282,7 @@ void FineOp<T>::upload(const Geometry& g, const double* D_ref, const double* clo
   DDAMG_HIP_CHECK(hipMemcpyAsync(clover_inv_, hI.data(), sizeof(T) * 72 * V, hipMemcpyHostToDevice, st));
   DDAMG_HIP_CHECK(hipMemcpyAsync(nb_, g.nb.data(), sizeof(int) * 8 * V, hipMemcpyHostToDevice, st));
   DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+  if (g.distributed() && !halo_.active()) halo_.init(g);
 }
 
 // ---- layout converters ---------------------------------------------------------------------

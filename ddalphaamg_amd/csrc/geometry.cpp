@@ -4,11 +4,12 @@
 
 namespace ddamg {
 
-void Geometry::build(const int L_[4], const int B_[4], const int A_[4]) {
+void Geometry::build(const int L_[4], const int B_[4], const int A_[4], const int* P_, const int* pc_) {
   V = 1; block_sites = 1; agg_sites = 1; num_blocks = 1; num_aggs = 1;
   for (int mu = 0; mu < 4; mu++) {
     L[mu] = L_[mu]; B[mu] = B_[mu]; A[mu] = A_[mu];
-    P[mu] = 1; pc[mu] = 0;
+    P[mu] = P_ ? P_[mu] : 1; pc[mu] = pc_ ? pc_[mu] : 0;
+    DDAMG_REQUIRE(P[mu] >= 1 && pc[mu] >= 0 && pc[mu] < P[mu], "process coordinates outside the process grid");
     DDAMG_REQUIRE(L[mu] > 0 && B[mu] > 0 && A[mu] > 0, "lattice extents must be positive");
     DDAMG_REQUIRE(L[mu] % A[mu] == 0, "aggregate lattice must divide the local lattice");
     DDAMG_REQUIRE(A[mu] % B[mu] == 0, "Schwarz block lattice must divide the aggregate lattice");
@@ -18,6 +19,15 @@ void Geometry::build(const int L_[4], const int B_[4], const int A_[4]) {
     num_blocks *= nblk[mu]; num_aggs *= nagg[mu];
   }
   oe_offset = 0;
+  nranks = P[0] * P[1] * P[2] * P[3];
+  rank = rank_of(P, pc);
+  for (int mu = 0; mu < 4; mu++) {
+    oe_offset += pc[mu] * L[mu];   // reference src/data_layout.c:47-49
+    int q[4] = {pc[0], pc[1], pc[2], pc[3]};
+    q[mu] = (pc[mu] + 1) % P[mu];           neighbor_rank[mu] = rank_of(P, q);
+    q[mu] = (pc[mu] - 1 + P[mu]) % P[mu];   neighbor_rank[4 + mu] = rank_of(P, q);
+  }
+  oe_offset &= 1;
   site_of_lex.assign(V, -1);
   lex_of_site.assign(V, -1);
   coord.assign((size_t)V * 4, 0);
@@ -67,17 +77,30 @@ void Geometry::build(const int L_[4], const int B_[4], const int A_[4]) {
     }
   DDAMG_REQUIRE(s == V && blk == num_blocks, "site enumeration is inconsistent");
 
-  // neighbour tables (periodic wrap inside the local volume: single process per direction)
+  // neighbour tables: periodic wrap inside the local volume where the direction is not split over
+  // processes, a halo slot (-1 - slot) where it is
   nb.assign((size_t)8 * V, -1);
+  for (int d = 0; d < 8; d++) face_sites[d].clear();
+  for (int mu = 0; mu < 4; mu++)
+    if (P[mu] > 1) { face_sites[mu].assign(face_size(mu), -1); face_sites[4 + mu].assign(face_size(mu), -1); }
+  std::vector<unsigned char> tile_is_boundary((V + 255) / 256, 0);
   for (int st = 0; st < V; st++) {
     for (int mu = 0; mu < 4; mu++) {
+      const int x = coord[(size_t)st * 4 + mu];
       int cc[4] = {coord[(size_t)st * 4], coord[(size_t)st * 4 + 1], coord[(size_t)st * 4 + 2], coord[(size_t)st * 4 + 3]};
-      cc[mu] = (coord[(size_t)st * 4 + mu] + 1) % L[mu];
+      const int slot = slot_of(cc, mu);
+      cc[mu] = (x + 1) % L[mu];
       nb[(size_t)mu * V + st] = site_of_lex[lex(cc)];
-      cc[mu] = (coord[(size_t)st * 4 + mu] - 1 + L[mu]) % L[mu];
+      cc[mu] = (x - 1 + L[mu]) % L[mu];
       nb[(size_t)(4 + mu) * V + st] = site_of_lex[lex(cc)];
+      if (P[mu] > 1) {
+        if (x == L[mu] - 1) { nb[(size_t)mu * V + st] = -1 - slot; face_sites[mu][slot] = st; tile_is_boundary[st / 256] = 1; }
+        if (x == 0) { nb[(size_t)(4 + mu) * V + st] = -1 - slot; face_sites[4 + mu][slot] = st; tile_is_boundary[st / 256] = 1; }
+      }
     }
   }
+  interior_tiles.clear(); boundary_tiles.clear();
+  for (int t = 0; t < (int)tile_is_boundary.size(); t++) (tile_is_boundary[t] ? boundary_tiles : interior_tiles).push_back(t);
 
   // aggregate faces (geometric: a wrap-around into the same aggregate still counts as leaving it,
   // as the reference's agg_boundary_index tables do, src/coarsening_generic.c:39-111)

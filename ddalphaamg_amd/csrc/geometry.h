@@ -29,6 +29,12 @@ struct Geometry {
   std::vector<int> coord;        // [V*4] local coordinates of a site
   std::vector<int> parity;       // [V] global parity (t+z+y+x+oe_offset)&1 : 0 even, 1 odd
   std::vector<int> nb;           // [8*V] neighbour site: dir 0..3 = +T,+Z,+Y,+X ; 4..7 = -T,-Z,-Y,-X
+                                 //   off-rank neighbour (P[mu] > 1): -1 - slot, slot = transverse lexicographic index in the face
+  // halo exchange tables (reference: ghost cells + comm tables, src/ghost_generic.c:25-150, src/data_layout.c:254-420)
+  std::vector<int> face_sites[8];   // d < 4: my sites with coord[mu] == L-1 (send to +mu), d >= 4: coord[mu] == 0; slot order
+  int neighbor_rank[8];             // rank of the process in direction d (== my rank when P[mu] == 1)
+  int rank = 0, nranks = 1;
+  std::vector<int> interior_tiles, boundary_tiles;  // 256-site tiles without / with an off-rank neighbour
   std::vector<int> blk_nb;       // [8*block_sites] in-block neighbour (block-local index) or -1
   std::vector<int> block_color;  // [num_blocks] red-black colour (src/schwarz_generic.c:383-395)
   std::vector<int> block_list;   // [num_blocks] 0..7: red-black list of the reference (:415-428)
@@ -36,7 +42,15 @@ struct Geometry {
   std::vector<unsigned char> blk_face;  // [V] bit d set: the neighbour in direction d lies outside the site's Schwarz block
   std::vector<unsigned char> agg_face;  // [V] bit d set: the neighbour in direction d lies outside the site's aggregate
 
-  void build(const int L_[4], const int B_[4], const int A_[4]);
+  void build(const int L_[4], const int B_[4], const int A_[4], const int* P_ = nullptr, const int* pc_ = nullptr);
+  bool distributed() const { return nranks > 1; }
+  int face_size(int mu) const { return V / L[mu]; }
+  int slot_of(const int c[4], int mu) const {  // lexicographic index over the three directions != mu
+    int idx = 0;
+    for (int nu = 0; nu < 4; nu++) if (nu != mu) idx = idx * L[nu] + c[nu];
+    return idx;
+  }
+  static int rank_of(const int P[4], const int pc[4]) { return ((pc[0] * P[1] + pc[1]) * P[2] + pc[2]) * P[3] + pc[3]; }
   int lex(const int c[4]) const { return ((c[0] * L[1] + c[1]) * L[2] + c[2]) * L[3] + c[3]; }
 };
 

@@ -1,0 +1,63 @@
+// halo.h -- boundary exchange of the fine Wilson-Clover operator between GPUs.
+// Reference: ghost_sendrecv_PRECISION / ghost_wait_PRECISION src/ghost_generic.c:152-330 and the
+// prp / prn half-spinor phases of d_plus_clover_PRECISION src/dirac_generic.c:178-262.  As there,
+// what travels is the projected half spinor (6 complex per face site and direction):
+//   to the +mu neighbour:  D_mu(x)^dagger (1+gamma_mu) phi(x)   for x on my +mu face   (buffer d = mu)
+//   to the -mu neighbour:              (1-gamma_mu) phi(x)      for x on my -mu face   (buffer d = 4+mu)
+// so no gauge links cross the boundary.  recv[d] holds what the neighbour in direction d sent me:
+// recv[mu] = (1-gamma_mu) phi(x+mu) (multiplied with my own link), recv[4+mu] = the finished backward
+// product of x-mu.  Buffers are chunked SoA with the face size as the site count (common.h).
+//
+// Transports: RCCL send/recv on a dedicated stream (xGMI, device to device) or a host callback
+// (pinned staging buffers; the host application moves the messages with its own MPI).
+#pragma once
+#include "common.h"
+#include "geometry.h"
+#include "../../include/ddamg_hip.h"
+
+namespace ddamg {
+
+struct HaloDev {
+  int off[8];   // element offset of buffer d inside the send / recv arena
+  int F[4];     // face sites per direction (0 when the direction is not split)
+};
+
+struct Comm;  // transport state (RCCL communicator or host callback), shared by both precisions
+
+Comm* comm_create_rccl(const Geometry& g, const void* id128);
+Comm* comm_create_host(const Geometry& g, ddamg_hip_exchange_fn fn, void* user);
+void comm_destroy(Comm* c);
+void rccl_unique_id(void* id128);
+
+template <typename T>
+class Halo {
+ public:
+  ~Halo();
+  void init(const Geometry& g);
+  bool active() const { return nface_total_ > 0; }
+  const HaloDev& dev() const { return hd_; }
+  const T* recv() const { return recv_; }
+  const int* interior_tiles() const { return d_interior_; }
+  const int* boundary_tiles() const { return d_boundary_; }
+  int n_interior() const { return n_interior_; }
+  int n_boundary() const { return n_boundary_; }
+  // pack kernel: fills the send arena from phi (needs the links: D = FineOpDev::D)
+  void pack(const T* phi, const T* D, int V, hipStream_t st);
+  // start the exchange of the packed data (returns at once for RCCL; the host transport blocks the
+  // calling thread while the interior kernel, launched before, runs) and make `st` wait for it
+  void exchange_begin(Comm* c, hipStream_t st);
+  void exchange_finish(Comm* c, hipStream_t st);
+
+ private:
+  HaloDev hd_{};
+  int nface_total_ = 0;
+  int* d_face_sites_ = nullptr;  // [nface_total] concatenated face_sites[d] in arena order
+  T* send_ = nullptr; T* recv_ = nullptr;
+  T* h_send_ = nullptr; T* h_recv_ = nullptr;  // pinned, host transport only
+  int* d_interior_ = nullptr; int* d_boundary_ = nullptr;
+  int n_interior_ = 0, n_boundary_ = 0;
+  int nbr_[8];
+  hipEvent_t ev_packed_ = nullptr, ev_done_ = nullptr;
+};
+
+}  // namespace ddamg

@@ -1,0 +1,213 @@
+// halo.hip -- see halo.h
+#include "halo.h"
+#include "dirac_device.h"
+#include <rccl/rccl.h>
+#include <cstring>
+#include <stdexcept>
+#include <vector>
+#include <string>
+
+namespace ddamg {
+
+#define DDAMG_NCCL_CHECK(expr)                                                                        \
+  do {                                                                                                \
+    ncclResult_t r_ = (expr);                                                                         \
+    if (r_ != ncclSuccess) throw std::runtime_error(std::string("RCCL: ") + ncclGetErrorString(r_) + " at " #expr); \
+  } while (0)
+
+struct Comm {
+  int kind = 0;  // 1 RCCL, 2 host callback
+  ncclComm_t nccl = nullptr;
+  hipStream_t stream = nullptr;
+  ddamg_hip_exchange_fn fn = nullptr;
+  void* user = nullptr;
+  int rank = 0, nranks = 1;
+};
+
+void rccl_unique_id(void* id128) {
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+  ncclUniqueId id;
+  DDAMG_NCCL_CHECK(ncclGetUniqueId(&id));
+  memcpy(id128, &id, sizeof id);
+}
+
+Comm* comm_create_rccl(const Geometry& g, const void* id128) {
+  Comm* c = new Comm;
+  c->kind = 1; c->rank = g.rank; c->nranks = g.nranks;
+  ncclUniqueId id;
+  memcpy(&id, id128, sizeof id);
+  DDAMG_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  DDAMG_NCCL_CHECK(ncclCommInitRank(&c->nccl, g.nranks, id, g.rank));
+  return c;
+}
+Comm* comm_create_host(const Geometry& g, ddamg_hip_exchange_fn fn, void* user) {
+  DDAMG_REQUIRE(fn != nullptr, "exchange callback is null");
+  Comm* c = new Comm;
+  c->kind = 2; c->rank = g.rank; c->nranks = g.nranks; c->fn = fn; c->user = user;
+  DDAMG_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  return c;
+}
+void comm_destroy(Comm* c) {
+  if (!c) return;
+  if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->nccl) (void)ncclCommDestroy(c->nccl);
+  if (c->stream) (void)hipStreamDestroy(c->stream);
+  delete c;
+}
+
+// ---- pack -----------------------------------------------------------------------------------------
+template <typename T, int MU>
+__device__ __forceinline__ void pack_site(const T* __restrict__ phi, const T* __restrict__ D, size_t V, int s, bool plus, T (&out)[12]) {
+  T p[24];
+  load_site<T, 24>(phi, V, s, p);
+  if (plus) {
+    T U[18], h[12];
+    load_site<T, 18>(D + (size_t)MU * 18 * V, V, s, U);
+    spin_project<T, MU, +1>(p, h);
+    su3_mul_dag<T>(U, h, out);
+  } else {
+    spin_project<T, MU, -1>(p, out);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void halo_pack_kernel(T* __restrict__ send, const T* __restrict__ phi, const T* __restrict__ D,
+                                                        const int* __restrict__ face_sites, HaloDev hd, int V, int total) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  // arena order: d = 0..7, F[d&3] sites each (only split directions are present)
+  int d = 0, first = 0;
+  bool found = false;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    const int f = hd.F[k & 3];
+    if (!found) {
+      if (i >= first + f) { first += f; d = k + 1; }
+      else found = true;
+    }
+  }
+  const int slot = i - first;
+  const int mu = d & 3;
+  const bool plus = d < 4;
+  const int s = face_sites[i];
+  T out[12];
+  switch (mu) {
+    case 0: pack_site<T, 0>(phi, D, V, s, plus, out); break;
+    case 1: pack_site<T, 1>(phi, D, V, s, plus, out); break;
+    case 2: pack_site<T, 2>(phi, D, V, s, plus, out); break;
+    default: pack_site<T, 3>(phi, D, V, s, plus, out); break;
+  }
+  store_site<T, 12>(send + hd.off[d], (size_t)hd.F[mu], (size_t)slot, out);
+}
+
+template <typename T>
+void Halo<T>::init(const Geometry& g) {
+  nface_total_ = 0;
+  std::vector<int> fs;
+  int off = 0;
+  for (int mu = 0; mu < 4; mu++) hd_.F[mu] = g.P[mu] > 1 ? g.face_size(mu) : 0;
+  for (int d = 0; d < 8; d++) {
+    hd_.off[d] = off;
+    nbr_[d] = g.neighbor_rank[d];
+    const int f = hd_.F[d & 3];
+    DDAMG_REQUIRE((int)g.face_sites[d].size() == f, "face table size mismatch");
+    fs.insert(fs.end(), g.face_sites[d].begin(), g.face_sites[d].end());
+    off += f * 12;
+    nface_total_ += f;
+  }
+  if (nface_total_ == 0) return;
+  for (int s : fs) DDAMG_REQUIRE(s >= 0 && s < g.V, "face table holds an invalid site");
+  DDAMG_HIP_CHECK(hipMalloc(&d_face_sites_, sizeof(int) * nface_total_));
+  DDAMG_HIP_CHECK(hipMemcpy(d_face_sites_, fs.data(), sizeof(int) * nface_total_, hipMemcpyHostToDevice));
+  const size_t bytes = sizeof(T) * 12 * (size_t)nface_total_;
+  DDAMG_HIP_CHECK(hipMalloc(&send_, bytes));
+  DDAMG_HIP_CHECK(hipMalloc(&recv_, bytes));
+  DDAMG_HIP_CHECK(hipMemset(recv_, 0, bytes));
+  n_interior_ = (int)g.interior_tiles.size();
+  n_boundary_ = (int)g.boundary_tiles.size();
+  if (n_interior_) {
+    DDAMG_HIP_CHECK(hipMalloc(&d_interior_, sizeof(int) * n_interior_));
+    DDAMG_HIP_CHECK(hipMemcpy(d_interior_, g.interior_tiles.data(), sizeof(int) * n_interior_, hipMemcpyHostToDevice));
+  }
+  if (n_boundary_) {
+    DDAMG_HIP_CHECK(hipMalloc(&d_boundary_, sizeof(int) * n_boundary_));
+    DDAMG_HIP_CHECK(hipMemcpy(d_boundary_, g.boundary_tiles.data(), sizeof(int) * n_boundary_, hipMemcpyHostToDevice));
+  }
+  DDAMG_HIP_CHECK(hipEventCreateWithFlags(&ev_packed_, hipEventDisableTiming));
+  DDAMG_HIP_CHECK(hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
+}
+
+template <typename T>
+Halo<T>::~Halo() {
+  if (d_face_sites_) (void)hipFree(d_face_sites_);
+  if (send_) (void)hipFree(send_);
+  if (recv_) (void)hipFree(recv_);
+  if (h_send_) (void)hipHostFree(h_send_);
+  if (h_recv_) (void)hipHostFree(h_recv_);
+  if (d_interior_) (void)hipFree(d_interior_);
+  if (d_boundary_) (void)hipFree(d_boundary_);
+  if (ev_packed_) (void)hipEventDestroy(ev_packed_);
+  if (ev_done_) (void)hipEventDestroy(ev_done_);
+}
+
+template <typename T>
+void Halo<T>::pack(const T* phi, const T* D, int V, hipStream_t st) {
+  hipLaunchKernelGGL(halo_pack_kernel<T>, dim3((nface_total_ + 255) / 256), dim3(256), 0, st, send_, phi, D, d_face_sites_, hd_, V, nface_total_);
+  DDAMG_HIP_CHECK(hipGetLastError());
+  DDAMG_HIP_CHECK(hipEventRecord(ev_packed_, st));
+}
+
+template <typename T>
+void Halo<T>::exchange_begin(Comm* c, hipStream_t st) {
+  DDAMG_REQUIRE(c != nullptr, "process grid > 1 but no transport: call ddamg_hip_comm_init_rccl or ddamg_hip_comm_init_host first");
+  DDAMG_HIP_CHECK(hipStreamWaitEvent(c->stream, ev_packed_, 0));
+  const size_t bytes = sizeof(T) * 12 * (size_t)nface_total_;
+  if (c->kind == 1) {
+    DDAMG_NCCL_CHECK(ncclGroupStart());
+    for (int mu = 0; mu < 4; mu++) {
+      if (!hd_.F[mu]) continue;
+      const size_t mb = sizeof(T) * 12 * (size_t)hd_.F[mu];
+      // data travelling in +mu: my +face products to the +mu neighbour, the -mu neighbour's into recv[4+mu];
+      // then data travelling in -mu.  With two processes in a direction both messages go to the same
+      // peer and are matched in this order.
+      DDAMG_NCCL_CHECK(ncclSend(send_ + hd_.off[mu], mb, ncclChar, nbr_[mu], c->nccl, c->stream));
+      DDAMG_NCCL_CHECK(ncclRecv(recv_ + hd_.off[4 + mu], mb, ncclChar, nbr_[4 + mu], c->nccl, c->stream));
+      DDAMG_NCCL_CHECK(ncclSend(send_ + hd_.off[4 + mu], mb, ncclChar, nbr_[4 + mu], c->nccl, c->stream));
+      DDAMG_NCCL_CHECK(ncclRecv(recv_ + hd_.off[mu], mb, ncclChar, nbr_[mu], c->nccl, c->stream));
+    }
+    DDAMG_NCCL_CHECK(ncclGroupEnd());
+    DDAMG_HIP_CHECK(hipEventRecord(ev_done_, c->stream));
+  } else {
+    if (!h_send_) {
+      DDAMG_HIP_CHECK(hipHostMalloc(&h_send_, bytes));
+      DDAMG_HIP_CHECK(hipHostMalloc(&h_recv_, bytes));
+    }
+    DDAMG_HIP_CHECK(hipMemcpyAsync(h_send_, send_, bytes, hipMemcpyDeviceToHost, c->stream));
+  }
+  (void)st;
+}
+
+template <typename T>
+void Halo<T>::exchange_finish(Comm* c, hipStream_t st) {
+  if (c->kind == 2) {
+    DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
+    ddamg_hip_halo_msg msgs[8];
+    int n = 0;
+    for (int mu = 0; mu < 4; mu++) {
+      if (!hd_.F[mu]) continue;
+      const unsigned long long mb = sizeof(T) * 12 * (unsigned long long)hd_.F[mu];
+      msgs[n++] = ddamg_hip_halo_msg{nbr_[mu], nbr_[4 + mu], mu, h_send_ + hd_.off[mu], h_recv_ + hd_.off[4 + mu], mb};
+      msgs[n++] = ddamg_hip_halo_msg{nbr_[4 + mu], nbr_[mu], 4 + mu, h_send_ + hd_.off[4 + mu], h_recv_ + hd_.off[mu], mb};
+    }
+    c->fn(c->user, n, msgs);
+    const size_t bytes = sizeof(T) * 12 * (size_t)nface_total_;
+    DDAMG_HIP_CHECK(hipMemcpyAsync(recv_, h_recv_, bytes, hipMemcpyHostToDevice, c->stream));
+    DDAMG_HIP_CHECK(hipEventRecord(ev_done_, c->stream));
+  }
+  DDAMG_HIP_CHECK(hipStreamWaitEvent(st, ev_done_, 0));
+}
+
+template class Halo<float>;
+template class Halo<double>;
+
+}  // namespace ddamg

@@ -48,6 +48,11 @@ typedef struct ddamg_hip_params {
   int method;                                  /* 0 pure GMRES, 2 FGMRES + red-black SAP      */
   double m0, csw;
   int device;                                  /* HIP device ordinal                          */
+  /* domain decomposition over GPUs: one process per GPU on a Cartesian grid (reference: g.process_grid and
+   * the MPI_Cart communicator, src/init.c:455-520 + src/data_layout.c:23-60).  rank = ((pt*Pz+pz)*Py+py)*Px+px.
+   * local_lattice[] is the per-process lattice.  All 1 / 0: single GPU. */
+  int process_grid[4];
+  int process_coords[4];
 } ddamg_hip_params;
 
 const char* ddamg_hip_last_error(void);
@@ -137,6 +142,35 @@ int ddamg_hip_residual_history(ddamg_hip_ctx* ctx, double* history, int max_len,
 /* device site ordering of a level: lex_of_site[s] = lexicographic index of device site s (the role of the
  * reference's translation_table, src/data_layout.c:152-251) */
 int ddamg_hip_get_site_order(ddamg_hip_ctx* ctx, int level, int* lex_of_site);
+
+/* ---- multi-GPU halo exchange (replaces ghost_sendrecv_PRECISION / ghost_wait_PRECISION and the
+ * plus/minus_dir_param phases of d_plus_clover_PRECISION, src/ghost_generic.c:152-330,
+ * src/dirac_generic.c:178-262) --------------------------------------------------------------------
+ * With process_grid != 1111 ddamg_hip_dirac_apply runs: pack the projected boundary half spinors
+ * (6 complex per face site and direction, as the reference sends) -> exchange -> interior
+ * tiles (overlapped with the exchange) -> boundary tiles.  Two transports:
+ *  - RCCL: ncclSend/ncclRecv on device buffers over xGMI.  Rank 0 obtains an id with
+ *    ddamg_hip_rccl_unique_id (128 bytes), the host application broadcasts it (MPI_Bcast /
+ *    torch.distributed) and every rank calls ddamg_hip_comm_init_rccl;
+ *  - host: the boundary data is staged through pinned host buffers and handed to a callback of the
+ *    host application, which moves the nmsg messages with its own MPI (MPI_Sendrecv per message).
+ *    send/recv peers are ranks in the process grid above. */
+typedef struct ddamg_hip_halo_msg {
+  int send_peer, recv_peer;  /* send `send` to send_peer, receive `recv` from recv_peer                 */
+  int tag;                   /* 0..3: data travelling in +mu, 4..7: data travelling in -mu              */
+  const void* send;
+  void* recv;
+  unsigned long long bytes;
+} ddamg_hip_halo_msg;
+typedef void (*ddamg_hip_exchange_fn)(void* user, int nmsg, const ddamg_hip_halo_msg* msgs);
+int ddamg_hip_rccl_unique_id(void* id128);
+int ddamg_hip_comm_init_rccl(ddamg_hip_ctx* ctx, const void* id128);
+int ddamg_hip_comm_init_host(ddamg_hip_ctx* ctx, ddamg_hip_exchange_fn fn, void* user);
+/* host-only helper (no GPU needed): the halo plan of one process.  For face d (0..3: +mu face sending to
+ * +mu, 4..7: -mu face) returns the neighbour rank and, if lex_sites != NULL, the local lexicographic index
+ * of the face sites in message (slot) order; *count = 0 when the direction is not split. */
+int ddamg_hip_halo_plan(const int local_lattice[4], const int process_grid[4], const int process_coords[4],
+                        int face, int* neighbor_rank, int* count, int* lex_sites);
 
 /* HIP-event timing on the context stream (bench.py's live roofline measurement) */
 int ddamg_hip_timer_begin(ddamg_hip_ctx* ctx);

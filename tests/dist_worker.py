@@ -1,0 +1,124 @@
+"""Worker of the multi-process tests (started through torch.distributed.run, gloo backend).
+
+mode plan  (CPU only): every process builds its halo plan through the C-ABI (host-only entry
+    point), the face-site coordinates travel as the halo messages would, and every receiver
+    checks that slot i of a message really is its neighbour x +- mu on the global lattice.
+mode dirac (GPU): the decomposed Wilson-Clover operator (pack -> exchange -> interior -> boundary)
+    against the reference's own output for the undivided 8^4 lattice (tests/golden).
+"""
+import argparse, os, sys
+import numpy as np
+import torch
+import torch.distributed as dist
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from ddalphaamg_amd import api, dist as ddist  # noqa: E402
+
+
+def lex_coords(idx, L):
+    c = np.zeros((len(idx), 4), dtype=np.int64)
+    r = np.asarray(idx, dtype=np.int64).copy()
+    for mu in (3, 2, 1, 0):
+        c[:, mu] = r % L[mu]
+        r //= L[mu]
+    return c
+
+
+def run_plan(rank, world, P, L):
+    C = ddist.coords_of(rank, P)
+    G = [L[mu] * P[mu] for mu in range(4)]
+    origin = np.array([C[mu] * L[mu] for mu in range(4)])
+    reqs, expect = [], []
+    for mu in range(4):
+        for face in (mu, 4 + mu):
+            nb, sites = api.halo_plan(L, P, C, face)
+            if P[mu] == 1:
+                assert len(sites) == 0 and nb == rank
+                continue
+            assert len(sites) == int(np.prod(L)) // L[mu]
+            gc = lex_coords(sites, L) + origin      # global coordinates of what I send
+            assert np.all(lex_coords(sites, L)[:, mu] == (L[mu] - 1 if face < 4 else 0))
+            reqs.append(dist.isend(torch.from_numpy(gc.copy()), dst=nb, tag=face))
+            # what arrives with this tag comes from the opposite neighbour and describes ITS face
+            # sites; they must be my opposite-face sites shifted by -+1 in mu
+            opp_nb, opp_sites = api.halo_plan(L, P, C, (face + 4) % 8)
+            buf = torch.empty((len(sites), 4), dtype=torch.int64)
+            reqs.append(dist.irecv(buf, src=opp_nb, tag=face))
+            mine = lex_coords(opp_sites, L) + origin
+            shift = np.zeros(4, dtype=np.int64); shift[mu] = -1 if face < 4 else +1
+            expect.append((buf, (mine + shift) % np.array(G)))
+    for r in reqs:
+        r.wait()
+    for buf, want in expect:
+        assert np.array_equal(buf.numpy(), want), "halo slot order does not match the neighbour's"
+    return 0.0
+
+
+def run_dirac(rank, world, P, prec, transport):
+    import ddalphaamg_amd as dd
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = np.load(os.path.join(here, "golden", "ref_8x8_dirac.npz"))
+    G = [int(x) for x in g["meta_int"][:4]]
+    L = [G[mu] // P[mu] for mu in range(4)]
+    C = ddist.coords_of(rank, P)
+    # the undivided operator, from the same entry point the single-GPU parity tests pin to the reference
+    p = api.default_params(); p.num_levels = 1
+    for mu in range(4):
+        p.local_lattice[0][mu] = G[mu]; p.block_lattice[0][mu] = 4
+    p.m0, p.csw = g["meta_f64"][0], g["meta_f64"][1]
+    whole = dd.Context(p)
+    whole.set_gauge(g["gauge"], anti_pbc=True)
+    D, cl = whole.get_operator()
+    whole.close()
+    q = api.default_params(); q.num_levels = 1
+    for mu in range(4):
+        q.local_lattice[0][mu] = L[mu]; q.block_lattice[0][mu] = 4 if L[mu] % 4 == 0 else 2
+        q.process_grid[mu] = P[mu]; q.process_coords[mu] = C[mu]
+    q.m0, q.csw = p.m0, p.csw
+    ctx = dd.Context(q)
+    ctx.set_operator(ddist.local_part(D, G, P, C), ddist.local_part(cl, G, P, C))
+    if transport == "host":
+        ddist.attach_host(ctx)
+    else:
+        ddist.attach_rccl(ctx, rank)
+    x = ctx.vector(0, prec).upload(ddist.local_part(g["dirac_in"], G, P, C))
+    y = ctx.vector(0, prec)
+    err = 0.0
+    for _ in range(3):   # repeated applies reuse the send/recv arenas
+        ctx.dirac_apply(y, x)
+        want = ddist.local_part(g["dirac_out_f64"], G, P, C).reshape(-1, 12, 2)
+        got = y.download()
+        err = max(err, float(np.linalg.norm(got - want) / np.linalg.norm(want)))
+    dist.barrier()
+    ctx.close()
+    return err
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mode", default="plan")
+    ap.add_argument("--grid", default="2,1,1,1")
+    ap.add_argument("--lattice", default="4,4,4,4")
+    ap.add_argument("--prec", type=int, default=64)
+    ap.add_argument("--transport", default="host")
+    ap.add_argument("--tol", type=float, default=1e-13)
+    a = ap.parse_args()
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    P = [int(x) for x in a.grid.split(",")]
+    assert int(np.prod(P)) == world
+    if a.mode == "plan":
+        err = run_plan(rank, world, P, [int(x) for x in a.lattice.split(",")])
+    else:
+        err = run_dirac(rank, world, P, a.prec, a.transport)
+    t = torch.tensor([err], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(f"DIST_WORKER_OK mode={a.mode} grid={a.grid} err={t.item():.3e}", flush=True)
+    dist.destroy_process_group()
+    if not t.item() <= a.tol:
+        sys.exit(3)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,65 @@
+"""Multi-process (one process per GPU) path: halo plan over gloo on the CPU, and the decomposed
+Wilson-Clover operator on the GPU with 2 and 4 processes (host transport; all on one card).
+Reference: ghost_sendrecv / d_plus_clover boundary phases, src/ghost_generic.c:152-330,
+src/dirac_generic.c:178-262; process grid src/data_layout.c:23-60."""
+import os, subprocess, sys, socket
+import numpy as np
+import pytest
+from ddalphaamg_amd import api, dist as ddist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def launch(nproc, *args, timeout=300):
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.join(HERE, "dist_worker.py"), *args]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "DIST_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+    return r.stdout
+
+
+def test_process_grid_helpers():
+    assert ddist.process_grid_for(1) == [1, 1, 1, 1]
+    assert ddist.process_grid_for(2) == [2, 1, 1, 1]
+    assert ddist.process_grid_for(8) == [2, 2, 2, 1]
+    assert ddist.process_grid_for(32) == [4, 2, 2, 2]
+    P = [2, 1, 2, 2]
+    for r in range(8):
+        c = ddist.coords_of(r, P)
+        assert ((c[0] * P[1] + c[1]) * P[2] + c[2]) * P[3] + c[3] == r
+    a = np.arange(4 * 4 * 4 * 4 * 2).reshape(256, 2)
+    part = ddist.local_part(a, [4, 4, 4, 4], [2, 1, 1, 2], [1, 0, 0, 1])
+    assert part.shape == (64, 2) and part[0, 0] == 2 * ((2 * 4 + 0) * 4 * 4 + 2)
+
+
+def test_halo_plan_single_process():
+    nb, sites = api.halo_plan([4, 4, 4, 4], [1, 1, 1, 1], [0, 0, 0, 0], 0)
+    assert nb == 0 and len(sites) == 0
+    nb, sites = api.halo_plan([4, 2, 6, 4], [1, 2, 1, 1], [0, 1, 0, 0], 5)
+    assert nb == 0 and len(sites) == 4 * 6 * 4
+    with pytest.raises(api.DDAMGError):
+        api.halo_plan([4, 4, 4, 4], [2, 1, 1, 1], [2, 0, 0, 0], 0)
+
+
+@pytest.mark.parametrize("nproc,grid,local", [(2, "2,1,1,1", "4,4,4,4"), (2, "1,1,1,2", "2,4,6,4"), (4, "1,2,2,1", "4,2,4,6")])
+def test_halo_plan_over_gloo(nproc, grid, local):
+    launch(nproc, "--mode", "plan", "--grid", grid, "--lattice", local, "--tol", "0")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,grid", [(2, "2,1,1,1"), (2, "1,1,1,2"), (4, "2,2,1,1"), (4, "1,1,2,2")])
+def test_decomposed_dirac_fp64(nproc, grid):
+    launch(nproc, "--mode", "dirac", "--grid", grid, "--prec", "64", "--tol", "1e-13")
+
+
+@pytest.mark.gpu
+def test_decomposed_dirac_fp32():
+    launch(4, "--mode", "dirac", "--grid", "2,1,2,1", "--prec", "32", "--tol", "2e-6")
