@@ -47,6 +47,7 @@ class HaloMsg(ctypes.Structure):
 
 
 EXCHANGE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(HaloMsg))
+ALLREDUCE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.POINTER(ctypes.c_double), ctypes.c_int)
 
 
 _lib = None
@@ -109,7 +110,7 @@ def load_library():
         "ddamg_hip_get_site_order": [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
         "ddamg_hip_rccl_unique_id": [vp],
         "ddamg_hip_comm_init_rccl": [vp, vp],
-        "ddamg_hip_comm_init_host": [vp, EXCHANGE_FN, vp],
+        "ddamg_hip_comm_init_host": [vp, EXCHANGE_FN, ALLREDUCE_FN, vp],
         "ddamg_hip_halo_plan": [ctypes.POINTER(ctypes.c_int)] * 3 + [ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 3,
         "ddamg_hip_timer_begin": [vp],
         "ddamg_hip_timer_end": [vp, ctypes.POINTER(ctypes.c_float)],
@@ -311,8 +312,9 @@ class Context:
         buf = ctypes.create_string_buffer(bytes(unique_id), 128)
         _check(self._lib.ddamg_hip_comm_init_rccl(self._h, ctypes.cast(buf, ctypes.c_void_p)))
 
-    def comm_init_host(self, exchange):
-        """exchange(list of (send_peer, recv_peer, tag, send: np.uint8 array, recv: np.uint8 array))"""
+    def comm_init_host(self, exchange, allreduce):
+        """exchange(list of (send_peer, recv_peer, tag, send: np.uint8 array, recv: np.uint8 array));
+        allreduce(np.float64 array) sums it over all processes in place"""
         def trampoline(_user, n, msgs):
             items = []
             for i in range(n):
@@ -322,8 +324,11 @@ class Context:
                 rcv = np.ctypeslib.as_array(ctypes.cast(m.recv, ctypes.POINTER(ctypes.c_uint8)), shape=(nb,))
                 items.append((m.send_peer, m.recv_peer, m.tag, snd, rcv))
             exchange(items)
-        self._exchange_cb = EXCHANGE_FN(trampoline)   # keep the callback object alive
-        _check(self._lib.ddamg_hip_comm_init_host(self._h, self._exchange_cb, None))
+        def reduce_trampoline(_user, buf, n):
+            allreduce(np.ctypeslib.as_array(buf, shape=(n,)))
+        self._exchange_cb = EXCHANGE_FN(trampoline)   # keep the callback objects alive
+        self._allreduce_cb = ALLREDUCE_FN(reduce_trampoline)
+        _check(self._lib.ddamg_hip_comm_init_host(self._h, self._exchange_cb, self._allreduce_cb, None))
 
     def timer_begin(self):
         _check(self._lib.ddamg_hip_timer_begin(self._h))

@@ -28,7 +28,12 @@ inline View site_range(int nreal, size_t V, size_t s0, size_t s1) {
 }
 
 // workspace for reductions (per stream user); holds per-block partials and the device/host result slots
+struct Comm;  // halo.h: transport between the processes of a decomposed lattice
+// sum d_buf[0..n) over all processes in place (enqueued behind `st`, which then waits for the result)
+void comm_allreduce(Comm* c, double* d_buf, int n, hipStream_t st);
+
 struct ReduceWork {
+  Comm* comm = nullptr;         // set on a process grid: every reduction below becomes a global one
   double* d_partial = nullptr;  // [max_blocks][2*max_m]
   double* d_result = nullptr;   // [2*max_m + 2]
   double* h_result = nullptr;   // pinned mirror

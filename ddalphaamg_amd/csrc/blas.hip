@@ -236,6 +236,8 @@ __global__ __launch_bounds__(BLK) void final_sum_kernel(const double* __restrict
   if (threadIdx.x == 0) out[k] = (sqrt_first && k == 0) ? sqrt(s[0]) : s[0];
 }
 
+__global__ void sqrt_inplace_kernel(double* x) { x[0] = sqrt(x[0]); }
+
 template <typename T>
 void vec_multi_dot(const T* X, size_t xstride, int m, const T* w, View v, ReduceWork& rw, double* d_out, hipStream_t st) {
   DDAMG_REQUIRE(m >= 1 && m <= rw.max_m, "multi_dot: too many vectors for the reduction workspace");
@@ -244,6 +246,7 @@ void vec_multi_dot(const T* X, size_t xstride, int m, const T* w, View v, Reduce
   hipLaunchKernelGGL(multi_dot_kernel<T>, dim3(gx, gy), dim3(BLK), 0, st, X, xstride, m, w, v, rw.d_partial);
   hipLaunchKernelGGL(final_sum_kernel, dim3(2 * m), dim3(BLK), 0, st, rw.d_partial, gx, 2 * m, d_out, 0);
   DDAMG_HIP_CHECK(hipGetLastError());
+  if (rw.comm) comm_allreduce(rw.comm, d_out, 2 * m, st);
 }
 
 template <typename T>
@@ -265,8 +268,13 @@ template <typename T>
 void vec_norm(const T* x, View v, ReduceWork& rw, double* d_out, hipStream_t st) {
   const int gx = std::min(grid_for(v.total() / Chunk<T>::CH), 1024);
   hipLaunchKernelGGL(norm2_kernel<T>, dim3(gx), dim3(BLK), 0, st, x, v, rw.d_partial);
-  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(BLK), 0, st, rw.d_partial, gx, 1, d_out, 1);
+  hipLaunchKernelGGL(final_sum_kernel, dim3(1), dim3(BLK), 0, st, rw.d_partial, gx, 1, d_out, rw.comm ? 0 : 1);
   DDAMG_HIP_CHECK(hipGetLastError());
+  if (rw.comm) {
+    comm_allreduce(rw.comm, d_out, 1, st);
+    hipLaunchKernelGGL(sqrt_inplace_kernel, dim3(1), dim3(1), 0, st, d_out);
+    DDAMG_HIP_CHECK(hipGetLastError());
+  }
 }
 
 template <typename T>
@@ -298,6 +306,7 @@ void vec_dot_and_norm2(const T* x, const T* y, View v, ReduceWork& rw, double* d
   hipLaunchKernelGGL(dot_norm2_kernel<T>, dim3(gx), dim3(BLK), 0, st, x, y, v, rw.d_partial);
   hipLaunchKernelGGL(final_sum_kernel, dim3(3), dim3(BLK), 0, st, rw.d_partial, gx, 3, d_out, 0);
   DDAMG_HIP_CHECK(hipGetLastError());
+  if (rw.comm) comm_allreduce(rw.comm, d_out, 3, st);
 }
 
 #define INST(T)                                                                                         \

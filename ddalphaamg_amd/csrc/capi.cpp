@@ -173,6 +173,9 @@ static void install_comm(ddamg_hip_ctx* c, Comm* comm) {
   c->comm = comm;
   c->fop32.set_comm(comm);
   c->fop64.set_comm(comm);
+  c->rw_outer.comm = comm; c->rw_blas.comm = comm; c->rw_mp.comm = comm;
+  if (c->mg32) c->mg32->set_comm(comm);
+  if (c->mg64) c->mg64->set_comm(comm);
 }
 
 int ddamg_hip_comm_init_rccl(ddamg_hip_ctx* c, const void* id128) {
@@ -183,11 +186,11 @@ int ddamg_hip_comm_init_rccl(ddamg_hip_ctx* c, const void* id128) {
   DDAMG_API_END
 }
 
-int ddamg_hip_comm_init_host(ddamg_hip_ctx* c, ddamg_hip_exchange_fn fn, void* user) {
+int ddamg_hip_comm_init_host(ddamg_hip_ctx* c, ddamg_hip_exchange_fn fn, ddamg_hip_allreduce_fn reduce_fn, void* user) {
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c, "null argument");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
-  install_comm(c, comm_create_host(c->levels[0]->geom, fn, user));
+  install_comm(c, comm_create_host(c->levels[0]->geom, fn, reduce_fn, user));
   DDAMG_API_END
 }
 

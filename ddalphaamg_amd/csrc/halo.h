@@ -25,7 +25,7 @@ struct HaloDev {
 struct Comm;  // transport state (RCCL communicator or host callback), shared by both precisions
 
 Comm* comm_create_rccl(const Geometry& g, const void* id128);
-Comm* comm_create_host(const Geometry& g, ddamg_hip_exchange_fn fn, void* user);
+Comm* comm_create_host(const Geometry& g, ddamg_hip_exchange_fn fn, ddamg_hip_allreduce_fn reduce_fn, void* user);
 void comm_destroy(Comm* c);
 void rccl_unique_id(void* id128);
 

@@ -1,5 +1,6 @@
 // halo.hip -- see halo.h
 #include "halo.h"
+#include "blas.h"
 #include "dirac_device.h"
 #include <rccl/rccl.h>
 #include <cstring>
@@ -20,9 +21,36 @@ struct Comm {
   ncclComm_t nccl = nullptr;
   hipStream_t stream = nullptr;
   ddamg_hip_exchange_fn fn = nullptr;
+  ddamg_hip_allreduce_fn reduce_fn = nullptr;
   void* user = nullptr;
   int rank = 0, nranks = 1;
+  hipEvent_t ev_a = nullptr, ev_b = nullptr;   // ordering between the compute stream and the transport stream
+  double* h_red = nullptr;                      // pinned staging for the host transport's reductions
+  int h_red_n = 0;
 };
+
+void comm_allreduce(Comm* c, double* d_buf, int n, hipStream_t st) {
+  if (!c || c->nranks == 1) return;
+  if (c->kind == 1) {
+    DDAMG_HIP_CHECK(hipEventRecord(c->ev_a, st));
+    DDAMG_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_a, 0));
+    DDAMG_NCCL_CHECK(ncclAllReduce(d_buf, d_buf, (size_t)n, ncclDouble, ncclSum, c->nccl, c->stream));
+    DDAMG_HIP_CHECK(hipEventRecord(c->ev_b, c->stream));
+    DDAMG_HIP_CHECK(hipStreamWaitEvent(st, c->ev_b, 0));
+  } else {
+    DDAMG_REQUIRE(c->reduce_fn != nullptr, "host transport without an allreduce callback");
+    if (n > c->h_red_n) {
+      if (c->h_red) DDAMG_HIP_CHECK(hipHostFree(c->h_red));
+      DDAMG_HIP_CHECK(hipHostMalloc(&c->h_red, sizeof(double) * n));
+      c->h_red_n = n;
+    }
+    DDAMG_HIP_CHECK(hipMemcpyAsync(c->h_red, d_buf, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+    DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+    c->reduce_fn(c->user, c->h_red, n);
+    DDAMG_HIP_CHECK(hipMemcpyAsync(d_buf, c->h_red, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    DDAMG_HIP_CHECK(hipStreamSynchronize(st));   // h_red is reused by the next reduction
+  }
+}
 
 void rccl_unique_id(void* id128) {
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
@@ -37,13 +65,15 @@ Comm* comm_create_rccl(const Geometry& g, const void* id128) {
   ncclUniqueId id;
   memcpy(&id, id128, sizeof id);
   DDAMG_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  DDAMG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
+  DDAMG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
   DDAMG_NCCL_CHECK(ncclCommInitRank(&c->nccl, g.nranks, id, g.rank));
   return c;
 }
-Comm* comm_create_host(const Geometry& g, ddamg_hip_exchange_fn fn, void* user) {
+Comm* comm_create_host(const Geometry& g, ddamg_hip_exchange_fn fn, ddamg_hip_allreduce_fn reduce_fn, void* user) {
   DDAMG_REQUIRE(fn != nullptr, "exchange callback is null");
   Comm* c = new Comm;
-  c->kind = 2; c->rank = g.rank; c->nranks = g.nranks; c->fn = fn; c->user = user;
+  c->kind = 2; c->rank = g.rank; c->nranks = g.nranks; c->fn = fn; c->reduce_fn = reduce_fn; c->user = user;
   DDAMG_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   return c;
 }
@@ -52,6 +82,9 @@ void comm_destroy(Comm* c) {
   if (c->stream) (void)hipStreamSynchronize(c->stream);
   if (c->nccl) (void)ncclCommDestroy(c->nccl);
   if (c->stream) (void)hipStreamDestroy(c->stream);
+  if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+  if (c->ev_b) (void)hipEventDestroy(c->ev_b);
+  if (c->h_red) (void)hipHostFree(c->h_red);
   delete c;
 }
 

@@ -37,14 +37,13 @@ static void ensure_mg(ddamg_hip_ctx* c) {
   std::vector<const Geometry*> geoms;
   for (auto& lv : c->levels) geoms.push_back(&lv->geom);
   if (c->par.mixed_precision == 0) {
-    if (!c->mg64) c->mg64.reset(new Multigrid<double>(c->par, geoms, &c->fop64, c->stream));
+    if (!c->mg64) { c->mg64.reset(new Multigrid<double>(c->par, geoms, &c->fop64, c->stream)); c->mg64->set_comm(c->comm); }
   } else {
-    if (!c->mg32) c->mg32.reset(new Multigrid<float>(c->par, geoms, &c->fop32, c->stream));
+    if (!c->mg32) { c->mg32.reset(new Multigrid<float>(c->par, geoms, &c->fop32, c->stream)); c->mg32->set_comm(c->comm); }
   }
 }
 
 static void ensure_outer(ddamg_hip_ctx* c) {
-  require_single_gpu(c, "the Krylov solver");
   if (c->outer_ready) return;
   const size_t n = (size_t)24 * c->levels[0]->geom.V;
   c->rw_outer.init(c->par.restart + 4);

@@ -63,4 +63,7 @@ def attach_host(ctx, group=None):
         for r in reqs:
             r.wait()
 
-    ctx.comm_init_host(exchange)
+    def allreduce(buf):
+        dist.all_reduce(torch.from_numpy(buf), op=dist.ReduceOp.SUM, group=group)
+
+    ctx.comm_init_host(exchange, allreduce)

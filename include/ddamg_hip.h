@@ -163,9 +163,12 @@ typedef struct ddamg_hip_halo_msg {
   unsigned long long bytes;
 } ddamg_hip_halo_msg;
 typedef void (*ddamg_hip_exchange_fn)(void* user, int nmsg, const ddamg_hip_halo_msg* msgs);
+/* sum buf[0..n) over all processes in place (MPI_Allreduce(MPI_IN_PLACE, buf, n, MPI_DOUBLE, MPI_SUM)): the global
+ * inner products and norms of the Krylov solvers (global_inner_product_PRECISION, src/linalg_generic.c:29-120) */
+typedef void (*ddamg_hip_allreduce_fn)(void* user, double* buf, int n);
 int ddamg_hip_rccl_unique_id(void* id128);
 int ddamg_hip_comm_init_rccl(ddamg_hip_ctx* ctx, const void* id128);
-int ddamg_hip_comm_init_host(ddamg_hip_ctx* ctx, ddamg_hip_exchange_fn fn, void* user);
+int ddamg_hip_comm_init_host(ddamg_hip_ctx* ctx, ddamg_hip_exchange_fn fn, ddamg_hip_allreduce_fn reduce_fn, void* user);
 /* host-only helper (no GPU needed): the halo plan of one process.  For face d (0..3: +mu face sending to
  * +mu, 4..7: -mu face) returns the neighbour rank and, if lex_sites != NULL, the local lexicographic index
  * of the face sites in message (slot) order; *count = 0 when the direction is not split. */

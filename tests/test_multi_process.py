@@ -63,3 +63,10 @@ def test_decomposed_dirac_fp64(nproc, grid):
 @pytest.mark.gpu
 def test_decomposed_dirac_fp32():
     launch(4, "--mode", "dirac", "--grid", "2,1,2,1", "--prec", "32", "--tol", "2e-6")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,grid,mp", [(2, "2,1,1,1", 1), (4, "1,2,1,2", 2)])
+def test_decomposed_pure_gmres(nproc, grid, mp):
+    """method 0: Arnoldi with global reductions over the process grid; --prec carries the mixed-precision mode"""
+    launch(nproc, "--mode", "gmres", "--grid", grid, "--prec", str(mp), "--tol", "1e-6")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""tools/solve_bench.py -- set up a two-level hierarchy on a synthetic lattice and time the FGMRES+AMG solve.
+"""tools/solve_bench.py -- set up a 2- or 3-level hierarchy on a synthetic lattice and time the FGMRES+AMG solve.
 
   python tools/solve_bench.py --lattice 16 16 16 16 --block 4 4 4 4 --nvec 24 --setup-iter 4
 """
@@ -33,20 +33,36 @@ def main():
     ap.add_argument("--csw", type=float, default=1.0)
     ap.add_argument("--eps", type=float, default=0.35)
     ap.add_argument("--solves", type=int, default=2)
+    ap.add_argument("--levels", type=int, default=2)
+    ap.add_argument("--agg1", type=int, nargs=4, default=[2, 2, 2, 2], help="level-1 aggregates (= blocks) for --levels 3")
+    ap.add_argument("--nvec1", type=int, default=28)
+    ap.add_argument("--mixed-precision", type=int, default=1)
+    ap.add_argument("--gauge", default="near_unit", choices=["near_unit", "random"])
     args = ap.parse_args()
     import ddalphaamg_amd as dd
     from ddalphaamg_amd import api
     L = args.lattice; V = int(np.prod(L))
-    p = api.default_params(); p.num_levels = 2
+    p = api.default_params(); p.num_levels = args.levels
     for mu in range(4):
         p.local_lattice[0][mu] = L[mu]; p.block_lattice[0][mu] = args.block[mu]; p.local_lattice[1][mu] = L[mu] // args.agg[mu]
+        if args.levels == 3:
+            p.block_lattice[1][mu] = args.agg1[mu]; p.local_lattice[2][mu] = p.local_lattice[1][mu] // args.agg1[mu]
     p.num_vect[0] = args.nvec; p.post_smooth_iter[0] = 2; p.block_iter[0] = 4; p.setup_iter[0] = args.setup_iter
+    if args.levels == 3:
+        p.num_vect[1] = args.nvec1; p.post_smooth_iter[1] = 2; p.block_iter[1] = 4; p.setup_iter[1] = 2
     p.restart, p.max_restart, p.tol = 50, 20, 1e-10
     p.coarse_iter, p.coarse_restart, p.coarse_tol = 100, 5, 5e-2
-    p.mixed_precision, p.method, p.odd_even = 1, 2, 1
+    p.mixed_precision, p.method, p.odd_even = args.mixed_precision, 2, 1
     p.m0, p.csw = args.m0, args.csw
     ctx = dd.Context(p)
-    t0 = time.time(); U = near_unit_gauge(V, args.eps, 20260101); t1 = time.time()
+    t0 = time.time()
+    if args.gauge == "near_unit":
+        U = near_unit_gauge(V, args.eps, 20260101)
+    else:
+        sys.path.insert(0, REPO)
+        from bench import synth_gauge
+        U = synth_gauge(V, 20260101)
+    t1 = time.time()
     plaq = ctx.set_gauge(U, anti_pbc=True); t2 = time.time()
     print(f"gauge gen {t1-t0:.1f}s  set_gauge {t2-t1:.1f}s  plaquette {plaq:.6f}", flush=True)
     t0 = time.time(); ci = ctx.setup(args.setup_iter); ctx.sync(); t1 = time.time()
