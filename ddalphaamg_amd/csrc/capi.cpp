@@ -100,7 +100,7 @@ int ddamg_hip_create(const ddamg_hip_params* p, ddamg_hip_ctx** out) {
     DDAMG_HIP_CHECK(hipMemcpy(lv->d_lex_of_site, lv->geom.lex_of_site.data(), sizeof(int) * lv->geom.V, hipMemcpyHostToDevice));
     c->levels.push_back(std::move(lv));
   }
-  srand(0);  // reference: srand( 1000*g.my_rank ) unless "randomize test vectors" (src/init.c:870-873)
+  srand(1000u * (unsigned)c->levels[0]->geom.rank);  // reference: srand( 1000*g.my_rank ) unless "randomize test vectors" (src/init.c:870-873)
   *out = c.release();
   DDAMG_API_END
 }

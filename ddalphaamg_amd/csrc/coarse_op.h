@@ -17,6 +17,7 @@
 #pragma once
 #include "common.h"
 #include "geometry.h"
+#include "halo.h"
 #include <vector>
 
 namespace ddamg {
@@ -25,9 +26,15 @@ template <typename T>
 struct CoarseOpDev {
   const T* M;      // [V][5][msize] complex
   const T* Minv;   // [V][msize] complex (self-coupling inverse)
-  const int* nb;   // [8][V]
+  const int* nb;   // [8][V]; -1 - slot for a neighbour on another GPU
   int V, n, nt;    // sites, dof per site, tiles per matrix dimension
   size_t msize;    // complex numbers per stored matrix = nt*nt*64
+  // halo of a decomposed lattice (reference: ghost_update_PRECISION + the '+=' receive of the backward
+  // products, src/ghost_generic.c:233-330, src/coarse_oddeven_generic.c:447-729): recv buffer d holds n complex
+  // per face site: d < 4 the neighbour's vector entries in(x+mu), d >= 4 the finished product
+  // G5 U_mu(x-mu)^H G5 in(x-mu) computed by the sender
+  const T* halo;
+  int hoff[8];     // element offsets of the 8 buffers
 };
 
 template <typename T>
@@ -41,7 +48,15 @@ class CoarseOp {
   void import_reference(const Geometry& g, const double* D_ref, const double* clover_ref, hipStream_t st);
   void export_reference(const Geometry& g, double* D_ref, double* clover_ref, hipStream_t st) const;
   void compute_self_inverse(hipStream_t st);  // Minv = M[0]^-1 on every site
-  CoarseOpDev<T> dev() const { return CoarseOpDev<T>{M_, Minv_, nb_, V_, n_, nt_, msize_}; }
+  CoarseOpDev<T> dev() const {
+    CoarseOpDev<T> d{M_, Minv_, nb_, V_, n_, nt_, msize_, reinterpret_cast<const T*>(arena_.recv()), {0, 0, 0, 0, 0, 0, 0, 0}};
+    for (int k = 0; k < 8; k++) d.hoff[k] = arena_.site_offset(k) * n_ * 2;
+    return d;
+  }
+  void set_comm(Comm* c) { comm_ = c; }
+  bool distributed() const { return arena_.active(); }
+  // fill the receive buffers from `in` (every routine below that includes hopping terms does this itself)
+  void halo_exchange(const T* in, hipStream_t st) const;
   int V() const { return V_; }
   int n() const { return n_; }
   T* matrices() { return M_; }
@@ -65,6 +80,8 @@ class CoarseOp {
   int* nb_ = nullptr;
   int V_ = 0, n_ = 0, nt_ = 0;
   size_t msize_ = 0;
+  mutable HaloArena arena_;
+  Comm* comm_ = nullptr;
 };
 
 }  // namespace ddamg

@@ -88,11 +88,17 @@ __global__ void coarse_site_kernel(T* __restrict__ out, const T* __restrict__ in
   } else if (prod <= 4) {
     const int mu = prod - 1;
     const int y = op.nb[(size_t)mu * V + x];
-    wave_mv<T, NT, false>(Mx + (size_t)(1 + mu) * op.msize * 2, in + (size_t)y * n * 2, n, r);
+    const T* vin = y >= 0 ? in + (size_t)y * n * 2 : op.halo + op.hoff[mu] + (size_t)(-1 - y) * n * 2;
+    wave_mv<T, NT, false>(Mx + (size_t)(1 + mu) * op.msize * 2, vin, n, r);
   } else {
     const int mu = prod - 5;
     const int y = op.nb[(size_t)(4 + mu) * V + x];
-    wave_mv<T, NT, true>(op.M + ((size_t)y * 5 + 1 + mu) * op.msize * 2, in + (size_t)y * n * 2, n, r);
+    if (y >= 0) {
+      wave_mv<T, NT, true>(op.M + ((size_t)y * 5 + 1 + mu) * op.msize * 2, in + (size_t)y * n * 2, n, r);
+    } else {   // the neighbouring process multiplied with its link already
+      const T* h = op.halo + op.hoff[4 + mu] + (size_t)(-1 - y) * n * 2;
+      for (int k = threadIdx.x & 63; k < 2 * np; k += 64) r[k] = k < 2 * n ? h[k] : (T)0;
+    }
   }
   __syncthreads();
   const int nwaves = blockDim.x >> 6;
@@ -112,6 +118,53 @@ __global__ void coarse_site_kernel(T* __restrict__ out, const T* __restrict__ in
   }
 }
 
+// boundary data for the neighbouring processes: one wavefront per face site
+template <typename T, int NT>
+__global__ void coarse_halo_pack_kernel(T* __restrict__ send, const T* __restrict__ in, CoarseOpDev<T> op, const int* __restrict__ face_sites,
+                                        int total, int f0, int f1, int f2, int f3) {
+  const int i = blockIdx.x;
+  if (i >= total) return;
+  const int F[4] = {f0, f1, f2, f3};
+  int d = 0, first = 0;
+  bool found = false;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    if (!found) {
+      if (i >= first + F[k & 3]) { first += F[k & 3]; d = k + 1; }
+      else found = true;
+    }
+  }
+  const int y = face_sites[i], n = op.n;
+  T* out = send + (size_t)i * n * 2;
+  __shared__ T tmp[2 * 8 * NT];   // wave_mv writes the padded length
+  if (d < 4) {
+    wave_mv<T, NT, true>(op.M + ((size_t)y * 5 + 1 + d) * op.msize * 2, in + (size_t)y * n * 2, n, tmp);
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * n; k += 64) out[k] = tmp[k];
+  } else {
+    for (int k = threadIdx.x; k < 2 * n; k += 64) out[k] = in[(size_t)y * n * 2 + k];
+  }
+}
+
+template <typename T>
+void CoarseOp<T>::halo_exchange(const T* in, hipStream_t st) const {
+  if (!arena_.active()) return;
+  const int total = arena_.total_sites();
+  T* send = reinterpret_cast<T*>(arena_.send());
+  const CoarseOpDev<T> op = dev();
+#define DDAMG_CASE(NTV) case NTV: hipLaunchKernelGGL((coarse_halo_pack_kernel<T, NTV>), dim3(total), dim3(64), 0, st, send, in, op, arena_.d_face_sites(), total, \
+                                                     arena_.face_sites(0), arena_.face_sites(1), arena_.face_sites(2), arena_.face_sites(3)); break;
+  switch (nt_) {
+    DDAMG_CASE(1) DDAMG_CASE(2) DDAMG_CASE(3) DDAMG_CASE(4) DDAMG_CASE(5) DDAMG_CASE(6) DDAMG_CASE(7) DDAMG_CASE(8)
+    default: DDAMG_REQUIRE(false, "coarse operator: more than 64 dof per site are not supported");
+  }
+#undef DDAMG_CASE
+  DDAMG_HIP_CHECK(hipGetLastError());
+  arena_.mark_packed(st);
+  arena_.exchange_begin(comm_, st);
+  arena_.exchange_finish(comm_, st);
+}
+
 template <typename T>
 static void launch_site(const CoarseOpDev<T>& op, T* out, const T* in, int s0, int s1, int mode, double ss, double sh, bool acc, hipStream_t st,
                         const int* site_list = nullptr, const unsigned char* dir_mask = nullptr, bool mask_invert = false) {
@@ -129,10 +182,12 @@ static void launch_site(const CoarseOpDev<T>& op, T* out, const T* in, int s0, i
 
 template <typename T> void CoarseOp<T>::apply(T* out, const T* in, hipStream_t st) const {
   DDAMG_REQUIRE(out != in, "coarse apply cannot run in place");
+  halo_exchange(in, st);
   launch_site<T>(dev(), out, in, 0, V_, MODE_FULL, 1.0, -1.0, false, st);
 }
 template <typename T> void CoarseOp<T>::hop(T* out, const T* in, int s0, int s1, double sign, bool accumulate, hipStream_t st) const {
   DDAMG_REQUIRE(out != in, "coarse hopping term cannot run in place");
+  halo_exchange(in, st);
   launch_site<T>(dev(), out, in, s0, s1, MODE_HOP, 0.0, sign, accumulate, st);
 }
 template <typename T> void CoarseOp<T>::self_mul(T* out, const T* in, int s0, int s1, bool inverse, hipStream_t st) const {
@@ -145,6 +200,8 @@ template <typename T> void CoarseOp<T>::self_mul(T* out, const T* in, int s0, in
 template <typename T> void CoarseOp<T>::apply_masked(T* out, const T* in, const int* site_list, int nsites, const unsigned char* dir_mask,
                                                      bool mask_invert, double sign_self, double sign_hop, bool accumulate, hipStream_t st) const {
   DDAMG_REQUIRE(out != in, "coarse apply cannot run in place");
+  // inverted face masks select couplings inside a block / aggregate, which never leave the process
+  if (!(dir_mask != nullptr && mask_invert)) halo_exchange(in, st);
   if (sign_self != 0.0) launch_site<T>(dev(), out, in, 0, nsites, MODE_FULL, sign_self, sign_hop, accumulate, st, site_list, dir_mask, mask_invert);
   else launch_site<T>(dev(), out, in, 0, nsites, MODE_HOP, 0.0, sign_hop, accumulate, st, site_list, dir_mask, mask_invert);
 }
@@ -221,6 +278,7 @@ void CoarseOp<T>::alloc(const Geometry& g, int n) {
   DDAMG_HIP_CHECK(hipMemset(Minv_, 0, sizeof(T) * 2 * msize_ * V_));
   DDAMG_HIP_CHECK(hipMalloc(&nb_, sizeof(int) * 8 * V_));
   DDAMG_HIP_CHECK(hipMemcpy(nb_, g.nb.data(), sizeof(int) * 8 * V_, hipMemcpyHostToDevice));
+  if (g.distributed()) arena_.init(g, sizeof(T) * 2 * n);
 }
 
 static inline size_t tile_off(int nt, int i, int j) { return ((size_t)((i >> 3) * nt + (j >> 3)) * 64 + (i & 7) * 8 + (j & 7)) * 2; }

@@ -43,6 +43,9 @@ class FineOp {
   FineOpDev<T> dev() const { return FineOpDev<T>{D_, clover_, clover_inv_, nb_, V_, halo_.recv(), halo_.dev()}; }
   int V() const { return V_; }
   void set_comm(Comm* c) { comm_ = c; }
+  // fill the receive arena with the boundary half spinors of `v` (for kernels other than apply() that couple
+  // to off-process neighbours through FineOpDev::halo: Schwarz residual updates, Galerkin products)
+  void halo_exchange(const T* v, hipStream_t st) const;
   bool distributed() const { return halo_.active(); }
 
  private:
@@ -54,6 +57,27 @@ class FineOp {
   mutable Halo<T> halo_;
   Comm* comm_ = nullptr;
 };
+
+#ifdef __HIPCC__
+}  // namespace ddamg
+#include "dirac_device.h"
+namespace ddamg {
+// couplings to a site on another GPU: the neighbour sent the projected half spinor (halo.h)
+template <typename T, int MU>
+__device__ __forceinline__ void halo_forward(const FineOpDev<T>& op, int slot, const T (&U)[18], T (&eta)[24]) {
+  T h[12], g[12];
+  load_site<T, 12>(op.halo + op.hd.off[MU], (size_t)op.hd.F[MU], (size_t)slot, h);       // (1-gamma_mu) phi(x+mu)
+  su3_mul<T>(U, h, g);
+  spin_reconstruct_sub<T, MU, -1>(g, eta);
+}
+template <typename T, int MU>
+__device__ __forceinline__ void halo_backward(const FineOpDev<T>& op, int slot, T (&eta)[24]) {
+  T g[12];
+  load_site<T, 12>(op.halo + op.hd.off[4 + MU], (size_t)op.hd.F[MU], (size_t)slot, g);   // D_mu(x-mu)^dagger (1+gamma_mu) phi(x-mu)
+  spin_reconstruct_sub<T, MU, +1>(g, eta);
+}
+
+#endif  // __HIPCC__
 
 // layout converters between the reference's lexicographic AoS fp64 vectors
 // ([V][ndof] complex, src/main_pre_def_generic.h:25-27) and device chunked-SoA vectors.

@@ -15,21 +15,6 @@
 #endif
 namespace ddamg {
 
-// couplings to a site on another GPU: the neighbour sent the projected half spinor (halo.h)
-template <typename T, int MU>
-__device__ __forceinline__ void halo_forward(const FineOpDev<T>& op, int slot, const T (&U)[18], T (&eta)[24]) {
-  T h[12], g[12];
-  load_site<T, 12>(op.halo + op.hd.off[MU], (size_t)op.hd.F[MU], (size_t)slot, h);       // (1-gamma_mu) phi(x+mu)
-  su3_mul<T>(U, h, g);
-  spin_reconstruct_sub<T, MU, -1>(g, eta);
-}
-template <typename T, int MU>
-__device__ __forceinline__ void halo_backward(const FineOpDev<T>& op, int slot, T (&eta)[24]) {
-  T g[12];
-  load_site<T, 12>(op.halo + op.hd.off[4 + MU], (size_t)op.hd.F[MU], (size_t)slot, g);   // D_mu(x-mu)^dagger (1+gamma_mu) phi(x-mu)
-  spin_reconstruct_sub<T, MU, +1>(g, eta);
-}
-
 template <typename T, int MU>
 __device__ __forceinline__ void hop_pair(const T* __restrict__ phi, const FineOpDev<T>& op, size_t s, T (&eta)[24]) {
   const size_t V = op.V;
@@ -205,6 +190,14 @@ void FineOp<T>::apply(T* eta, const T* phi, hipStream_t st) const {
   launch(halo_.n_interior(), halo_.interior_tiles());
   halo_.exchange_finish(comm_, st);
   launch(halo_.n_boundary(), halo_.boundary_tiles());
+}
+
+template <typename T>
+void FineOp<T>::halo_exchange(const T* v, hipStream_t st) const {
+  if (!halo_.active()) return;
+  halo_.pack(v, D_, V_, st);
+  halo_.exchange_begin(comm_, st);
+  halo_.exchange_finish(comm_, st);
 }
 
 template <typename T>

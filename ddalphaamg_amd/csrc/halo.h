@@ -29,35 +29,55 @@ Comm* comm_create_host(const Geometry& g, ddamg_hip_exchange_fn fn, ddamg_hip_al
 void comm_destroy(Comm* c);
 void rccl_unique_id(void* id128);
 
+// send / receive arenas of the 8 face messages of one field type and their exchange (any payload)
+class HaloArena {
+ public:
+  ~HaloArena();
+  void init(const Geometry& g, size_t bytes_per_face_site);
+  bool active() const { return total_sites_ > 0; }
+  int total_sites() const { return total_sites_; }
+  int face_sites(int mu) const { return F_[mu]; }
+  int site_offset(int d) const { return soff_[d]; }   // first face site of buffer d in arena order
+  const int* d_face_sites() const { return d_face_sites_; }
+  char* send() const { return send_; }
+  char* recv() const { return recv_; }
+  void mark_packed(hipStream_t st);                 // the pack kernel has been enqueued on st
+  // start the exchange of the packed data (returns at once for RCCL; with the host transport the calling
+  // thread blocks in exchange_finish while kernels launched in between run) and make `st` wait for it
+  void exchange_begin(Comm* c, hipStream_t st);
+  void exchange_finish(Comm* c, hipStream_t st);
+
+ private:
+  size_t bpfs_ = 0;
+  int F_[4] = {0, 0, 0, 0}, soff_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, nbr_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int total_sites_ = 0;
+  int* d_face_sites_ = nullptr;  // [total_sites] concatenated face_sites[d] in arena order
+  char *send_ = nullptr, *recv_ = nullptr, *h_send_ = nullptr, *h_recv_ = nullptr;
+  hipEvent_t ev_packed_ = nullptr, ev_done_ = nullptr;
+};
+
 template <typename T>
 class Halo {
  public:
   ~Halo();
   void init(const Geometry& g);
-  bool active() const { return nface_total_ > 0; }
+  bool active() const { return arena_.active(); }
   const HaloDev& dev() const { return hd_; }
-  const T* recv() const { return recv_; }
+  const T* recv() const { return reinterpret_cast<const T*>(arena_.recv()); }
   const int* interior_tiles() const { return d_interior_; }
   const int* boundary_tiles() const { return d_boundary_; }
   int n_interior() const { return n_interior_; }
   int n_boundary() const { return n_boundary_; }
   // pack kernel: fills the send arena from phi (needs the links: D = FineOpDev::D)
   void pack(const T* phi, const T* D, int V, hipStream_t st);
-  // start the exchange of the packed data (returns at once for RCCL; the host transport blocks the
-  // calling thread while the interior kernel, launched before, runs) and make `st` wait for it
-  void exchange_begin(Comm* c, hipStream_t st);
-  void exchange_finish(Comm* c, hipStream_t st);
+  void exchange_begin(Comm* c, hipStream_t st) { arena_.exchange_begin(c, st); }
+  void exchange_finish(Comm* c, hipStream_t st) { arena_.exchange_finish(c, st); }
 
  private:
   HaloDev hd_{};
-  int nface_total_ = 0;
-  int* d_face_sites_ = nullptr;  // [nface_total] concatenated face_sites[d] in arena order
-  T* send_ = nullptr; T* recv_ = nullptr;
-  T* h_send_ = nullptr; T* h_recv_ = nullptr;  // pinned, host transport only
+  HaloArena arena_;
   int* d_interior_ = nullptr; int* d_boundary_ = nullptr;
   int n_interior_ = 0, n_boundary_ = 0;
-  int nbr_[8];
-  hipEvent_t ev_packed_ = nullptr, ev_done_ = nullptr;
 };
 
 }  // namespace ddamg

@@ -133,80 +133,61 @@ __global__ __launch_bounds__(256) void halo_pack_kernel(T* __restrict__ send, co
   store_site<T, 12>(send + hd.off[d], (size_t)hd.F[mu], (size_t)slot, out);
 }
 
-template <typename T>
-void Halo<T>::init(const Geometry& g) {
-  nface_total_ = 0;
+// ---- arena + exchange -----------------------------------------------------------------------------
+void HaloArena::init(const Geometry& g, size_t bytes_per_face_site) {
+  bpfs_ = bytes_per_face_site;
+  DDAMG_REQUIRE(bpfs_ % 16 == 0, "halo payload per face site must be a multiple of 16 bytes");
+  total_sites_ = 0;
   std::vector<int> fs;
-  int off = 0;
-  for (int mu = 0; mu < 4; mu++) hd_.F[mu] = g.P[mu] > 1 ? g.face_size(mu) : 0;
+  for (int mu = 0; mu < 4; mu++) F_[mu] = g.P[mu] > 1 ? g.face_size(mu) : 0;
   for (int d = 0; d < 8; d++) {
-    hd_.off[d] = off;
+    soff_[d] = total_sites_;
     nbr_[d] = g.neighbor_rank[d];
-    const int f = hd_.F[d & 3];
+    const int f = F_[d & 3];
     DDAMG_REQUIRE((int)g.face_sites[d].size() == f, "face table size mismatch");
     fs.insert(fs.end(), g.face_sites[d].begin(), g.face_sites[d].end());
-    off += f * 12;
-    nface_total_ += f;
+    total_sites_ += f;
   }
-  if (nface_total_ == 0) return;
+  if (total_sites_ == 0) return;
   for (int s : fs) DDAMG_REQUIRE(s >= 0 && s < g.V, "face table holds an invalid site");
-  DDAMG_HIP_CHECK(hipMalloc(&d_face_sites_, sizeof(int) * nface_total_));
-  DDAMG_HIP_CHECK(hipMemcpy(d_face_sites_, fs.data(), sizeof(int) * nface_total_, hipMemcpyHostToDevice));
-  const size_t bytes = sizeof(T) * 12 * (size_t)nface_total_;
+  DDAMG_HIP_CHECK(hipMalloc(&d_face_sites_, sizeof(int) * total_sites_));
+  DDAMG_HIP_CHECK(hipMemcpy(d_face_sites_, fs.data(), sizeof(int) * total_sites_, hipMemcpyHostToDevice));
+  const size_t bytes = bpfs_ * (size_t)total_sites_;
   DDAMG_HIP_CHECK(hipMalloc(&send_, bytes));
   DDAMG_HIP_CHECK(hipMalloc(&recv_, bytes));
   DDAMG_HIP_CHECK(hipMemset(recv_, 0, bytes));
-  n_interior_ = (int)g.interior_tiles.size();
-  n_boundary_ = (int)g.boundary_tiles.size();
-  if (n_interior_) {
-    DDAMG_HIP_CHECK(hipMalloc(&d_interior_, sizeof(int) * n_interior_));
-    DDAMG_HIP_CHECK(hipMemcpy(d_interior_, g.interior_tiles.data(), sizeof(int) * n_interior_, hipMemcpyHostToDevice));
-  }
-  if (n_boundary_) {
-    DDAMG_HIP_CHECK(hipMalloc(&d_boundary_, sizeof(int) * n_boundary_));
-    DDAMG_HIP_CHECK(hipMemcpy(d_boundary_, g.boundary_tiles.data(), sizeof(int) * n_boundary_, hipMemcpyHostToDevice));
-  }
   DDAMG_HIP_CHECK(hipEventCreateWithFlags(&ev_packed_, hipEventDisableTiming));
   DDAMG_HIP_CHECK(hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
 }
 
-template <typename T>
-Halo<T>::~Halo() {
+HaloArena::~HaloArena() {
   if (d_face_sites_) (void)hipFree(d_face_sites_);
   if (send_) (void)hipFree(send_);
   if (recv_) (void)hipFree(recv_);
   if (h_send_) (void)hipHostFree(h_send_);
   if (h_recv_) (void)hipHostFree(h_recv_);
-  if (d_interior_) (void)hipFree(d_interior_);
-  if (d_boundary_) (void)hipFree(d_boundary_);
   if (ev_packed_) (void)hipEventDestroy(ev_packed_);
   if (ev_done_) (void)hipEventDestroy(ev_done_);
 }
 
-template <typename T>
-void Halo<T>::pack(const T* phi, const T* D, int V, hipStream_t st) {
-  hipLaunchKernelGGL(halo_pack_kernel<T>, dim3((nface_total_ + 255) / 256), dim3(256), 0, st, send_, phi, D, d_face_sites_, hd_, V, nface_total_);
-  DDAMG_HIP_CHECK(hipGetLastError());
-  DDAMG_HIP_CHECK(hipEventRecord(ev_packed_, st));
-}
+void HaloArena::mark_packed(hipStream_t st) { DDAMG_HIP_CHECK(hipEventRecord(ev_packed_, st)); }
 
-template <typename T>
-void Halo<T>::exchange_begin(Comm* c, hipStream_t st) {
+void HaloArena::exchange_begin(Comm* c, hipStream_t st) {
   DDAMG_REQUIRE(c != nullptr, "process grid > 1 but no transport: call ddamg_hip_comm_init_rccl or ddamg_hip_comm_init_host first");
   DDAMG_HIP_CHECK(hipStreamWaitEvent(c->stream, ev_packed_, 0));
-  const size_t bytes = sizeof(T) * 12 * (size_t)nface_total_;
+  const size_t bytes = bpfs_ * (size_t)total_sites_;
   if (c->kind == 1) {
     DDAMG_NCCL_CHECK(ncclGroupStart());
     for (int mu = 0; mu < 4; mu++) {
-      if (!hd_.F[mu]) continue;
-      const size_t mb = sizeof(T) * 12 * (size_t)hd_.F[mu];
-      // data travelling in +mu: my +face products to the +mu neighbour, the -mu neighbour's into recv[4+mu];
+      if (!F_[mu]) continue;
+      const size_t mb = bpfs_ * (size_t)F_[mu];
+      // data travelling in +mu: my +face buffer to the +mu neighbour, the -mu neighbour's into recv[4+mu];
       // then data travelling in -mu.  With two processes in a direction both messages go to the same
       // peer and are matched in this order.
-      DDAMG_NCCL_CHECK(ncclSend(send_ + hd_.off[mu], mb, ncclChar, nbr_[mu], c->nccl, c->stream));
-      DDAMG_NCCL_CHECK(ncclRecv(recv_ + hd_.off[4 + mu], mb, ncclChar, nbr_[4 + mu], c->nccl, c->stream));
-      DDAMG_NCCL_CHECK(ncclSend(send_ + hd_.off[4 + mu], mb, ncclChar, nbr_[4 + mu], c->nccl, c->stream));
-      DDAMG_NCCL_CHECK(ncclRecv(recv_ + hd_.off[mu], mb, ncclChar, nbr_[mu], c->nccl, c->stream));
+      DDAMG_NCCL_CHECK(ncclSend(send_ + bpfs_ * soff_[mu], mb, ncclChar, nbr_[mu], c->nccl, c->stream));
+      DDAMG_NCCL_CHECK(ncclRecv(recv_ + bpfs_ * soff_[4 + mu], mb, ncclChar, nbr_[4 + mu], c->nccl, c->stream));
+      DDAMG_NCCL_CHECK(ncclSend(send_ + bpfs_ * soff_[4 + mu], mb, ncclChar, nbr_[4 + mu], c->nccl, c->stream));
+      DDAMG_NCCL_CHECK(ncclRecv(recv_ + bpfs_ * soff_[mu], mb, ncclChar, nbr_[mu], c->nccl, c->stream));
     }
     DDAMG_NCCL_CHECK(ncclGroupEnd());
     DDAMG_HIP_CHECK(hipEventRecord(ev_done_, c->stream));
@@ -220,24 +201,57 @@ void Halo<T>::exchange_begin(Comm* c, hipStream_t st) {
   (void)st;
 }
 
-template <typename T>
-void Halo<T>::exchange_finish(Comm* c, hipStream_t st) {
+void HaloArena::exchange_finish(Comm* c, hipStream_t st) {
   if (c->kind == 2) {
     DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
     ddamg_hip_halo_msg msgs[8];
     int n = 0;
     for (int mu = 0; mu < 4; mu++) {
-      if (!hd_.F[mu]) continue;
-      const unsigned long long mb = sizeof(T) * 12 * (unsigned long long)hd_.F[mu];
-      msgs[n++] = ddamg_hip_halo_msg{nbr_[mu], nbr_[4 + mu], mu, h_send_ + hd_.off[mu], h_recv_ + hd_.off[4 + mu], mb};
-      msgs[n++] = ddamg_hip_halo_msg{nbr_[4 + mu], nbr_[mu], 4 + mu, h_send_ + hd_.off[4 + mu], h_recv_ + hd_.off[mu], mb};
+      if (!F_[mu]) continue;
+      const unsigned long long mb = bpfs_ * (unsigned long long)F_[mu];
+      msgs[n++] = ddamg_hip_halo_msg{nbr_[mu], nbr_[4 + mu], mu, h_send_ + bpfs_ * soff_[mu], h_recv_ + bpfs_ * soff_[4 + mu], mb};
+      msgs[n++] = ddamg_hip_halo_msg{nbr_[4 + mu], nbr_[mu], 4 + mu, h_send_ + bpfs_ * soff_[4 + mu], h_recv_ + bpfs_ * soff_[mu], mb};
     }
     c->fn(c->user, n, msgs);
-    const size_t bytes = sizeof(T) * 12 * (size_t)nface_total_;
+    const size_t bytes = bpfs_ * (size_t)total_sites_;
     DDAMG_HIP_CHECK(hipMemcpyAsync(recv_, h_recv_, bytes, hipMemcpyHostToDevice, c->stream));
     DDAMG_HIP_CHECK(hipEventRecord(ev_done_, c->stream));
   }
   DDAMG_HIP_CHECK(hipStreamWaitEvent(st, ev_done_, 0));
+}
+
+// ---- fine-level halo --------------------------------------------------------------------------------
+template <typename T>
+void Halo<T>::init(const Geometry& g) {
+  arena_.init(g, sizeof(T) * 12);
+  for (int mu = 0; mu < 4; mu++) hd_.F[mu] = arena_.face_sites(mu);
+  for (int d = 0; d < 8; d++) hd_.off[d] = arena_.site_offset(d) * 12;
+  if (!arena_.active()) return;
+  n_interior_ = (int)g.interior_tiles.size();
+  n_boundary_ = (int)g.boundary_tiles.size();
+  if (n_interior_) {
+    DDAMG_HIP_CHECK(hipMalloc(&d_interior_, sizeof(int) * n_interior_));
+    DDAMG_HIP_CHECK(hipMemcpy(d_interior_, g.interior_tiles.data(), sizeof(int) * n_interior_, hipMemcpyHostToDevice));
+  }
+  if (n_boundary_) {
+    DDAMG_HIP_CHECK(hipMalloc(&d_boundary_, sizeof(int) * n_boundary_));
+    DDAMG_HIP_CHECK(hipMemcpy(d_boundary_, g.boundary_tiles.data(), sizeof(int) * n_boundary_, hipMemcpyHostToDevice));
+  }
+}
+
+template <typename T>
+Halo<T>::~Halo() {
+  if (d_interior_) (void)hipFree(d_interior_);
+  if (d_boundary_) (void)hipFree(d_boundary_);
+}
+
+template <typename T>
+void Halo<T>::pack(const T* phi, const T* D, int V, hipStream_t st) {
+  const int total = arena_.total_sites();
+  hipLaunchKernelGGL(halo_pack_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, st, reinterpret_cast<T*>(arena_.send()), phi, D,
+                     arena_.d_face_sites(), hd_, V, total);
+  DDAMG_HIP_CHECK(hipGetLastError());
+  arena_.mark_packed(st);
 }
 
 template class Halo<float>;

@@ -59,7 +59,7 @@ class Multigrid {
   void import_interpolation(const double* P_lex_host);   // level-0 interpolation vectors as they are
   void operator_changed();              // fine operator re-uploaded: rebuild the coarse operators
   void set_kcycle_tol(double tol);
-  void set_comm(Comm* c) { comm_ = c; for (auto& lv : lv_) lv->rw.comm = c; }
+  void set_comm(Comm* c) { comm_ = c; for (auto& lv : lv_) { lv->rw.comm = c; lv->cop.set_comm(c); } }
 
   // ---- hot path -----------------------------------------------------------------------------
   void apply_op(int l, T* out, const T* in);

@@ -26,32 +26,41 @@ template <> struct Eps<float> { static constexpr float v = 1e-6f; };    // EPS_f
 template <> struct Eps<double> { static constexpr double v = 1e-14; };  // EPS_double (src/main.h:46)
 
 // acc -= hop_d(phi(nb)) for the couplings of `site` that leave the block (mask bit d set), phi in global memory
-template <typename T, int MU>
+template <typename T, int MU, bool DIST>
 __device__ __forceinline__ void ext_hop_pair(const T* __restrict__ phi, const FineOpDev<T>& op, size_t site, unsigned mask, T (&acc)[24]) {
   const size_t V = op.V;
   __builtin_amdgcn_sched_barrier(0);  // one direction at a time: bounds the live registers
   if (mask & (1u << MU)) {
     int j = op.nb[(size_t)MU * V + site];
-    T pn[24], U[18];
-    load_site<T, 24>(phi, V, j, pn);
+    T U[18];
     load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, site, U);
-    hop_accumulate<T, MU, true>(U, pn, acc);
+    if (!DIST || j >= 0) {
+      T pn[24];
+      load_site<T, 24>(phi, V, j, pn);
+      hop_accumulate<T, MU, true>(U, pn, acc);
+    } else {
+      halo_forward<T, MU>(op, -1 - j, U, acc);   // neighbour on another GPU: FineOp::halo_exchange(phi) ran before
+    }
   }
   __builtin_amdgcn_sched_barrier(0);
   if (mask & (1u << (4 + MU))) {
     int j = op.nb[(size_t)(4 + MU) * V + site];
-    T pn[24], U[18];
-    load_site<T, 24>(phi, V, j, pn);
-    load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, j, U);
-    hop_accumulate<T, MU, false>(U, pn, acc);
+    if (!DIST || j >= 0) {
+      T pn[24], U[18];
+      load_site<T, 24>(phi, V, j, pn);
+      load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, j, U);
+      hop_accumulate<T, MU, false>(U, pn, acc);
+    } else {
+      halo_backward<T, MU>(op, -1 - j, acc);
+    }
   }
 }
-template <typename T>
+template <typename T, bool DIST>
 __device__ __forceinline__ void ext_hops(const T* __restrict__ phi, const FineOpDev<T>& op, size_t site, unsigned mask, T (&acc)[24]) {
-  ext_hop_pair<T, 0>(phi, op, site, mask, acc);
-  ext_hop_pair<T, 1>(phi, op, site, mask, acc);
-  ext_hop_pair<T, 2>(phi, op, site, mask, acc);
-  ext_hop_pair<T, 3>(phi, op, site, mask, acc);
+  ext_hop_pair<T, 0, DIST>(phi, op, site, mask, acc);
+  ext_hop_pair<T, 1, DIST>(phi, op, site, mask, acc);
+  ext_hop_pair<T, 2, DIST>(phi, op, site, mask, acc);
+  ext_hop_pair<T, 3, DIST>(phi, op, site, mask, acc);
 }
 
 // acc -= sum over in-block neighbours of hop_d(src(nb)), src = LDS image [24][HS] of the other parity
@@ -121,7 +130,7 @@ __device__ __forceinline__ void block_allreduce3(T& a, T& b, T& c, T* red /* LDS
   }
 }
 
-template <typename T, int HS>
+template <typename T, int HS, bool DIST>
 __global__ __launch_bounds__((HS < 64 ? 64 : HS)) void sap_block_kernel(SapArgs<T> a) {
   constexpr int NT = HS < 64 ? 64 : HS;   // threads per workgroup
   constexpr int BPW = NT / HS;            // blocks per workgroup
@@ -163,13 +172,13 @@ __global__ __launch_bounds__((HS < 64 ? 64 : HS)) void sap_block_kernel(SapArgs<
     T xs[24], e[24], et[24];
     load_site<T, 24>(a.x, V, se, xs);
     clover_apply<T>(op.clover, V, se, xs, e);
-    ext_hops<T>(a.x, op, se, 0xffu, e);
+    ext_hops<T, DIST>(a.x, op, se, 0xffu, e);
     load_site<T, 24>(a.eta, V, se, et);
 #pragma unroll
     for (int k = 0; k < 24; k++) re[k] = et[k] - e[k];
     load_site<T, 24>(a.x, V, so, xs);
     clover_apply<T>(op.clover, V, so, xs, e);
-    ext_hops<T>(a.x, op, so, 0xffu, e);
+    ext_hops<T, DIST>(a.x, op, so, 0xffu, e);
     load_site<T, 24>(a.eta, V, so, et);
 #pragma unroll
     for (int k = 0; k < 24; k++) ro[k] = et[k] - e[k];
@@ -181,10 +190,10 @@ __global__ __launch_bounds__((HS < 64 ? 64 : HS)) void sap_block_kernel(SapArgs<
       T acc[24];
 #pragma unroll
       for (int k = 0; k < 24; k++) acc[k] = 0;
-      ext_hops<T>(a.latest, op, se, extE, acc);
+      ext_hops<T, DIST>(a.latest, op, se, extE, acc);
 #pragma unroll
       for (int k = 0; k < 24; k++) { re[k] -= acc[k]; acc[k] = 0; }
-      ext_hops<T>(a.latest, op, so, extO, acc);
+      ext_hops<T, DIST>(a.latest, op, so, extO, acc);
 #pragma unroll
       for (int k = 0; k < 24; k++) ro[k] -= acc[k];
     }
@@ -389,7 +398,7 @@ __device__ __forceinline__ void clover_reg(const T (&C)[72], const T (&in)[24], 
   herm6_mul<T>(C + 36, in + 12, out + 12);
 }
 
-template <typename T, int BS>
+template <typename T, int BS, bool DIST>
 __global__ __launch_bounds__((BS < 64 ? 64 : BS), (sizeof(T) == 4 ? 2 : 1)) void sap_site_kernel(SapArgs<T> a) {
   constexpr int HS = BS / 2;
   constexpr int NT = BS < 64 ? 64 : BS;
@@ -426,7 +435,7 @@ __global__ __launch_bounds__((BS < 64 ? 64 : BS), (sizeof(T) == 4 ? 2 : 1)) void
     T xs[24], e[24], et[24];
     load_site<T, 24>(a.x, V, s, xs);
     clover_apply<T>(op.clover, V, s, xs, e);
-    ext_hops<T>(a.x, op, s, 0xffu, e);
+    ext_hops<T, DIST>(a.x, op, s, 0xffu, e);
     load_site<T, 24>(a.eta, V, s, et);
 #pragma unroll
     for (int k = 0; k < 24; k++) v0[k] = et[k] - e[k];
@@ -436,7 +445,7 @@ __global__ __launch_bounds__((BS < 64 ? 64 : BS), (sizeof(T) == 4 ? 2 : 1)) void
       T acc[24];
 #pragma unroll
       for (int k = 0; k < 24; k++) acc[k] = 0;
-      ext_hops<T>(a.latest, op, s, ext, acc);
+      ext_hops<T, DIST>(a.latest, op, s, ext, acc);
 #pragma unroll
       for (int k = 0; k < 24; k++) v0[k] -= acc[k];
     }
@@ -597,13 +606,15 @@ static void launch_hs(const SapArgs<T>& a, hipStream_t st) {
     constexpr int NT = HS < 64 ? 64 : HS;
     constexpr int BPW = NT / HS;
     const int grid = (a.nblocks + BPW - 1) / BPW;
-    hipLaunchKernelGGL((sap_block_kernel<T, HS>), dim3(grid), dim3(NT), 0, st, a);
+    if (a.s.op.halo) hipLaunchKernelGGL((sap_block_kernel<T, HS, true>), dim3(grid), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((sap_block_kernel<T, HS, false>), dim3(grid), dim3(NT), 0, st, a);
   } else {
     constexpr int BS = 2 * HS > 256 ? 256 : 2 * HS;
     constexpr int NT = BS < 64 ? 64 : BS;
     constexpr int BPW = NT / BS;
     const int grid = (a.nblocks + BPW - 1) / BPW;
-    hipLaunchKernelGGL((sap_site_kernel<T, BS>), dim3(grid), dim3(NT), 0, st, a);
+    if (a.s.op.halo) hipLaunchKernelGGL((sap_site_kernel<T, BS, true>), dim3(grid), dim3(NT), 0, st, a);
+    else hipLaunchKernelGGL((sap_site_kernel<T, BS, false>), dim3(grid), dim3(NT), 0, st, a);
   }
   DDAMG_HIP_CHECK(hipGetLastError());
 }
@@ -616,6 +627,9 @@ void SapSmoother<T>::launch(int color, int mode, unsigned skip_mask, const T* et
   a.x = x; a.r = r; a.latest = latest; a.eta = eta;
   a.blocks = d_color_blocks_[color]; a.nblocks = ncol_[color];
   a.mode = mode < 0 ? MODE_NBOUNDARY : mode; a.skip_mask = skip_mask; a.solve = mode < 0 ? 0 : 1;
+  // couplings to blocks on neighbouring processes: the reference exchanges the ghost shell of latest_iter
+  // (or of x for the full residual) between the colour sweeps (src/schwarz_generic.c:1334-1339,1402-1420)
+  if (op_->distributed() && a.mode != MODE_NONE) op_->halo_exchange(a.mode == MODE_FULLRES ? x : latest, st);
   switch (HS_) {
     case 8: launch_hs<T, 8>(a, st); break;
     case 16: launch_hs<T, 16>(a, st); break;

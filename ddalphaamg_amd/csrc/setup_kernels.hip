@@ -10,20 +10,26 @@ __device__ __forceinline__ void mask_chirality(T (&v)[24], int chir) {
   for (int k = 0; k < 12; k++) v[12 * (1 - chir) + k] = 0;
 }
 
-template <typename T, int MU>
+template <typename T, int MU, bool DIST>
 __device__ __forceinline__ void agg_hop_pair(const T* __restrict__ v, int chir, const FineOpDev<T>& op, const unsigned char face,
                                              size_t s, T (&w0)[24], T* __restrict__ W, size_t wstride) {
   const size_t V = op.V;
   {
     const int j = op.nb[(size_t)MU * V + s];
     T pn[24], U[18];
-    load_site<T, 24>(v, V, j, pn);
-    mask_chirality<T>(pn, chir);
+    if (!DIST || j >= 0) {
+      load_site<T, 24>(v, V, j, pn);
+      mask_chirality<T>(pn, chir);
+    }
     load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, s, U);
     if (face & (1u << MU)) {
       T acc[24];
 #pragma unroll
       for (int k = 0; k < 24; k++) acc[k] = 0;
+      // a neighbour on another GPU (always across an aggregate face): its chirality-masked, projected
+      // spinor was exchanged beforehand (aggregate_dirac below)
+      if (DIST && j < 0) halo_forward<T, MU>(op, -1 - j, U, acc);
+      else
       hop_accumulate<T, MU, true>(U, pn, acc);  // acc = -hop
 #pragma unroll
       for (int k = 0; k < 24; k++) acc[k] = -acc[k];
@@ -46,7 +52,7 @@ __device__ __forceinline__ void agg_hop_pair(const T* __restrict__ v, int chir, 
   }
 }
 
-template <typename T>
+template <typename T, bool DIST>
 __global__ __launch_bounds__(256) void aggregate_dirac_kernel(T* __restrict__ W, const T* __restrict__ v, int chir, FineOpDev<T> op,
                                                               const unsigned char* __restrict__ agg_face) {
   const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -63,16 +69,25 @@ __global__ __launch_bounds__(256) void aggregate_dirac_kernel(T* __restrict__ W,
     if (chir == 0) { load_site<T, 36>(op.clover, V, s, cl); herm6_mul<T>(cl, p, w0); }
     else { load_site<T, 36>(op.clover + (size_t)36 * V, V, s, cl); herm6_mul<T>(cl, p + 12, w0 + 12); }
   }
-  agg_hop_pair<T, 0>(v, chir, op, face, s, w0, W, ws);
-  agg_hop_pair<T, 1>(v, chir, op, face, s, w0, W, ws);
-  agg_hop_pair<T, 2>(v, chir, op, face, s, w0, W, ws);
-  agg_hop_pair<T, 3>(v, chir, op, face, s, w0, W, ws);
+  agg_hop_pair<T, 0, DIST>(v, chir, op, face, s, w0, W, ws);
+  agg_hop_pair<T, 1, DIST>(v, chir, op, face, s, w0, W, ws);
+  agg_hop_pair<T, 2, DIST>(v, chir, op, face, s, w0, W, ws);
+  agg_hop_pair<T, 3, DIST>(v, chir, op, face, s, w0, W, ws);
   store_site<T, 24>(W, V, s, w0);
 }
 
 template <typename T>
 void aggregate_dirac(T* W, const T* v, int chir, const FineOp<T>& op, const unsigned char* d_agg_face, hipStream_t st) {
-  hipLaunchKernelGGL(aggregate_dirac_kernel<T>, dim3((op.V() + 255) / 256), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face);
+  if (op.distributed()) {
+    // W[0] serves as scratch for the chirality-masked copy whose boundary is sent to the neighbours
+    const size_t half = (size_t)12 * op.V();
+    DDAMG_HIP_CHECK(hipMemcpyAsync(W + chir * half, v + chir * half, sizeof(T) * half, hipMemcpyDeviceToDevice, st));
+    DDAMG_HIP_CHECK(hipMemsetAsync(W + (1 - chir) * half, 0, sizeof(T) * half, st));
+    op.halo_exchange(W, st);
+    hipLaunchKernelGGL((aggregate_dirac_kernel<T, true>), dim3((op.V() + 255) / 256), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face);
+  } else {
+    hipLaunchKernelGGL((aggregate_dirac_kernel<T, false>), dim3((op.V() + 255) / 256), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face);
+  }
   DDAMG_HIP_CHECK(hipGetLastError());
 }
 

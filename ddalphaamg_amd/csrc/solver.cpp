@@ -22,15 +22,13 @@ extern thread_local std::string g_ddamg_last_error;
   }                                                    \
   return 0;
 
-// this round the decomposed (multi-GPU) lattice carries the fine operator only; the smoother, the
-// coarse levels and the Krylov reductions are single-GPU
-static void require_single_gpu(ddamg_hip_ctx* c, const char* what) {
-  if (c->levels[0]->geom.distributed())
-    throw std::runtime_error(std::string(what) + " is not available on a process grid yet (only ddamg_hip_dirac_apply is)");
-}
-
 static void ensure_mg(ddamg_hip_ctx* c) {
-  require_single_gpu(c, "the multigrid hierarchy");
+  if (c->levels[0]->geom.distributed()) {
+    // on a process grid: fine operator, Schwarz smoother, transfer operators, coarsest-level solve and setup of a
+    // two-level method; the coarse-level smoother of deeper hierarchies is single-GPU so far
+    DDAMG_REQUIRE(c->par.num_levels == 2, "on a process grid only two-level hierarchies are available so far");
+    DDAMG_REQUIRE(c->comm != nullptr, "process grid > 1 but no transport: call ddamg_hip_comm_init_rccl or ddamg_hip_comm_init_host first");
+  }
   DDAMG_REQUIRE(c->have_operator, "no operator set (call ddamg_hip_set_gauge / ddamg_hip_set_operator first)");
   DDAMG_REQUIRE(c->par.num_levels >= 2, "multigrid needs at least two levels");
   DDAMG_REQUIRE(c->par.method == 2, "multigrid preconditioner needs method == 2 (red-black SAP)");

@@ -134,6 +134,92 @@ def run_gmres(rank, world, P, mp):
     return err
 
 
+def run_amg(rank, world, P, mp):
+    """two-level FGMRES+AMG on the decomposed 8^4 sample configuration (2^4 blocks and aggregates, Nvec 20):
+    (1) the hierarchy of the undivided run is handed over (interpolation vectors) and the Galerkin operator,
+    smoother, coarse operator and solve of the decomposed run are compared with it; (2) the decomposed run
+    does its own setup (each process draws its own random test vectors, srand(1000*rank) as the reference)."""
+    import ddalphaamg_amd as dd
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = np.load(os.path.join(here, "golden", "ref_8x8_dirac.npz"))
+    G = [8, 8, 8, 8]; Gc = [4, 4, 4, 4]
+    L = [G[mu] // P[mu] for mu in range(4)]
+    C = ddist.coords_of(rank, P)
+
+    def params(lat, grid, coords):
+        p = api.default_params(); p.num_levels = 2
+        for mu in range(4):
+            p.local_lattice[0][mu] = lat[mu]; p.block_lattice[0][mu] = 2; p.local_lattice[1][mu] = lat[mu] // 2
+            p.process_grid[mu] = grid[mu]; p.process_coords[mu] = coords[mu]
+        p.num_vect[0] = 20; p.post_smooth_iter[0] = 2; p.block_iter[0] = 4; p.setup_iter[0] = 3
+        p.restart, p.max_restart, p.tol = 30, 20, 1e-10
+        p.coarse_iter, p.coarse_restart, p.coarse_tol = 30, 10, 5e-2
+        p.mixed_precision, p.method, p.odd_even = mp, 2, 1
+        p.m0, p.csw = -0.5, 1.0
+        return p
+
+    def rel(a, b):
+        return float(np.linalg.norm(np.asarray(a) - np.asarray(b)) / np.linalg.norm(b))
+
+    V = 4096
+    b = np.zeros((V, 12, 2)); b[..., 0] = 1.0
+    rng = np.random.default_rng(5)
+    eta = rng.standard_normal((V, 12, 2)); phi0 = rng.standard_normal((V, 12, 2))
+    vc = rng.standard_normal((256, 40, 2))
+    whole = dd.Context(params(G, [1] * 4, [0] * 4))
+    whole.set_gauge(g["gauge"], anti_pbc=True)
+    D, cl = whole.get_operator()
+    whole.setup(3)
+    Pint = whole.get_interpolation()
+    Dc, clc = whole.get_coarse_operator()
+    x1, it1, cit1, rr1 = whole.solve(b, 1e-10)
+    prec = whole.vprec()
+    e = whole.vector(0, prec).upload(eta); ph = whole.vector(0, prec).upload(phi0)
+    whole.smoother(ph, e, 2, initial_guess_zero=False)
+    smooth1 = ph.download()
+    ci = whole.vector(1, prec).upload(vc); co = whole.vector(1, prec)
+    whole.coarse_apply(co, ci)
+    capp1 = co.download()
+    whole.close()
+
+    lp = lambda a, lat=G: ddist.local_part(a, lat, P, C)
+    # (1) same hierarchy
+    ctx = dd.Context(params(L, P, C))
+    ctx.set_operator(lp(D), lp(cl))
+    ddist.attach_host(ctx)
+    Ploc = np.stack([lp(Pint[k]) for k in range(20)])
+    ctx.set_test_vectors(Ploc, orthonormalised=True)
+    Dcl, clcl = ctx.get_coarse_operator()
+    errs = {"galerkin_D": rel(Dcl.reshape(-1), lp(Dc, Gc).reshape(-1)), "galerkin_self": rel(clcl.reshape(-1), lp(clc, Gc).reshape(-1))}
+    e = ctx.vector(0, prec).upload(lp(eta)); ph = ctx.vector(0, prec).upload(lp(phi0))
+    ctx.smoother(ph, e, 2, initial_guess_zero=False)
+    errs["smoother"] = rel(ph.download().reshape(-1), lp(smooth1).reshape(-1))
+    ci = ctx.vector(1, prec).upload(lp(vc, Gc)); co = ctx.vector(1, prec)
+    ctx.coarse_apply(co, ci)
+    errs["coarse_apply"] = rel(co.download().reshape(-1), lp(capp1, Gc).reshape(-1))
+    xl, it, cit, rr = ctx.solve(lp(b), 1e-10)
+    errs["solution"] = rel(xl.reshape(-1), lp(x1).reshape(-1))
+    ctx.close()
+    # (2) own setup on the process grid
+    ctx = dd.Context(params(L, P, C))
+    ctx.set_operator(lp(D), lp(cl))
+    ddist.attach_host(ctx)
+    ctx.setup(3)
+    xl2, it2, cit2, rr2 = ctx.solve(lp(b), 1e-10)
+    errs["solution_own_setup"] = rel(xl2.reshape(-1), lp(x1).reshape(-1))
+    dist.barrier()
+    ctx.close()
+    if rank == 0:
+        print(f"amg mp{mp}: undivided {it1} its ({cit1} coarse) relres {rr1:.2e} | same hierarchy {it} ({cit}) {rr:.2e} | own setup {it2} ({cit2}) {rr2:.2e}", flush=True)
+        print("errs", {k: f"{v:.2e}" for k, v in errs.items()}, flush=True)
+    tol32 = {"galerkin_D": 2e-5, "galerkin_self": 2e-5, "smoother": 5e-5, "coarse_apply": 2e-5, "solution": 1e-7, "solution_own_setup": 1e-7}
+    for k, v in errs.items():
+        assert v < tol32[k], (k, v)
+    assert abs(it - it1) <= 1 and abs(it2 - it1) <= 2, (it1, it, it2)
+    assert rr < 1.5e-10 and rr2 < 1.5e-10
+    return max(errs["solution"], errs["solution_own_setup"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="plan")
@@ -149,6 +235,8 @@ def main():
     assert int(np.prod(P)) == world
     if a.mode == "plan":
         err = run_plan(rank, world, P, [int(x) for x in a.lattice.split(",")])
+    elif a.mode == "amg":
+        err = run_amg(rank, world, P, a.prec)
     elif a.mode == "gmres":
         err = run_gmres(rank, world, P, a.prec)
     else:

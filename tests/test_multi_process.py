@@ -70,3 +70,10 @@ def test_decomposed_dirac_fp32():
 def test_decomposed_pure_gmres(nproc, grid, mp):
     """method 0: Arnoldi with global reductions over the process grid; --prec carries the mixed-precision mode"""
     launch(nproc, "--mode", "gmres", "--grid", grid, "--prec", str(mp), "--tol", "1e-6")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,grid,mp", [(2, "2,1,1,1", 1), (4, "1,2,1,2", 1), (2, "1,1,2,1", 2)])
+def test_decomposed_two_level_amg(nproc, grid, mp):
+    """Schwarz smoother, Galerkin construction, coarse operator and coarsest-level solve with halo exchange"""
+    launch(nproc, "--mode", "amg", "--grid", grid, "--prec", str(mp), "--tol", "1e-6", timeout=600)
