@@ -225,7 +225,7 @@ template <typename T> CoarseSap<T>::~CoarseSap() {
 template <typename T>
 void CoarseSap<T>::setup(const Geometry& g, const CoarseOp<T>* op, int block_iter, hipStream_t st) {
   op_ = op; V_ = g.V; n_ = op->n(); BS_ = g.block_sites; block_iter_ = block_iter;
-  for (int mu = 0; mu < 4; mu++) DDAMG_REQUIRE(g.nblk[mu] % 2 == 0, "red-black SAP needs an even number of blocks per direction");
+  for (int mu = 0; mu < 4; mu++) DDAMG_REQUIRE((g.nblk[mu] * g.P[mu]) % 2 == 0, "red-black SAP needs an even number of blocks per direction of the global lattice");
   const size_t nel = (size_t)V_ * n_ * 2;
   for (T** p : {&r, &latest, &x, &tmp}) { DDAMG_HIP_CHECK(hipMalloc(p, sizeof(T) * nel)); DDAMG_HIP_CHECK(hipMemsetAsync(*p, 0, sizeof(T) * nel, st)); }
   std::vector<int> bl[3], sl[3];

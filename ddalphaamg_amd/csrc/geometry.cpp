@@ -47,7 +47,7 @@ void Geometry::build(const int L_[4], const int B_[4], const int A_[4], const in
       int gb[4], minus = 0, plus = 0, inner = 0, csum = 0;
       for (int mu = 0; mu < 4; mu++) {
         gb[mu] = a[mu] * bpa[mu] + b[mu];
-        csum += gb[mu];
+        csum += gb[mu] + pc[mu] * nblk[mu];   // red-black colouring of the GLOBAL block lattice
         if (gb[mu] == 0) minus++;
         if (gb[mu] + 1 == nblk[mu]) plus++;
         if (gb[mu] != 0 && gb[mu] + 1 != nblk[mu]) inner++;
@@ -64,7 +64,9 @@ void Geometry::build(const int L_[4], const int B_[4], const int A_[4], const in
       for (int par = 0; par < 2; par++)
         for (r[0] = 0; r[0] < B[0]; r[0]++) for (r[1] = 0; r[1] < B[1]; r[1]++)
         for (r[2] = 0; r[2] < B[2]; r[2]++) for (r[3] = 0; r[3] < B[3]; r[3]++) {
-          if (((r[0] + r[1] + r[2] + r[3]) & 1) != par) continue;
+          // even sites first; parity of the global lattice (matters where the process origin is odd, which
+          // needs an odd local extent and hence only happens on a coarsest level with B == L)
+          if (((r[0] + r[1] + r[2] + r[3] + oe_offset) & 1) != par) continue;
           for (int mu = 0; mu < 4; mu++) c[mu] = gb[mu] * B[mu] + r[mu];
           int lx = lex(c);
           site_of_lex[lx] = s;
@@ -126,7 +128,7 @@ void Geometry::build(const int L_[4], const int B_[4], const int A_[4], const in
     for (int par = 0; par < 2; par++) {
       for (r[0] = 0; r[0] < B[0]; r[0]++) for (r[1] = 0; r[1] < B[1]; r[1]++)
       for (r[2] = 0; r[2] < B[2]; r[2]++) for (r[3] = 0; r[3] < B[3]; r[3]++) {
-        if (((r[0] + r[1] + r[2] + r[3]) & 1) != par) continue;
+        if (((r[0] + r[1] + r[2] + r[3] + oe_offset) & 1) != par) continue;
         int lb = ((r[0] * B[1] + r[1]) * B[2] + r[2]) * B[3] + r[3];
         local_of_lex[lb] = i;
         rc[i] = {r[0], r[1], r[2], r[3]};

@@ -574,7 +574,7 @@ void SapSmoother<T>::setup(const Geometry& g, const FineOp<T>* op, int block_ite
   DDAMG_REQUIRE(HS_ == 8 || HS_ == 16 || HS_ == 32 || HS_ == 64 || HS_ == 128 || HS_ == 256,
                 "Schwarz block volume must be 16..512 sites and a power of two on the GPU smoother");
   for (int mu = 0; mu < 4; mu++)
-    DDAMG_REQUIRE(g.nblk[mu] % 2 == 0, "red-black SAP needs an even number of blocks per direction");
+    DDAMG_REQUIRE((g.nblk[mu] * g.P[mu]) % 2 == 0, "red-black SAP needs an even number of blocks per direction of the global lattice");
   const size_t n = (size_t)24 * V_;
   DDAMG_HIP_CHECK(hipMalloc(&r, sizeof(T) * n));
   DDAMG_HIP_CHECK(hipMalloc(&latest, sizeof(T) * n));

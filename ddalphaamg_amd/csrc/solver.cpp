@@ -24,9 +24,6 @@ extern thread_local std::string g_ddamg_last_error;
 
 static void ensure_mg(ddamg_hip_ctx* c) {
   if (c->levels[0]->geom.distributed()) {
-    // on a process grid: fine operator, Schwarz smoother, transfer operators, coarsest-level solve and setup of a
-    // two-level method; the coarse-level smoother of deeper hierarchies is single-GPU so far
-    DDAMG_REQUIRE(c->par.num_levels == 2, "on a process grid only two-level hierarchies are available so far");
     DDAMG_REQUIRE(c->comm != nullptr, "process grid > 1 but no transport: call ddamg_hip_comm_init_rccl or ddamg_hip_comm_init_host first");
   }
   DDAMG_REQUIRE(c->have_operator, "no operator set (call ddamg_hip_set_gauge / ddamg_hip_set_operator first)");

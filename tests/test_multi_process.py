@@ -77,3 +77,11 @@ def test_decomposed_pure_gmres(nproc, grid, mp):
 def test_decomposed_two_level_amg(nproc, grid, mp):
     """Schwarz smoother, Galerkin construction, coarse operator and coarsest-level solve with halo exchange"""
     launch(nproc, "--mode", "amg", "--grid", grid, "--prec", str(mp), "--tol", "1e-6", timeout=600)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,grid,lattice", [(2, "2,1,1,1", "16,8,8,8"), (2, "2,1,1,1", "8,8,8,8"), (4, "1,2,2,1", "8,16,16,8")])
+def test_decomposed_three_level_amg(nproc, grid, lattice):
+    """K-cycle, coarse-level Schwarz smoother and coarse Galerkin construction on a process grid (random links; the
+    8^4 case is the reference's sample configuration, with odd local extents on the coarse levels)"""
+    launch(nproc, "--mode", "amg3", "--grid", grid, "--lattice", lattice, "--prec", "1", "--tol", "1e-6", timeout=900)
