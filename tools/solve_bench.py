@@ -9,17 +9,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
 
 
-def near_unit_gauge(V, eps, seed):
-    """SU(3) links exp(i eps H) with Gaussian Hermitian traceless H (smooth, solvable at m0 ~ -0.1...-0.5)"""
-    rng = np.random.default_rng(seed)
-    n = V * 4
-    a = rng.standard_normal((n, 3, 3)) + 1j * rng.standard_normal((n, 3, 3))
-    h = (a + a.conj().transpose(0, 2, 1)) / 2
-    h -= np.trace(h, axis1=1, axis2=2)[:, None, None] * np.eye(3) / 3
-    w, v = np.linalg.eigh(h)
-    u = (v * np.exp(1j * eps * w)[:, None, :]) @ v.conj().transpose(0, 2, 1)
-    out = np.empty((n, 9, 2)); out[..., 0] = u.reshape(n, 9).real; out[..., 1] = u.reshape(n, 9).imag
-    return out.reshape(V, 4, 9, 2)
+from bench import near_unit_gauge  # noqa: E402
 
 
 def main():
