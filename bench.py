@@ -294,6 +294,7 @@ def main():
         q.coarse_iter, q.coarse_restart, q.coarse_tol = 100, 5, 5e-2
         q.mixed_precision, q.method, q.odd_even = 1, 2, 1
         q.m0, q.csw, q.device = -0.3, 1.0, local_rank
+        q.test_vector_rng, q.rng_seed = 1, 20260101     # device generator for the random test vectors
         U = near_unit_gauge(V, 0.35, 20260101 + rank)   # smooth links: a system on which the multigrid has work to do
         # the headline number must survive the secondary leg: an exception is recorded, and on several GPUs a
         # watchdog prints the headline line and ends the process if the leg does not come back (a process that

@@ -35,6 +35,8 @@ class Params(ctypes.Structure):
         ("device", ctypes.c_int),
         ("process_grid", ctypes.c_int * 4),
         ("process_coords", ctypes.c_int * 4),
+        ("test_vector_rng", ctypes.c_int),
+        ("rng_seed", ctypes.c_ulonglong),
     ]
 
 

@@ -45,6 +45,8 @@ struct ReduceWork {
 };
 
 template <typename T> void vec_zero(T* x, View v, hipStream_t st);
+// x[i] = uniform(-0.5, 0.5) from a counter-based generator (splitmix64 of seed, stream, i); n reals
+template <typename T> void vec_random(T* x, size_t n, unsigned long long seed, unsigned long long stream, hipStream_t st);
 template <typename T> void vec_copy(T* y, const T* x, View v, hipStream_t st);
 // precision conversion between the float and double chunked-SoA layouts (V sites, nreal reals/site)
 template <typename TO, typename TI> void vec_convert(TO* y, const TI* x, size_t V, int nreal, hipStream_t st);

@@ -309,6 +309,24 @@ void vec_dot_and_norm2(const T* x, const T* y, View v, ReduceWork& rw, double* d
   if (rw.comm) comm_allreduce(rw.comm, d_out, 3, st);
 }
 
+template <typename T>
+__global__ void random_kernel(T* __restrict__ x, size_t n, unsigned long long seed, unsigned long long stream) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (i + 1) + 0xD1B54A32D192ED03ull * (stream + 1);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    x[i] = (T)((double)(z >> 11) * (1.0 / 9007199254740992.0) - 0.5);
+  }
+}
+template <typename T>
+void vec_random(T* x, size_t n, unsigned long long seed, unsigned long long stream, hipStream_t st) {
+  hipLaunchKernelGGL(random_kernel<T>, dim3(std::min<size_t>((n + 255) / 256, 4096)), dim3(256), 0, st, x, n, seed, stream);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+template void vec_random<float>(float*, size_t, unsigned long long, unsigned long long, hipStream_t);
+template void vec_random<double>(double*, size_t, unsigned long long, unsigned long long, hipStream_t);
+
 #define INST(T)                                                                                         \
   template void vec_zero<T>(T*, View, hipStream_t);                                                      \
   template void vec_copy<T>(T*, const T*, View, hipStream_t);                                            \

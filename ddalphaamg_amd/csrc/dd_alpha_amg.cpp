@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <string>
 #include <vector>
 
@@ -99,6 +100,10 @@ void params_from_ini(const Ini& ini, ddamg_hip_params& hp, int* anti_pbc) {
   ini.geti("kcycle:", &hp.kcycle); ini.geti("kcycle length:", &hp.kcycle_restart);
   ini.geti("kcycle restarts:", &hp.kcycle_max_restart); ini.getd("kcycle tolerance:", &hp.kcycle_tol);
   *anti_pbc = 0; ini.geti("antiperiodic boundary conditions:", anti_pbc);
+  // "randomize test vectors: 1" seeds rand() with the time in the reference (src/init.c:870-873): no particular
+  // sequence is promised, so the device generator takes over
+  int randomize = 0; ini.geti("randomize test vectors:", &randomize);
+  if (randomize) { hp.test_vector_rng = 1; hp.rng_seed = (unsigned long long)time(nullptr); }
 }
 
 void params_from_struct(const dd_alpha_amg_parameters& a, ddamg_hip_params& hp) {

@@ -1,5 +1,7 @@
 // mg.cpp -- see mg.h
 #include "mg.h"
+#include <chrono>
+#include <cstdlib>
 #include "setup_kernels.h"
 #include <cmath>
 #include <cstdlib>
@@ -187,6 +189,21 @@ void Multigrid<T>::vcycle(int l, T* phi, T* Dphi, const T* eta, int res) {
 }
 
 // ---- setup ------------------------------------------------------------------------------------------
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+template <typename T>
+double Multigrid<T>::tick(const char* phase, double t0) {
+  static const bool on = getenv("DDAMG_SETUP_TIMING") != nullptr;
+  if (!on) return 0;
+  DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
+  const double t = now_s();
+  if (phase) {
+    bool found = false;
+    for (auto& e : setup_times) if (e.first == phase) { e.second += t - t0; found = true; }
+    if (!found) setup_times.emplace_back(phase, t - t0);
+  }
+  return t;
+}
+
 template <typename T>
 double Multigrid<T>::norm_of(int l, const T* v) {
   MGLevel<T>& lv = *lv_[l];
@@ -203,6 +220,11 @@ template <typename T>
 void Multigrid<T>::random_vector(int l, T* dst) {
   MGLevel<T>& lv = *lv_[l];
   const int n = lv.n, V = lv.g->V;
+  if (par_.test_vector_rng == 1) {
+    // device generator: the layout of the vector does not matter for independent uniform numbers
+    vec_random<T>(dst, lv.nel, par_.rng_seed + 7919ull * (unsigned long long)lv.g->rank, rng_stream_++, st_);
+    return;
+  }
   std::vector<double> h((size_t)V * n * 2);
   for (int pos = 0; pos < V; pos++) {
     const size_t site = l == 0 ? (size_t)pos : (size_t)lv.ref_order[pos];
@@ -224,12 +246,15 @@ void Multigrid<T>::define_interpolation(int l) {
   const View all = whole(lv.nel);
   for (int k = 0; k < lv.nvec; k++) {
     T* tv = test_vector(l, k);
+    double t0 = tick(nullptr, 0);
     random_vector(l, tv);
+    t0 = tick("random test vectors", t0);
     // three smoother passes with 1, 2, 3 cycles (src/setup_generic.c:215-231)
     for (int c = 1; c <= 3; c++) {
       smoother(l, lv.buf[2], nullptr, tv, c, NO_RES);
       vec_copy<T>(tv, lv.buf[2], all, st_);
     }
+    tick("initial smoothing", t0);
   }
   for (int k = 0; k < lv.nvec; k++) {
     T* tv = test_vector(l, k);
@@ -249,6 +274,7 @@ void Multigrid<T>::build_coarse_operator(int l) {
   MGLevel<T>& lv = *lv_[l];
   MGLevel<T>& nx = *lv_[l + 1];
   const int N = lv.nvec;
+  const double t_start = tick(nullptr, 0);
   if (l == 0) {
     for (int chir = 0; chir < 2; chir++)
       for (int j = 0; j < N; j++) {
@@ -274,12 +300,15 @@ void Multigrid<T>::build_coarse_operator(int l) {
   }
   if (nx.coarsest) nx.cop.compute_self_inverse(st_);
   DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
+  tick("Galerkin coarse operator", t_start);
 }
 
 template <typename T>
 void Multigrid<T>::re_setup(int l) {
   if (lv_[l]->coarsest) return;
+  const double t0 = tick(nullptr, 0);
   orthonormalize(l);
+  tick("aggregate Gram-Schmidt", t0);
   build_coarse_operator(l);
   re_setup(l + 1);
 }
@@ -312,6 +341,7 @@ void Multigrid<T>::bootstrap(int l, int iters) {
   const size_t stride = tv_stride(l);
   for (int j = 0; j < iters; j++) {
     // gram_schmidt_PRECISION on the test vectors (classical, src/linalg_generic.c:483-528)
+    double tb = tick(nullptr, 0);
     for (int i = 0; i < lv.nvec; i++) {
       T* vi = test_vector(l, i);
       if (i > 0) {
@@ -320,6 +350,7 @@ void Multigrid<T>::bootstrap(int l, int iters) {
       }
       vec_scale<T>(vi, vi, 1.0 / norm_of(l, vi), 0.0, all, st_);
     }
+    tb = tick("test-vector Gram-Schmidt", tb);
     for (int i = 0; i < lv.nvec; i++) {
       T* out = l == 0 ? lv.buf[2] : lv.gm.x;   // the reference writes into l->p_PRECISION.x
       vcycle(l, out, nullptr, test_vector(l, i), NO_RES);
@@ -330,6 +361,7 @@ void Multigrid<T>::bootstrap(int l, int iters) {
       }
       vec_scale<T>(test_vector(l, i), out, 1.0 / norm_of(l, out), 0.0, all, st_);
     }
+    if (l == 0) tick("bootstrap V-cycles", tb);
     re_setup(l);
     if (l == 0 && !lv_[1]->coarsest)
       bootstrap(1, std::max(1, (int)std::lround((double)((j + 1) * par_.setup_iter[1]) / (double)iters)));

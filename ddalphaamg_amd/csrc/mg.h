@@ -18,6 +18,8 @@
 #include "../../include/ddamg_hip.h"
 #include <memory>
 #include <vector>
+#include <string>
+#include <utility>
 
 namespace ddamg {
 
@@ -79,6 +81,12 @@ class Multigrid {
   ddamg_hip_params par_;
   hipStream_t st_;
   Comm* comm_ = nullptr;
+  unsigned long long rng_stream_ = 0;
+ public:
+  // wall-clock seconds per setup phase (stream-synchronised), filled when DDAMG_SETUP_TIMING is set
+  std::vector<std::pair<std::string, double>> setup_times;
+ private:
+  double tick(const char* phase, double t0);
   std::vector<std::unique_ptr<MGLevel<T>>> lv_;
   int* d_lex0_ = nullptr;
   int* d_identity0_ = nullptr;

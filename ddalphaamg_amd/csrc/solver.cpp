@@ -3,6 +3,7 @@
 // fgmres_double + preconditioner (mixed precision 1) src/linsolve_generic.c:219-413, src/preconditioner.c:25-69.
 #include "context.h"
 #include <cstring>
+#include <cstdio>
 #include <string>
 
 using namespace ddamg;
@@ -143,6 +144,10 @@ int ddamg_hip_setup(ddamg_hip_ctx* c, int setup_iterations, int* coarse_iteratio
   if (c->mg32) { c->mg32->coarse_iter_count = 0; c->mg32->initial_setup(); c->mg32->iterative_setup(iters); if (coarse_iterations) *coarse_iterations = c->mg32->coarse_iter_count; }
   else { c->mg64->coarse_iter_count = 0; c->mg64->initial_setup(); c->mg64->iterative_setup(iters); if (coarse_iterations) *coarse_iterations = c->mg64->coarse_iter_count; }
   c->setup_done = true;
+  auto report = [](const std::vector<std::pair<std::string, double>>& t) {
+    for (auto& e : t) fprintf(stderr, "[ddamg setup] %-28s %8.3f s\n", e.first.c_str(), e.second);
+  };
+  if (c->mg32) report(c->mg32->setup_times); else report(c->mg64->setup_times);
   DDAMG_API_END
 }
 

@@ -53,6 +53,11 @@ typedef struct ddamg_hip_params {
    * local_lattice[] is the per-process lattice.  All 1 / 0: single GPU. */
   int process_grid[4];
   int process_coords[4];
+  /* random test vectors of the setup: 0 = libc rand() consumed in the reference's order (src/data_generic.c:42-56;
+   * reproduces the reference's hierarchies number for number, but costs ~5 ns per real on one host core),
+   * 1 = counter-based generator on the device (the role of "randomize test vectors: 1", src/init.c:870-873) */
+  int test_vector_rng;
+  unsigned long long rng_seed;
 } ddamg_hip_params;
 
 const char* ddamg_hip_last_error(void);

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--nvec1", type=int, default=28)
     ap.add_argument("--mixed-precision", type=int, default=1)
     ap.add_argument("--gauge", default="near_unit", choices=["near_unit", "random"])
+    ap.add_argument("--rng", type=int, default=1, help="0: libc rand() in the reference's order, 1: device generator")
     args = ap.parse_args()
     import ddalphaamg_amd as dd
     from ddalphaamg_amd import api
@@ -44,6 +45,7 @@ def main():
     p.coarse_iter, p.coarse_restart, p.coarse_tol = 100, 5, 5e-2
     p.mixed_precision, p.method, p.odd_even = args.mixed_precision, 2, 1
     p.m0, p.csw = args.m0, args.csw
+    p.test_vector_rng, p.rng_seed = args.rng, 20260101
     ctx = dd.Context(p)
     t0 = time.time()
     if args.gauge == "near_unit":
