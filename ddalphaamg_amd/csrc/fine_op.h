@@ -25,6 +25,9 @@ struct FineOpDev {
   int V;
   const T* halo;     // received boundary half spinors (null on a single GPU)
   HaloDev hd;
+  // arithmetic neighbours when a 256-site tile is exactly one Schwarz block (geometry.h); null otherwise
+  const int* tile_nb;             // [8][V/256]
+  const unsigned short* tnb;      // [256][8]
 };
 
 template <typename T>
@@ -40,7 +43,7 @@ class FineOp {
   void upload(const Geometry& g, const double* D_ref, const double* clover_ref, hipStream_t st);
   // eta = D_W phi; with a process grid: pack -> exchange (overlapped with the interior tiles) -> boundary tiles
   void apply(T* eta, const T* phi, hipStream_t st) const;
-  FineOpDev<T> dev() const { return FineOpDev<T>{D_, clover_, clover_inv_, nb_, V_, halo_.recv(), halo_.dev()}; }
+  FineOpDev<T> dev() const { return FineOpDev<T>{D_, clover_, clover_inv_, nb_, V_, halo_.recv(), halo_.dev(), tile_nb_, tnb_}; }
   int V() const { return V_; }
   void set_comm(Comm* c) { comm_ = c; }
   // fill the receive arena with the boundary half spinors of `v` (for kernels other than apply() that couple
@@ -53,6 +56,8 @@ class FineOp {
   T* clover_ = nullptr;
   T* clover_inv_ = nullptr;
   int* nb_ = nullptr;
+  int* tile_nb_ = nullptr;
+  unsigned short* tnb_ = nullptr;
   int V_ = 0;
   mutable Halo<T> halo_;
   Comm* comm_ = nullptr;

@@ -76,8 +76,25 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 4 : 3)) void dirac_apply_ker
 // the backward term of the +mu neighbour, which travels through LDS as a projected half spinor
 // (the scatter form of the reference's phase 3, src/dirac_generic.c:196-217, but inside a tile).
 // Only couplings that leave the tile touch global memory for neighbour data.
-template <typename T, int MU>
-__device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOpDev<T>& op, size_t s, bool live, int tile0,
+// neighbour of the thread's site in direction d (0..7): from the global table, or arithmetically when the tile is
+// one Schwarz block (no 32 B/site index traffic: a 16 B/thread tile-independent table + 8 scalars per tile)
+template <bool ARITH>
+__device__ __forceinline__ int tile_neighbor(const int* __restrict__ nb, size_t V, size_t s, int d, int tile0, const uint4& q,
+                                             const int* __restrict__ tile_nb, int ntiles_all) {
+  if constexpr (!ARITH) {
+    return nb[(size_t)d * V + s];
+  } else {
+    const unsigned w = (d >> 1) == 0 ? q.x : (d >> 1) == 1 ? q.y : (d >> 1) == 2 ? q.z : q.w;
+    const unsigned e = (d & 1) ? (w >> 16) : (w & 0xffffu);
+    const int li = (int)(e & 0x7fffu);
+    if (!(e & 0x8000u)) return tile0 + li;
+    const int tn = tile_nb[(size_t)d * ntiles_all + (tile0 >> 8)];   // wave-uniform
+    return tn >= 0 ? tn * 256 + li : nb[(size_t)d * V + s];
+  }
+}
+
+template <typename T, int MU, bool ARITH>
+__device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOpDev<T>& op, size_t s, bool live, int tile0, const uint4& q,
                                          const T (&p)[24], T (&e)[24], T* __restrict__ sp, T* __restrict__ hb) {
   const size_t V = op.V;
   const int t = threadIdx.x;
@@ -93,7 +110,7 @@ __device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOp
   }
   // (b) forward term with my own link
   if (live) {
-    const int j = op.nb[(size_t)MU * V + s];
+    const int j = tile_neighbor<ARITH>(op.nb, V, s, MU, tile0, q, op.tile_nb, (int)(V >> 8));
     if (j >= 0) {
       T pn[24];
       if (j - tile0 >= 0 && j - tile0 < 256) {
@@ -110,7 +127,7 @@ __device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOp
   __syncthreads();
   // (c) backward term: product computed by site s-mu (in LDS) or, across the tile face, from global memory
   if (live) {
-    const int j = op.nb[(size_t)(4 + MU) * V + s];
+    const int j = tile_neighbor<ARITH>(op.nb, V, s, 4 + MU, tile0, q, op.tile_nb, (int)(V >> 8));
     if (j < 0) {
       halo_backward<T, MU>(op, -1 - j, e);
     } else if (j - tile0 >= 0 && j - tile0 < 256) {
@@ -128,7 +145,7 @@ __device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOp
   __syncthreads();
 }
 
-template <typename T>
+template <typename T, bool ARITH>
 __global__ __launch_bounds__(256, 3) void dirac_apply_lds_kernel(T* __restrict__ eta, const T* __restrict__ phi, FineOpDev<T> op, int ntiles,
                                                                   const int* __restrict__ tile_list) {
   __shared__ T sp[24 * 256];
@@ -143,6 +160,8 @@ __global__ __launch_bounds__(256, 3) void dirac_apply_lds_kernel(T* __restrict__
   const size_t s = (size_t)tile0 + threadIdx.x;
   const bool live = s < V;
   T p[24], e[24];
+  uint4 q = make_uint4(0, 0, 0, 0);
+  if constexpr (ARITH) q = reinterpret_cast<const uint4*>(op.tnb)[threadIdx.x];
   if (live) load_site<T, 24>(phi, V, s, p);
   else {
 #pragma unroll
@@ -158,10 +177,10 @@ __global__ __launch_bounds__(256, 3) void dirac_apply_lds_kernel(T* __restrict__
     herm6_mul<T>(cl, p + 12, e + 12);
   }
   __syncthreads();
-  tile_dir<T, 0>(phi, op, s, live, tile0, p, e, sp, hb);
-  tile_dir<T, 1>(phi, op, s, live, tile0, p, e, sp, hb);
-  tile_dir<T, 2>(phi, op, s, live, tile0, p, e, sp, hb);
-  tile_dir<T, 3>(phi, op, s, live, tile0, p, e, sp, hb);
+  tile_dir<T, 0, ARITH>(phi, op, s, live, tile0, q, p, e, sp, hb);
+  tile_dir<T, 1, ARITH>(phi, op, s, live, tile0, q, p, e, sp, hb);
+  tile_dir<T, 2, ARITH>(phi, op, s, live, tile0, q, p, e, sp, hb);
+  tile_dir<T, 3, ARITH>(phi, op, s, live, tile0, q, p, e, sp, hb);
   if (live) store_site<T, 24, DDAMG_NT_STORE>(eta, V, s, e);
 }
 
@@ -177,7 +196,8 @@ void FineOp<T>::apply(T* eta, const T* phi, hipStream_t st) const {
   auto launch = [&](int ntiles, const int* tile_list) {
     if (ntiles == 0) return;
     if (g_dirac_variant == 0) hipLaunchKernelGGL(dirac_apply_kernel<T>, dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), tile_list);
-    else hipLaunchKernelGGL(dirac_apply_lds_kernel<T>, dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, tile_list);
+    else if (tnb_ && g_dirac_variant != 4) hipLaunchKernelGGL((dirac_apply_lds_kernel<T, true>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, tile_list);
+    else hipLaunchKernelGGL((dirac_apply_lds_kernel<T, false>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, tile_list);
     DDAMG_HIP_CHECK(hipGetLastError());
   };
   if (!halo_.active()) {
@@ -206,6 +226,8 @@ FineOp<T>::~FineOp() {
   if (clover_) (void)hipFree(clover_);
   if (clover_inv_) (void)hipFree(clover_inv_);
   if (nb_) (void)hipFree(nb_);
+  if (tile_nb_) (void)hipFree(tile_nb_);
+  if (tnb_) (void)hipFree(tnb_);
 }
 
 // inverse of a Hermitian positive definite-ish 6x6 matrix (Gauss-Jordan with partial pivoting)
@@ -274,6 +296,12 @@ void FineOp<T>::upload(const Geometry& g, const double* D_ref, const double* clo
   DDAMG_HIP_CHECK(hipMemcpyAsync(clover_, hC.data(), sizeof(T) * 72 * V, hipMemcpyHostToDevice, st));
   DDAMG_HIP_CHECK(hipMemcpyAsync(clover_inv_, hI.data(), sizeof(T) * 72 * V, hipMemcpyHostToDevice, st));
   DDAMG_HIP_CHECK(hipMemcpyAsync(nb_, g.nb.data(), sizeof(int) * 8 * V, hipMemcpyHostToDevice, st));
+  if (g.block_sites == 256 && !tnb_) {   // one tile of the LDS kernel == one Schwarz block: arithmetic neighbours
+    DDAMG_HIP_CHECK(hipMalloc(&tile_nb_, sizeof(int) * 8 * g.num_blocks));
+    DDAMG_HIP_CHECK(hipMalloc(&tnb_, sizeof(unsigned short) * 8 * 256));
+    DDAMG_HIP_CHECK(hipMemcpyAsync(tile_nb_, g.block_nb.data(), sizeof(int) * 8 * g.num_blocks, hipMemcpyHostToDevice, st));
+    DDAMG_HIP_CHECK(hipMemcpyAsync(tnb_, g.blk_wrap_nb.data(), sizeof(unsigned short) * 8 * 256, hipMemcpyHostToDevice, st));
+  }
   DDAMG_HIP_CHECK(hipStreamSynchronize(st));
   if (g.distributed() && !halo_.active()) halo_.init(g);
 }

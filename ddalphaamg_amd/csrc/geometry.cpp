@@ -40,6 +40,8 @@ void Geometry::build(const int L_[4], const int B_[4], const int A_[4], const in
   for (int mu = 0; mu < 4; mu++) bpa[mu] = A[mu] / B[mu];
   int s = 0, blk = 0;
   int a[4], b[4], r[4], c[4];
+  std::vector<int> blk_of_coord(num_blocks, -1);
+  std::vector<std::array<int, 4>> coord_of_blk(num_blocks);
   for (a[0] = 0; a[0] < nagg[0]; a[0]++) for (a[1] = 0; a[1] < nagg[1]; a[1]++)
   for (a[2] = 0; a[2] < nagg[2]; a[2]++) for (a[3] = 0; a[3] < nagg[3]; a[3]++)
     for (b[0] = 0; b[0] < bpa[0]; b[0]++) for (b[1] = 0; b[1] < bpa[1]; b[1]++)
@@ -52,6 +54,8 @@ void Geometry::build(const int L_[4], const int B_[4], const int A_[4], const in
         if (gb[mu] + 1 == nblk[mu]) plus++;
         if (gb[mu] != 0 && gb[mu] + 1 != nblk[mu]) inner++;
       }
+      blk_of_coord[((gb[0] * nblk[1] + gb[1]) * nblk[2] + gb[2]) * nblk[3] + gb[3]] = blk;
+      coord_of_blk[blk] = {gb[0], gb[1], gb[2], gb[3]};
       int col = csum & 1;
       block_color[blk] = col;
       // the reference's 8 red-black lists: per colour {inner, one-sided, two-sided, other one-sided}
@@ -78,6 +82,17 @@ void Geometry::build(const int L_[4], const int B_[4], const int A_[4], const in
       blk++;
     }
   DDAMG_REQUIRE(s == V && blk == num_blocks, "site enumeration is inconsistent");
+  block_nb.assign((size_t)8 * num_blocks, -1);
+  for (int bi = 0; bi < num_blocks; bi++)
+    for (int mu = 0; mu < 4; mu++)
+      for (int sgn = 0; sgn < 2; sgn++) {
+        auto q = coord_of_blk[bi];
+        const int nxt = q[mu] + (sgn == 0 ? 1 : -1);
+        const bool leaves = nxt < 0 || nxt >= nblk[mu];
+        q[mu] = (nxt + nblk[mu]) % nblk[mu];
+        block_nb[(size_t)(sgn * 4 + mu) * num_blocks + bi] =
+            (leaves && P[mu] > 1) ? -1 : blk_of_coord[((q[0] * nblk[1] + q[1]) * nblk[2] + q[2]) * nblk[3] + q[3]];
+      }
 
   // neighbour tables: periodic wrap inside the local volume where the direction is not split over
   // processes, a halo slot (-1 - slot) where it is
@@ -136,6 +151,18 @@ void Geometry::build(const int L_[4], const int B_[4], const int A_[4], const in
       }
       if (par == 0) block_even_sites = i;
     }
+    blk_wrap_nb.assign((size_t)block_sites * 8, 0);
+    if (block_sites < 0x8000)
+      for (i = 0; i < block_sites; i++)
+        for (int mu = 0; mu < 4; mu++)
+          for (int sgn = 0; sgn < 2; sgn++) {
+            auto q = rc[i];
+            const int nxt = q[mu] + (sgn == 0 ? 1 : -1);
+            const bool leaves = nxt < 0 || nxt >= B[mu];
+            q[mu] = (nxt + B[mu]) % B[mu];
+            const int li = local_of_lex[((q[0] * B[1] + q[1]) * B[2] + q[2]) * B[3] + q[3]];
+            blk_wrap_nb[(size_t)i * 8 + sgn * 4 + mu] = (unsigned short)(li | (leaves ? 0x8000 : 0));
+          }
     for (i = 0; i < block_sites; i++)
       for (int mu = 0; mu < 4; mu++) {
         auto q = rc[i];

@@ -35,6 +35,10 @@ struct Geometry {
   int neighbor_rank[8];             // rank of the process in direction d (== my rank when P[mu] == 1)
   int rank = 0, nranks = 1;
   std::vector<int> interior_tiles, boundary_tiles;  // 256-site tiles without / with an off-rank neighbour
+  // arithmetic neighbours for kernels whose workgroup is one Schwarz block: neighbour site =
+  //   (leaves the block ? block_nb[d][block] : block) * block_sites + (blk_wrap_nb[i][d] & 0x7fff)
+  std::vector<int> block_nb;                 // [8*num_blocks] neighbouring block (periodic), -1 across a process boundary
+  std::vector<unsigned short> blk_wrap_nb;   // [block_sites*8] block-local index of the neighbour wrapped into the block, | 0x8000 if it leaves it
   std::vector<int> blk_nb;       // [8*block_sites] in-block neighbour (block-local index) or -1
   std::vector<int> block_color;  // [num_blocks] red-black colour (src/schwarz_generic.c:383-395)
   std::vector<int> block_list;   // [num_blocks] 0..7: red-black list of the reference (:415-428)
