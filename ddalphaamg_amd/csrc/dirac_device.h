@@ -49,9 +49,43 @@ __device__ __forceinline__ void spin_project(const T (&phi)[24], T (&h)[12]) {
   spin_project_row<T, MU, SIGN, 1>(phi, h);
 }
 
+// ---- packed fp32 complex arithmetic ---------------------------------------------------------------
+// gfx950 reaches its fp32 vector peak only with v_pk_fma_f32 (two lanes' worth per instruction); a complex
+// multiply-accumulate is exactly two of them with operand swizzles (op_sel).  hipcc's SLP vectoriser is off
+// (it packed unrelated scalars and blew up register pressure); here the pairs are the (re,im) parts that sit
+// in neighbouring registers anyway.
+#ifndef DDAMG_PK
+#define DDAMG_PK 1
+#endif
+typedef float pkf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ pkf2 pk_make(float a, float b) { pkf2 r = {a, b}; return r; }
+// acc + a*b
+__device__ __forceinline__ pkf2 pk_cmac(pkf2 acc, pkf2 a, pkf2 b) {
+  acc = __builtin_elementwise_fma(pk_make(b.x, b.x), a, acc);
+  return __builtin_elementwise_fma(pk_make(-b.y, b.y), pk_make(a.y, a.x), acc);
+}
+// acc + conj(a)*b
+__device__ __forceinline__ pkf2 pk_cmac_conj(pkf2 acc, pkf2 a, pkf2 b) {
+  acc = __builtin_elementwise_fma(pk_make(a.x, a.x), b, acc);
+  return __builtin_elementwise_fma(pk_make(a.y, -a.y), pk_make(b.y, b.x), acc);
+}
+
 // g = U h on both spin rows (mvm) ; U row-major 3x3 complex (18 reals)
 template <typename T>
 __device__ __forceinline__ void su3_mul(const T (&U)[18], const T (&h)[12], T (&g)[12]) {
+  if constexpr (sizeof(T) == 4 && DDAMG_PK) {
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        pkf2 acc = pk_make(0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+          acc = pk_cmac(acc, pk_make(U[2 * (3 * i + j)], U[2 * (3 * i + j) + 1]), pk_make(h[2 * (3 * s + j)], h[2 * (3 * s + j) + 1]));
+        g[2 * (3 * s + i)] = acc.x; g[2 * (3 * s + i) + 1] = acc.y;
+      }
+    return;
+  }
 #pragma unroll
   for (int s = 0; s < 2; s++)
 #pragma unroll
@@ -71,6 +105,19 @@ __device__ __forceinline__ void su3_mul(const T (&U)[18], const T (&h)[12], T (&
 // g = U^dagger h on both spin rows (mvmh)
 template <typename T>
 __device__ __forceinline__ void su3_mul_dag(const T (&U)[18], const T (&h)[12], T (&g)[12]) {
+  if constexpr (sizeof(T) == 4 && DDAMG_PK) {
+#pragma unroll
+    for (int s = 0; s < 2; s++)
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        pkf2 acc = pk_make(0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < 3; j++)
+          acc = pk_cmac_conj(acc, pk_make(U[2 * (3 * j + i)], U[2 * (3 * j + i) + 1]), pk_make(h[2 * (3 * s + j)], h[2 * (3 * s + j) + 1]));
+        g[2 * (3 * s + i)] = acc.x; g[2 * (3 * s + i) + 1] = acc.y;
+      }
+    return;
+  }
 #pragma unroll
   for (int s = 0; s < 2; s++)
 #pragma unroll
@@ -107,6 +154,23 @@ __device__ __forceinline__ void spin_reconstruct_sub(const T (&g)[12], T (&eta)[
 // one Hermitian 6x6 block: 6 real diagonal entries + 15 complex strict-upper entries (row-major)
 template <typename T>
 __device__ __forceinline__ void herm6_mul(const T* __restrict__ c, const T* __restrict__ phi, T* __restrict__ eta) {
+  if constexpr (sizeof(T) == 4 && DDAMG_PK) {
+    pkf2 e[6], f[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) { f[i] = pk_make(phi[2 * i], phi[2 * i + 1]); e[i] = pk_make(c[i], c[i]) * f[i]; }
+    int k = 6;
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+#pragma unroll
+      for (int j = i + 1; j < 6; j++) {
+        const pkf2 a = pk_make(c[k], c[k + 1]); k += 2;
+        e[i] = pk_cmac(e[i], a, f[j]);        // eta_i += a phi_j
+        e[j] = pk_cmac_conj(e[j], a, f[i]);   // eta_j += conj(a) phi_i
+      }
+#pragma unroll
+    for (int i = 0; i < 6; i++) { eta[2 * i] = e[i].x; eta[2 * i + 1] = e[i].y; }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 6; i++) { eta[2 * i] = c[i] * phi[2 * i]; eta[2 * i + 1] = c[i] * phi[2 * i + 1]; }
   int k = 6;

@@ -1,4 +1,7 @@
 // sap.hip -- see sap.h
+// the block solver keeps 144 operator registers per thread resident; packed arithmetic needs aligned register
+// pairs for its temporaries and tips this kernel into heavy spilling, so it stays scalar here
+#define DDAMG_PK 0
 #include "sap.h"
 #include "dirac_device.h"
 #include "blas.h"
