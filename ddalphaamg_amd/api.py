@@ -107,6 +107,7 @@ def load_library():
         "ddamg_hip_coarse_solve": [vp, vp, vp, ctypes.POINTER(ctypes.c_int)],
         "ddamg_hip_vcycle": [vp, vp, vp],
         "ddamg_hip_solve": [vp, dp, dp, ctypes.c_double, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), dp],
+        "ddamg_hip_solve_vec": [vp, vp, vp, ctypes.c_double, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), dp],
         "ddamg_hip_preconditioner": [vp, dp, dp],
         "ddamg_hip_residual_history": [vp, dp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
         "ddamg_hip_get_site_order": [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
@@ -291,6 +292,12 @@ class Context:
         it = ctypes.c_int(0); ci = ctypes.c_int(0); rr = ctypes.c_double(0)
         _check(self._lib.ddamg_hip_solve(self._h, _dp(x), _dp(b), float(tol), ctypes.byref(it), ctypes.byref(ci), ctypes.byref(rr)))
         return x, it.value, ci.value, rr.value
+
+    def solve_vec(self, x, b, tol=0.0):
+        """device-resident solve: x, b fine-level fp64 Vectors; returns (iterations, coarse_iterations, relres)"""
+        it = ctypes.c_int(0); ci = ctypes.c_int(0); rr = ctypes.c_double(0)
+        _check(self._lib.ddamg_hip_solve_vec(self._h, x._h, b._h, float(tol), ctypes.byref(it), ctypes.byref(ci), ctypes.byref(rr)))
+        return it.value, ci.value, rr.value
 
     def preconditioner(self, in_lex):
         a = np.ascontiguousarray(in_lex, dtype=np.float64)

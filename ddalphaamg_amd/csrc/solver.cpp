@@ -285,51 +285,74 @@ int ddamg_hip_vcycle(ddamg_hip_ctx* c, ddamg_hip_vec* phi, const ddamg_hip_vec* 
   DDAMG_API_END
 }
 
-int ddamg_hip_solve(ddamg_hip_ctx* c, double* x_lex, const double* b_lex, double tol, int* iterations, int* coarse_iterations, double* relres) {
-  DDAMG_API_BEGIN
-  DDAMG_REQUIRE(c && x_lex && b_lex, "null argument");
+}  // extern "C"
+
+// the solve proper, on device vectors in the fine fp64 layout: load_b(dst) fills the right-hand side, store_x(src)
+// takes the solution
+template <typename LoadB, typename StoreX>
+static void solve_core(ddamg_hip_ctx* c, double tol, LoadB load_b, StoreX store_x, int* iterations, int* coarse_iterations, double* relres) {
   DDAMG_REQUIRE(c->have_operator, "no operator set");
   DDAMG_REQUIRE(c->par.method == 0 || c->setup_done, "setup has not been run");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
-  const int V = c->levels[0]->geom.V;
-  const size_t nb = sizeof(double) * 24 * V;
-  double* st = c->stage(nb);
-  if (c->par.mixed_precision == 2) {
-    ensure_mp(c);
-    DDAMG_HIP_CHECK(hipMemcpyAsync(st, b_lex, nb, hipMemcpyHostToDevice, c->stream));
-    vec_from_lex<double>(c->mp_b, st, c->levels[0]->d_lex_of_site, V, 12, c->stream);
-    if (c->mg32) c->mg32->coarse_iter_count = 0;
-    double rr = 0;
-    const int it = solve_mp(c, tol > 0 ? tol : c->par.tol, &rr);
-    vec_to_lex<double>(st, c->mp_x, c->levels[0]->d_lex_of_site, V, 12, c->stream);
-    DDAMG_HIP_CHECK(hipMemcpyAsync(x_lex, st, nb, hipMemcpyDeviceToHost, c->stream));
-    DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
-    c->last_iter = it; c->last_coarse_iter = c->mg32 ? c->mg32->coarse_iter_count : 0; c->last_relres = rr;
-    if (iterations) *iterations = it;
-    if (coarse_iterations) *coarse_iterations = c->last_coarse_iter;
-    if (relres) *relres = rr;
-    return 0;
-  }
-  ensure_outer(c);
-  DDAMG_HIP_CHECK(hipMemcpyAsync(st, b_lex, nb, hipMemcpyHostToDevice, c->stream));
-  vec_from_lex<double>(c->outer.b, st, c->levels[0]->d_lex_of_site, V, 12, c->stream);
-  c->outer.tol = tol > 0 ? tol : c->par.tol;
-  c->outer.initial_guess_zero = true;
+  int it; double rr = 0;
   if (c->mg32) c->mg32->coarse_iter_count = 0;
   if (c->mg64) c->mg64->coarse_iter_count = 0;
-  const int it = c->outer.solve();
-  // FGMRES_RESTEST: true residual in the outer precision (src/linsolve_generic.c:351-357)
-  const double rr = c->outer.norm_r0 > 0 ? c->outer.true_residual() : 0.0;
-  vec_to_lex<double>(st, c->outer.x, c->levels[0]->d_lex_of_site, V, 12, c->stream);
-  DDAMG_HIP_CHECK(hipMemcpyAsync(x_lex, st, nb, hipMemcpyDeviceToHost, c->stream));
+  if (c->par.mixed_precision == 2) {
+    ensure_mp(c);
+    load_b(c->mp_b);
+    it = solve_mp(c, tol > 0 ? tol : c->par.tol, &rr);
+    store_x(c->mp_x);
+  } else {
+    ensure_outer(c);
+    load_b(c->outer.b);
+    c->outer.tol = tol > 0 ? tol : c->par.tol;
+    c->outer.initial_guess_zero = true;
+    it = c->outer.solve();
+    // FGMRES_RESTEST: true residual in the outer precision (src/linsolve_generic.c:351-357)
+    rr = c->outer.norm_r0 > 0 ? c->outer.true_residual() : 0.0;
+    store_x(c->outer.x);
+    c->last_history = c->outer.history;
+  }
   DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
   c->last_iter = it;
   c->last_coarse_iter = c->mg32 ? c->mg32->coarse_iter_count : (c->mg64 ? c->mg64->coarse_iter_count : 0);
   c->last_relres = rr;
-  c->last_history = c->outer.history;
   if (iterations) *iterations = it;
   if (coarse_iterations) *coarse_iterations = c->last_coarse_iter;
   if (relres) *relres = rr;
+}
+
+extern "C" {
+
+int ddamg_hip_solve(ddamg_hip_ctx* c, double* x_lex, const double* b_lex, double tol, int* iterations, int* coarse_iterations, double* relres) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && x_lex && b_lex, "null argument");
+  const int V = c->levels[0]->geom.V;
+  const size_t nb = sizeof(double) * 24 * V;
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  double* st = c->stage(nb);
+  solve_core(c, tol,
+             [&](double* dst) {
+               DDAMG_HIP_CHECK(hipMemcpyAsync(st, b_lex, nb, hipMemcpyHostToDevice, c->stream));
+               vec_from_lex<double>(dst, st, c->levels[0]->d_lex_of_site, V, 12, c->stream);
+             },
+             [&](const double* src) {
+               vec_to_lex<double>(st, src, c->levels[0]->d_lex_of_site, V, 12, c->stream);
+               DDAMG_HIP_CHECK(hipMemcpyAsync(x_lex, st, nb, hipMemcpyDeviceToHost, c->stream));
+             },
+             iterations, coarse_iterations, relres);
+  DDAMG_API_END
+}
+
+int ddamg_hip_solve_vec(ddamg_hip_ctx* c, ddamg_hip_vec* x, const ddamg_hip_vec* b, double tol, int* iterations, int* coarse_iterations, double* relres) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && x && b, "null argument");
+  DDAMG_REQUIRE(x->level == 0 && b->level == 0 && x->precision == 64 && b->precision == 64, "solve_vec needs fine-level fp64 vectors");
+  const size_t n = (size_t)24 * c->levels[0]->geom.V;
+  solve_core(c, tol,
+             [&](double* dst) { vec_copy<double>(dst, (const double*)b->data, whole(n), c->stream); },
+             [&](const double* src) { vec_copy<double>((double*)x->data, src, whole(n), c->stream); },
+             iterations, coarse_iterations, relres);
   DDAMG_API_END
 }
 

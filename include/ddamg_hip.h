@@ -139,6 +139,10 @@ int ddamg_hip_vcycle(ddamg_hip_ctx* ctx, ddamg_hip_vec* phi, const ddamg_hip_vec
  * relres = true relative residual ||b - D x|| / ||b|| recomputed in fp64 (FGMRES_RESTEST). */
 int ddamg_hip_solve(ddamg_hip_ctx* ctx, double* x_lex, const double* b_lex, double tol,
                     int* iterations, int* coarse_iterations, double* relres);
+/* the same solve on device-resident vectors (fine level, precision 64, filled with ddamg_hip_vec_upload or by other
+ * device code): nothing crosses PCIe -- the form a GPU-resident host application uses */
+int ddamg_hip_solve_vec(ddamg_hip_ctx* ctx, ddamg_hip_vec* x, const ddamg_hip_vec* b, double tol,
+                        int* iterations, int* coarse_iterations, double* relres);
 /* replaces preconditioner() (src/preconditioner.c:25-69): one V-cycle, fp64 lexicographic in/out */
 int ddamg_hip_preconditioner(ddamg_hip_ctx* ctx, double* out_lex, const double* in_lex);
 /* Arnoldi residual estimates gamma_{j+1}/||r0|| of the last solve (the reference prints them under -DTRACK_RES) */
