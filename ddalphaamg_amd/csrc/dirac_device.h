@@ -55,7 +55,7 @@ __device__ __forceinline__ void spin_project(const T (&phi)[24], T (&h)[12]) {
 // (it packed unrelated scalars and blew up register pressure); here the pairs are the (re,im) parts that sit
 // in neighbouring registers anyway.
 #ifndef DDAMG_PK
-#define DDAMG_PK 1
+#define DDAMG_PK 3   // bit 0: SU(3) products, bit 1: Hermitian 6x6 (clover) products
 #endif
 typedef float pkf2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ pkf2 pk_make(float a, float b) { pkf2 r = {a, b}; return r; }
@@ -73,7 +73,7 @@ __device__ __forceinline__ pkf2 pk_cmac_conj(pkf2 acc, pkf2 a, pkf2 b) {
 // g = U h on both spin rows (mvm) ; U row-major 3x3 complex (18 reals)
 template <typename T>
 __device__ __forceinline__ void su3_mul(const T (&U)[18], const T (&h)[12], T (&g)[12]) {
-  if constexpr (sizeof(T) == 4 && DDAMG_PK) {
+  if constexpr (sizeof(T) == 4 && (DDAMG_PK & 1)) {
 #pragma unroll
     for (int s = 0; s < 2; s++)
 #pragma unroll
@@ -105,7 +105,7 @@ __device__ __forceinline__ void su3_mul(const T (&U)[18], const T (&h)[12], T (&
 // g = U^dagger h on both spin rows (mvmh)
 template <typename T>
 __device__ __forceinline__ void su3_mul_dag(const T (&U)[18], const T (&h)[12], T (&g)[12]) {
-  if constexpr (sizeof(T) == 4 && DDAMG_PK) {
+  if constexpr (sizeof(T) == 4 && (DDAMG_PK & 1)) {
 #pragma unroll
     for (int s = 0; s < 2; s++)
 #pragma unroll
@@ -154,7 +154,7 @@ __device__ __forceinline__ void spin_reconstruct_sub(const T (&g)[12], T (&eta)[
 // one Hermitian 6x6 block: 6 real diagonal entries + 15 complex strict-upper entries (row-major)
 template <typename T>
 __device__ __forceinline__ void herm6_mul(const T* __restrict__ c, const T* __restrict__ phi, T* __restrict__ eta) {
-  if constexpr (sizeof(T) == 4 && DDAMG_PK) {
+  if constexpr (sizeof(T) == 4 && (DDAMG_PK & 2)) {
     pkf2 e[6], f[6];
 #pragma unroll
     for (int i = 0; i < 6; i++) { f[i] = pk_make(phi[2 * i], phi[2 * i + 1]); e[i] = pk_make(c[i], c[i]) * f[i]; }

@@ -275,7 +275,29 @@ void Multigrid<T>::build_coarse_operator(int l) {
   MGLevel<T>& nx = *lv_[l + 1];
   const int N = lv.nvec;
   const double t_start = tick(nullptr, 0);
-  if (l == 0) {
+  static const bool no_batch = getenv("DDAMG_GALERKIN_UNBATCHED") != nullptr;
+  if (l == 0 && !no_batch && Interpolation<T>::restrict_batch_available(lv.fip.agg_sites, N)) {
+    // batched form: D P for a whole batch of columns (5 fields each), then ONE restriction on the matrix cores
+    const size_t ws = (size_t)24 * lv.g->V;             // one fine vector
+    const size_t cs = (size_t)nx.g->V * nx.n * 2;       // one coarse vector
+    size_t free_b = 0, total_b = 0;
+    DDAMG_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+    int batch = 2 * N;
+    while (batch > 1 && (5 * batch > 256 || sizeof(T) * 5 * batch * (ws + cs) > free_b / 2)) batch = (batch + 1) / 2;
+    T *Wb = nullptr, *Cb = nullptr;
+    DDAMG_HIP_CHECK(hipMalloc(&Wb, sizeof(T) * 5 * batch * ws));
+    DDAMG_HIP_CHECK(hipMalloc(&Cb, sizeof(T) * 5 * batch * cs));
+    for (int c0 = 0; c0 < 2 * N; c0 += batch) {
+      const int nb = std::min(batch, 2 * N - c0);
+      for (int c = 0; c < nb; c++)
+        aggregate_dirac<T>(Wb + (size_t)5 * c * ws, lv.fip.interp_vector((c0 + c) % N), (c0 + c) / N, *lv.fop, lv.d_agg_face, st_);
+      lv.fip.restrict_batch(Cb, cs, Wb, ws, 5 * nb, st_);
+      for (int c = 0; c < nb; c++) galerkin_store_column<T>(nx.cop, Cb + (size_t)5 * c * cs, c0 + c, st_);
+    }
+    DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
+    DDAMG_HIP_CHECK(hipFree(Wb));
+    DDAMG_HIP_CHECK(hipFree(Cb));
+  } else if (l == 0) {
     for (int chir = 0; chir < 2; chir++)
       for (int j = 0; j < N; j++) {
         aggregate_dirac<T>(W_, lv.fip.interp_vector(j), chir, *lv.fop, lv.d_agg_face, st_);

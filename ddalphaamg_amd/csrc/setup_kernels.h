@@ -20,4 +20,8 @@ void aggregate_dirac(T* W, const T* v, int chir, const FineOp<T>& op, const unsi
 template <typename T>
 void galerkin_column(CoarseOp<T>& cop, const Interpolation<T>& ip, const T* W, int col, T* work, hipStream_t st);
 
+// the same for five already restricted coarse vectors `work` = [part][Vc][n]
+template <typename T>
+void galerkin_store_column(CoarseOp<T>& cop, const T* work, int col, hipStream_t st);
+
 }  // namespace ddamg

@@ -114,6 +114,16 @@ void galerkin_column(CoarseOp<T>& cop, const Interpolation<T>& ip, const T* W, i
   DDAMG_HIP_CHECK(hipGetLastError());
 }
 
+template <typename T>
+void galerkin_store_column(CoarseOp<T>& cop, const T* work, int col, hipStream_t st) {
+  const int Vc = cop.V(), n = cop.n();
+  const int total = 5 * Vc * n;
+  hipLaunchKernelGGL(store_column_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, st, cop.matrices(), work, Vc, n, cop.nt(), cop.msize(), col);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+template void galerkin_store_column<float>(CoarseOp<float>&, const float*, int, hipStream_t);
+template void galerkin_store_column<double>(CoarseOp<double>&, const double*, int, hipStream_t);
+
 template void aggregate_dirac<float>(float*, const float*, int, const FineOp<float>&, const unsigned char*, hipStream_t);
 template void aggregate_dirac<double>(double*, const double*, int, const FineOp<double>&, const unsigned char*, hipStream_t);
 template void galerkin_column<float>(CoarseOp<float>&, const Interpolation<float>&, const float*, int, float*, hipStream_t);

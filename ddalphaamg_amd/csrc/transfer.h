@@ -33,6 +33,12 @@ struct Interpolation {
   void restrict_to(T* phi_c, const T* phi, hipStream_t st) const;
   // five input vectors at once (the Galerkin construction restricts the self part and the four link parts together)
   void restrict5(T* phi_c, size_t out_stride, const T* phi, size_t in_stride, hipStream_t st) const;
+  // many input vectors at once on the matrix cores (fp32 only): out[w] = P^dagger phi[w], w < nw <= 256.
+  // The Galerkin construction restricts 5 fields for each of the 2*Nvec columns; batched, P is read once per
+  // 256 fields instead of once per 5, and the reduction over the sites of an aggregate is the K dimension of
+  // v_mfma_f32_32x32x2_f32 instead of wavefront shuffles.
+  void restrict_batch(T* phi_c, size_t out_stride, const T* phi, size_t in_stride, int nw, hipStream_t st) const;
+  static bool restrict_batch_available(int agg_sites_, int nvec_) { return sizeof(T) == 4 && agg_sites_ % 16 == 0 && nvec_ <= 32; }
   // phi (+)= P phi_c
   void interpolate(T* phi, const T* phi_c, bool add, hipStream_t st) const;
 };

@@ -109,6 +109,93 @@ void Interpolation<T>::restrict5(T* phi_c, size_t out_stride, const T* phi, size
   DDAMG_HIP_CHECK(hipGetLastError());
 }
 
+// ---- batched restriction on the matrix cores --------------------------------------------------------
+// One workgroup per aggregate, 4 wavefronts.  Per chirality h the restriction is a real GEMM
+//   out_re[i][w] = sum_k A[k][i] B[k][w],   out_im[i][w] = sum_k A'[k][i] B[k][w]
+// with k running over the (re,im)-interleaved reals of the aggregate's sites (K = 12 * agg_sites),
+// A[k][i] = P_i[k], A'[2m] = -P_i[2m+1], A'[2m+1] = P_i[2m]  (the imaginary part of conj(p) f), B[k][w] = phi_w[k].
+// Operands are staged through LDS 16 sites (64 k) at a time; wavefront v owns the 32-column tiles v and v+4.
+// v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; result register r of
+// lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__global__ __launch_bounds__(256, 2) void restrict_mfma_kernel(float* __restrict__ out, size_t out_stride, const float* __restrict__ W, size_t wstride, int nw,
+                                                              const float* __restrict__ P, size_t pstride, int nvec, int V, int agg_sites,
+                                                              const int* __restrict__ agg_csite) {
+  constexpr int KS = 16;            // sites per K block
+  __shared__ float As[4 * KS][33];
+  __shared__ float Bs[4 * KS][257];
+  const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const size_t s0 = (size_t)a * agg_sites;
+  const int ntile = (nw + 31) >> 5;
+  for (int e = tid; e < 4 * KS * 33; e += 256) (&As[0][0])[e] = 0.f;   // rows i >= nvec stay zero
+  for (int h = 0; h < 2; h++) {
+    f32x16 accR[2], accI[2];
+#pragma unroll
+    for (int t = 0; t < 2; t++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) { accR[t][r] = 0.f; accI[t][r] = 0.f; }
+    for (int kk = 3 * h; kk < 3 * h + 3; kk++)
+      for (int sb = 0; sb < agg_sites; sb += KS) {
+        __syncthreads();
+        const size_t row = ((size_t)kk * V + s0 + sb) * 4;
+        for (int e = tid; e < nvec * KS; e += 256) {
+          const int i = e / KS, sl = e % KS;
+          const float4 v = *reinterpret_cast<const float4*>(P + (size_t)i * pstride + row + sl * 4);
+          As[4 * sl][i] = v.x; As[4 * sl + 1][i] = v.y; As[4 * sl + 2][i] = v.z; As[4 * sl + 3][i] = v.w;
+        }
+#pragma unroll 4
+        for (int r = 0; r < 16; r++) {
+          const int e = tid + 256 * r, col = e / KS, sl = e % KS;
+          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (col < nw) v = *reinterpret_cast<const float4*>(W + (size_t)col * wstride + row + sl * 4);
+          Bs[4 * sl][col] = v.x; Bs[4 * sl + 1][col] = v.y; Bs[4 * sl + 2][col] = v.z; Bs[4 * sl + 3][col] = v.w;
+        }
+        __syncthreads();
+#pragma unroll 4
+        for (int kp = 0; kp < 2 * KS; kp++) {
+          const int k = 2 * kp + (lane >> 5);
+          const float aR = As[k][lane & 31];
+          const float aI = (k & 1) ? As[k ^ 1][lane & 31] : -As[k ^ 1][lane & 31];
+#pragma unroll
+          for (int t = 0; t < 2; t++) {
+            const int tile = wv + 4 * t;
+            if (tile < ntile) {
+              const float b = Bs[k][tile * 32 + (lane & 31)];
+              accR[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aR, b, accR[t], 0, 0, 0);
+              accI[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aI, b, accI[t], 0, 0, 0);
+            }
+          }
+        }
+      }
+    const size_t cbase = ((size_t)agg_csite[a] * 2 * nvec + (size_t)h * nvec) * 2;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      const int col = (wv + 4 * t) * 32 + (lane & 31);
+      if (col < nw) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          if (i < nvec) {
+            float2 v; v.x = accR[t][r]; v.y = accI[t][r];
+            *reinterpret_cast<float2*>(out + (size_t)col * out_stride + cbase + 2 * i) = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <typename T>
+void Interpolation<T>::restrict_batch(T* phi_c, size_t out_stride, const T* phi, size_t in_stride, int nw, hipStream_t st) const {
+  if constexpr (sizeof(T) == 4) {
+    DDAMG_REQUIRE(restrict_batch_available(agg_sites, nvec) && nw >= 1 && nw <= 256, "batched restriction: unsupported shape");
+    hipLaunchKernelGGL(restrict_mfma_kernel, dim3(num_aggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite);
+    DDAMG_HIP_CHECK(hipGetLastError());
+  } else {
+    DDAMG_REQUIRE(false, "batched restriction is an fp32 path");
+  }
+}
+
 // ---- interpolation: phi(x,d) (+)= sum_j P_j(x,d) phi_c[a][h(d)*N + j] -------------------------------
 template <typename T>
 __global__ void interpolate_kernel(T* __restrict__ phi, const T* __restrict__ phi_c, const T* __restrict__ P, size_t pstride,
