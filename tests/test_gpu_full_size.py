@@ -1,0 +1,101 @@
+"""GPU tests at BASELINE.json's full single-GPU size (32^4, configs[2]): the oracle cannot run a solve at this
+volume in test time, so parity is checked through size-independent properties of the domain --
+linearity and gamma5-hermiticity of the operator, the Galerkin identity P^H D P = D_c and P^H P = 1 on the
+hierarchy built by the batched (matrix-core) setup, monotone smoother convergence, and the true residual and
+iteration count of the FGMRES+AMG solve through both the host-vector and the device-vector entry points."""
+import os, sys
+import numpy as np
+import pytest
+from conftest import relerr, splitmix_uniform
+from ddalphaamg_amd import api
+import ddalphaamg_amd as dd
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+pytestmark = pytest.mark.gpu
+
+L = [32, 32, 32, 32]
+V = 32 ** 4
+
+
+@pytest.fixture(scope="module")
+def ctx32():
+    from bench import near_unit_gauge
+    p = api.default_params(); p.num_levels = 2
+    for mu in range(4):
+        p.local_lattice[0][mu] = 32; p.block_lattice[0][mu] = 4; p.local_lattice[1][mu] = 8
+    p.num_vect[0] = 24; p.post_smooth_iter[0] = 2; p.block_iter[0] = 4; p.setup_iter[0] = 3
+    p.restart, p.max_restart, p.tol = 50, 20, 1e-10
+    p.coarse_iter, p.coarse_restart, p.coarse_tol = 100, 5, 5e-2
+    p.mixed_precision, p.method, p.odd_even = 1, 2, 1
+    p.m0, p.csw = -0.3, 1.0
+    p.test_vector_rng, p.rng_seed = 1, 7
+    ctx = dd.Context(p)
+    ctx.set_gauge(near_unit_gauge(V, 0.35, 11), anti_pbc=True)
+    ctx.setup(3)
+    yield ctx
+    ctx.close()
+
+
+def cx(a):
+    return a[..., 0] + 1j * a[..., 1]
+
+
+def test_operator_properties(ctx32):
+    x = splitmix_uniform(V * 24, 21).reshape(V, 12, 2)
+    y = splitmix_uniform(V * 24, 22).reshape(V, 12, 2)
+    g5 = np.array([-1] * 6 + [1] * 6, dtype=np.float64)[None, :, None]
+
+    def D(v, prec=64):
+        a = ctx32.vector(0, prec).upload(v); b = ctx32.vector(0, prec)
+        ctx32.dirac_apply(b, a); out = b.download(); a.free(); b.free(); return out
+    Dx, Dy = D(x), D(y)
+    assert relerr(D(2.0 * x - 3.0 * y), 2.0 * Dx - 3.0 * Dy) < 1e-13
+    lhs = np.vdot(cx(y), cx(Dx)); rhs = np.vdot(cx(g5 * D(g5 * y)), cx(x))
+    assert abs(lhs - rhs) / abs(lhs) < 1e-12
+    assert relerr(D(x, 32), Dx) < 2e-6
+
+
+def test_galerkin_identity_and_orthonormality(ctx32):
+    """restrict(D interpolate(e)) == D_c e and restrict(interpolate(e)) == e for a random coarse vector"""
+    n = 48; Vc = 8 ** 4
+    e = splitmix_uniform(Vc * n * 2, 5).reshape(Vc, n, 2)
+    ec = ctx32.vector(1, 32).upload(e)
+    f = ctx32.vector(0, 32); Df = ctx32.vector(0, 32); r = ctx32.vector(1, 32); Dce = ctx32.vector(1, 32)
+    ctx32.interpolate(f, ec, add=False)
+    ctx32.restrict(r, f)
+    assert relerr(r.download(), e) < 5e-6
+    ctx32.dirac_apply(Df, f)
+    ctx32.restrict(r, Df)
+    ctx32.coarse_apply(Dce, ec)
+    assert relerr(r.download(), Dce.download()) < 2e-5
+    for v in (ec, f, Df, r, Dce):
+        v.free()
+
+
+def test_smoother_converges(ctx32):
+    eta = splitmix_uniform(V * 24, 9).reshape(V, 12, 2)
+    e = ctx32.vector(0, 32).upload(eta); phi = ctx32.vector(0, 32); Dphi = ctx32.vector(0, 32)
+    res = []
+    for cycles in (1, 2, 4):
+        ctx32.smoother(phi, e, cycles, initial_guess_zero=True)
+        ctx32.dirac_apply(Dphi, phi)
+        res.append(np.linalg.norm(eta - Dphi.download()) / np.linalg.norm(eta))
+    assert res[0] < 0.7 and res[1] < res[0] and res[2] < res[1]
+    for v in (e, phi, Dphi):
+        v.free()
+
+
+def test_solve_host_and_device_vectors(ctx32):
+    b = np.zeros((V, 12, 2)); b[..., 0] = 1.0
+    x, it, cit, rr = ctx32.solve(b, 1e-10)
+    assert rr < 1e-10 and 8 <= it <= 16
+    # the returned relative residual is the true one: recompute it with the fp64 operator
+    xv = ctx32.vector(0, 64).upload(x); Dx = ctx32.vector(0, 64)
+    ctx32.dirac_apply(Dx, xv)
+    assert abs(np.linalg.norm(b - Dx.download()) / np.linalg.norm(b) - rr) < 1e-12
+    bv = ctx32.vector(0, 64).upload(b); yv = ctx32.vector(0, 64)
+    it2, cit2, rr2 = ctx32.solve_vec(yv, bv, 1e-10)
+    assert (it2, cit2) == (it, cit) and rr2 == rr
+    assert np.array_equal(yv.download(), x)
+    for v in (xv, Dx, bv, yv):
+        v.free()
