@@ -30,7 +30,7 @@ d0 block iter: 4
 d0 test vectors: {nvec}
 d0 setup iter: {setup}
 {extra}
-m0: -0.5
+m0: {m0}
 csw: 1.0
 tolerance for relative residual: 1E-10
 iterations between restarts: 50
@@ -60,6 +60,10 @@ CASES = {
     # mixed precision 2 (fgmres_MP): AMG-preconditioned on 4^4 and pure GMRES(50) on 8^4 (383 iterations)
     "4x4_mp2": dict(conf="conf/4x4x4x4b6.0000id3n1", levels=2, L="4 4 4 4", B="2 2 2 2", nvec=20, setup=4, extra="", method=2, mp=2,
                     keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),
+    # four different extents everywhere: lattice 8x4x4x8 (T,Z,Y,X), Schwarz blocks 4x2x2x2, aggregates 4x2x2x4
+    # (coarse lattice 2x2x2x2), seeded random SU(3) links, m0 = 0.3
+    "ragged": dict(conf="", synthetic=4711, levels=2, L="8 4 4 8", B="4 2 2 2", nvec=12, setup=2, m0=0.3,
+                   extra="d1 global lattice: 2 2 2 2\nd1 local lattice: 2 2 2 2", method=2, mp=1),
     "8x8_gmres_mp2": dict(conf="conf/8x8x8x8b6.0000id3n1", levels=1, L="8 8 8 8", B="2 2 2 2", nvec=4, setup=0, extra="", method=0, mp=2,
                           keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),
 }
@@ -67,13 +71,27 @@ CASES = {
 def run_case(name):
     cfg = dict(CASES[name])
     keep = cfg.pop("keep", None)
-    cfg["conf"] = os.path.join(REF, cfg["conf"])
+    cfg.setdefault("m0", -0.5)
+    synthetic = cfg.pop("synthetic", None)
     tmp = tempfile.mkdtemp(prefix="ddamg_gold_")
+    if synthetic is None:
+        cfg["conf"] = os.path.join(REF, cfg["conf"])
+    else:
+        # a gauge file in the reference's format (src/io.c:489-520) with seeded random SU(3) links: exercises
+        # lattices and blocks with four different extents, which the reference's sample configurations do not
+        sys.path.insert(0, os.path.join(REPO, "tests"))
+        from conftest import random_su3
+        Ls = [int(x) for x in cfg["L"].split()]
+        U = random_su3(int(np.prod(Ls)) * 4, synthetic)
+        cfg["conf"] = os.path.join(tmp, "synthetic.conf")
+        with open(cfg["conf"], "wb") as f:
+            f.write(np.asarray(Ls, dtype="<i4").tobytes()); f.write(np.asarray([0.0], dtype="<f8").tobytes())
+            f.write(np.ascontiguousarray(U, dtype="<f8").tobytes())
     try:
         ini = os.path.join(tmp, "case.ini")
         open(ini, "w").write(INI_COMMON.format(**cfg))
         log = subprocess.run([os.path.join(HERE, "_ref", "ref_dump"), ini, tmp], capture_output=True, text=True)
-        if log.returncode != 0:
+        if log.returncode != 0 or not os.path.exists(os.path.join(tmp, "manifest.txt")):   # error0 aborts with exit code 0
             sys.stderr.write(log.stdout[-3000:] + log.stderr[-3000:])
             raise SystemExit("ref_dump failed")
         arrays = {}

@@ -16,6 +16,7 @@ static void dump_fine_operator(level_struct *l, struct Thread *threading)
   int meta[16] = {0};
   for (int mu = 0; mu < 4; mu++) { meta[mu] = l->local_lattice[mu]; meta[4 + mu] = l->block_lattice[mu]; }
   meta[8] = g.num_levels; meta[9] = l->num_eig_vect; meta[10] = g.anti_pbc;
+  if (l->next_level) for (int mu = 0; mu < 4; mu++) meta[11 + mu] = l->next_level->local_lattice[mu];   /* coarse lattice */
   shape1(sh, 16); dump("meta_int", "i4", meta, sizeof meta, sh);
   double metad[8] = { creal(l->dirac_shift), g.csw, g.plaq, g.plaq_hopp, g.tol, g.coarse_tol, 0, 0 };
   shape1(sh, 8); dump("meta_f64", "f8", metad, sizeof metad, sh);
