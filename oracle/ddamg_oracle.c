@@ -126,6 +126,10 @@ double orc_gauge_to_operator(const int L[4], const double *gauge, int anti_pbc, 
   return plaq / ((double)V * 6.0);
 }
 
+/* OpenMP threads used by every entry point below (the default, one per visible core, is far too many for the small
+ * lattices of the parity tests on a many-core host) */
+void orc_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
+
 void orc_dirac_apply_f64(const int L[4], const double *D, const double *clover, const double *phi, double *eta)
 {
   dirac_apply_core_f64(L, (const double complex *)D, (const double complex *)clover, (const double complex *)phi, (double complex *)eta);

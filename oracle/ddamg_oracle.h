@@ -34,4 +34,6 @@ double orc_dirac_time_f32(const int L[4], const double *D, const double *clover,
 #ifdef __cplusplus
 }
 #endif
+void orc_set_threads(int n);
+
 #endif

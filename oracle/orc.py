@@ -25,6 +25,9 @@ def lib():
         for f in (_lib.orc_dirac_apply_f64, _lib.orc_dirac_apply_f32):
             f.restype = None
             f.argtypes = [ip, dp, dp, dp, dp]
+        _lib.orc_set_threads.restype = None
+        _lib.orc_set_threads.argtypes = [ctypes.c_int]
+        _lib.orc_set_threads(host_threads())   # never more than this box's CPU share
         _lib.orc_dirac_time_f32.restype = ctypes.c_double
         _lib.orc_dirac_time_f32.argtypes = [ip, dp, dp, dp, ctypes.c_int, ip]
     return _lib
@@ -50,6 +53,10 @@ def dirac_apply(L, D, clover, phi, precision=64):
     f = lib().orc_dirac_apply_f64 if precision == 64 else lib().orc_dirac_apply_f32
     f(_L(L), _dp(D), _dp(clover), _dp(phi), _dp(eta))
     return eta
+
+def set_threads(n):
+    lib().orc_set_threads(int(n))
+
 
 def host_threads():
     """threads to use on this box: its CPU share (16 per GPU on the pool), never the raw core count"""

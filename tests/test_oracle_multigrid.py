@@ -1,0 +1,79 @@
+"""CPU tests (-m "not gpu"): pin the numpy/scipy restatement of the multigrid path (oracle/mg_oracle.py) against the
+dumps of the real reference (tests/golden/ref_4x4.npz and the non-cubic ref_ragged.npz) -- restriction,
+interpolation, coarse operator, Galerkin identity, Schwarz smoother with and without initial guess, coarsest-level
+odd-even solve, V-cycle, and the iteration count of the full FGMRES+AMG solve.  The reference's V-cycle runs in fp32,
+the restatement in fp64: tolerances are fp32-sized."""
+import numpy as np
+import pytest
+from conftest import relerr, load_golden
+from oracle import mg_oracle as mo
+
+
+@pytest.fixture(scope="module", params=["ref_4x4.npz", "ref_ragged.npz"], ids=["4x4", "ragged"])
+def hier(request):
+    g = load_golden(request.param)
+    L = [int(x) for x in g["meta_int"][:4]]
+    B = [int(x) for x in g["meta_int"][4:8]]
+    Lc = [int(x) or L[mu] // 2 for mu, x in enumerate(g["meta_int"][11:15])]
+    tl = mo.TwoLevel(L, Lc, B, g["D"], g["clover"], g["interp_vectors"], g["coarse_D"], g["coarse_clover"])
+    return g, tl
+
+
+def vec(a):
+    return mo.cplx(np.asarray(a, dtype=np.float64)).ravel()
+
+
+def test_fine_matrix_is_the_oracle_operator(hier):
+    g, tl = hier
+    assert relerr(mo.reim(tl.A @ vec(g["dirac_in"])), np.asarray(g["dirac_out_f64"]).reshape(-1, 2)) < 1e-13
+
+
+def test_restrict_interpolate(hier):
+    g, tl = hier
+    assert relerr(mo.reim(tl.restrict(vec(g["restrict_in"]))), np.asarray(g["restrict_out"]).reshape(-1, 2)) < 2e-6
+    assert relerr(mo.reim(tl.interpolate(vec(g["interpolate_in"]))), np.asarray(g["interpolate_out"]).reshape(-1, 2)) < 2e-6
+    # P^H P = 1 (aggregate-wise orthonormal vectors)
+    PhP = (tl.P.conj().T @ tl.P).toarray()
+    assert np.abs(PhP - np.eye(PhP.shape[0])).max() < 5e-6
+
+
+def test_coarse_operator(hier):
+    g, tl = hier
+    assert relerr(mo.reim(tl.Mc @ vec(g["coarse_apply_in"])), np.asarray(g["coarse_apply_out"]).reshape(-1, 2)) < 2e-6
+    # Galerkin: the reference's coarse operator is P^H D P of its own interpolation (built in fp32)
+    G = (tl.P.conj().T @ tl.A @ tl.P).toarray()
+    assert np.abs(G - tl.Mc.toarray()).max() / np.abs(G).max() < 2e-5
+
+
+@pytest.mark.parametrize("cycles", [1, 2, 3])
+def test_schwarz_from_zero(hier, cycles):
+    g, tl = hier
+    out = tl.sap.smooth(vec(g["smoother_eta"]), cycles)
+    assert relerr(mo.reim(out), np.asarray(g[f"smoother_nores_out_c{cycles}"]).reshape(-1, 2)) < 5e-5
+
+
+def test_schwarz_with_initial_guess(hier):
+    g, tl = hier
+    out = tl.sap.smooth(vec(g["smoother_eta"]), 2, phi0=vec(g["smoother_phi0"]))
+    assert relerr(mo.reim(out), np.asarray(g["smoother_res_out_c2"]).reshape(-1, 2)) < 5e-5
+
+
+def test_coarse_solve(hier):
+    g, tl = hier
+    x, it = mo.coarse_solve(tl.Mc, tl.Lc, tl.n, vec(g["coarse_solve_in"]), 5e-2, 100, 5)
+    assert abs(it - int(g["coarse_solve_iters"][0])) <= 1
+    assert relerr(mo.reim(x), np.asarray(g["coarse_solve_out"]).reshape(-1, 2)) < 2e-4
+
+
+def test_vcycle(hier):
+    g, tl = hier
+    out = tl.vcycle(vec(g["vcycle_eta"]))
+    assert relerr(mo.reim(out), np.asarray(g["vcycle_out"]).reshape(-1, 2)) < 2e-4
+
+
+def test_solve_iteration_count(hier):
+    g, tl = hier
+    x, it, hist = tl.solve(vec(g["solve_rhs"]), 1e-10)
+    assert it == int(g["solve_iters"][0])
+    assert abs(tl.coarse_its - int(g["solve_iters"][1])) <= 3
+    assert relerr(mo.reim(x), np.asarray(g["solve_x"]).reshape(-1, 2)) < 1e-8
