@@ -13,7 +13,7 @@ L = [int(x) for x in (sys.argv[1:5] if len(sys.argv) > 4 else [32, 32, 32, 32])]
 V = int(np.prod(L))
 U = near_unit_gauge(V, 0.35, 1)
 eta_h = splitmix_uniform(V * 24, 3).reshape(V, 12, 2)
-for bi in (0, 1, 2, 4, 8):
+for bi in ([int(x) for x in os.environ['SAP_BENCH_ITERS'].split(',')] if 'SAP_BENCH_ITERS' in os.environ else (0, 1, 2, 4, 8)):
     p = api.default_params(); p.num_levels = 2
     for mu in range(4):
         p.local_lattice[0][mu] = L[mu]; p.block_lattice[0][mu] = 4; p.local_lattice[1][mu] = L[mu] // 4
