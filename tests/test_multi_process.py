@@ -93,3 +93,19 @@ def test_sample_configuration_on_two_processes_vs_reference_on_two_ranks():
     11 iterations, 1.55e-11; the decomposed GPU run must give the same count (+-1) and convergence curve"""
     out = launch(2, "--mode", "sample_np2", "--grid", "2,1,1,1", "--tol", "1", timeout=600)
     assert "sample.ini on 2 processes: 11 iterations" in out or "sample.ini on 2 processes: 1" in out
+
+
+MPIEXEC = "/opt/conda/bin/mpiexec"
+MPI_DRIVER = os.path.join(HERE, "mpi", "mpi_driver")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,grid", [(2, "2 1 1 1"), (4, "1 2 1 2")])
+def test_c_host_program_over_mpi(nproc, grid):
+    """tests/mpi/mpi_driver.c: an MPI host program written against include/ddamg_hip.h + ddamg_hip_mpi.h (what a
+    maintainer of the reference's main.c would write): decomposed operator and two-level solve against the undivided
+    run, host transport over MPI (MPICH from the image; all ranks share the one test GPU)"""
+    if not (os.path.exists(MPIEXEC) and os.path.exists(MPI_DRIVER)):
+        pytest.skip("no MPI in this image / driver not built (make -C ddalphaamg_amd/csrc mpi)")
+    r = subprocess.run([MPIEXEC, "-n", str(nproc), MPI_DRIVER, *grid.split()], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "MPI_DRIVER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
