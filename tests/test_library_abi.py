@@ -55,3 +55,35 @@ def test_create_without_gpu_fails_loudly():
         p.local_lattice[0][mu] = 4
     with pytest.raises(dd.DDAMGError):
         dd.Context(p)
+
+
+def test_params_struct_matches_header():
+    """the ctypes mirror of ddamg_hip_params has one field per member of the C struct, in order, and the defaults for
+    the members added after the reference's own parameters are neutral (single process, reference random numbers)"""
+    import re
+    from ddalphaamg_amd import api
+    hdr = open(os.path.join(os.path.dirname(dd.library_path()), "..", "include", "ddamg_hip.h")).read()
+    body = re.search(r"typedef struct ddamg_hip_params \{(.*?)\} ddamg_hip_params;", hdr, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        for part in decl.split(","):
+            names.append(re.findall(r"([A-Za-z_][A-Za-z_0-9]*)\s*(?:\[[^\]]*\])*\s*$", part.strip())[0])
+    assert names == [f[0] for f in api.Params._fields_]
+    p = api.default_params()
+    assert list(p.process_grid) == [1, 1, 1, 1] and list(p.process_coords) == [0, 0, 0, 0]
+    assert p.test_vector_rng == 0
+
+
+def test_mpi_glue_library_exports_its_symbol():
+    path = os.path.join(os.path.dirname(dd.library_path()), "libddamg_hip_mpi.so")
+    if not os.path.exists(path):
+        pytest.skip("libddamg_hip_mpi.so not built (no MPI in this image)")
+    hdr = open(os.path.join(os.path.dirname(dd.library_path()), "..", "include", "ddamg_hip_mpi.h")).read()
+    assert "ddamg_hip_comm_init_mpi" in hdr
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+    assert " T ddamg_hip_comm_init_mpi" in out
