@@ -141,11 +141,16 @@ int ddamg_hip_set_gauge(ddamg_hip_ctx* c, const double* gauge_lex, int anti_pbc,
   DDAMG_REQUIRE(c && gauge_lex, "null argument");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
   const Geometry& g = c->levels[0]->geom;
-  DDAMG_REQUIRE(!g.distributed(), "set_gauge needs the links of neighbouring processes for the clover term: with a process grid, "
-                                  "build the operator globally and hand each process its part through ddamg_hip_set_operator");
   c->D_host.resize((size_t)g.V * 72);
   c->clover_host.resize((size_t)g.V * 84);
-  double pl = gauge_to_operator(g.L, gauge_lex, anti_pbc, c->par.m0, c->par.csw, c->D_host.data(), c->clover_host.data());
+  double pl;
+  if (g.distributed()) {
+    DDAMG_REQUIRE(c->comm != nullptr, "set_gauge on a process grid fetches the neighbours' links: install a transport first "
+                                      "(ddamg_hip_comm_init_rccl / ddamg_hip_comm_init_host / ddamg_hip_comm_init_mpi)");
+    pl = gauge_to_operator_dist(g, c->comm, gauge_lex, anti_pbc, c->par.m0, c->par.csw, c->D_host.data(), c->clover_host.data());
+  } else {
+    pl = gauge_to_operator(g.L, gauge_lex, anti_pbc, c->par.m0, c->par.csw, c->D_host.data(), c->clover_host.data());
+  }
   if (plaquette) *plaquette = pl;
   upload_operator(c);
   DDAMG_API_END

@@ -5,7 +5,10 @@
 // lexicographic sites) so it can be compared one-to-one with g.op_double.
 #include "gauge.h"
 #include "common.h"
+#include "geometry.h"
+#include "halo.h"
 #include <complex>
+#include <cstring>
 #include <thread>
 #include <vector>
 #include <algorithm>
@@ -31,25 +34,32 @@ static inline M3 dag(const M3& x) {
 }
 
 namespace {
+// links on the local lattice, extended by a halo of depth h[mu] (0: the direction wraps periodically inside the
+// process, 1: coordinates -1 .. L[mu] are valid and hold the neighbouring processes' links)
 struct Field {
-  const double* U; int L[4];
-  inline int lex(int t, int z, int y, int x) const { return ((t * L[1] + z) * L[2] + y) * L[3] + x; }
+  const double* U; int L[4]; int h[4] = {0, 0, 0, 0};
+  inline size_t lex(const int c[4]) const {
+    size_t i = 0;
+    for (int mu = 0; mu < 4; mu++) i = i * (L[mu] + 2 * h[mu]) + (c[mu] + h[mu]);
+    return i;
+  }
   inline M3 link(const int c[4], int mu) const {
-    M3 m; const double* p = U + ((size_t)lex(c[0], c[1], c[2], c[3]) * 4 + mu) * 18;
+    M3 m; const double* p = U + (lex(c) * 4 + mu) * 18;
     for (int i = 0; i < 9; i++) m.a[i] = cd(p[2 * i], p[2 * i + 1]);
     return m;
   }
+  inline void shift(const int c[4], int mu, int d, int out[4]) const {
+    for (int i = 0; i < 4; i++) out[i] = c[i];
+    out[mu] = h[mu] ? c[mu] + d : (c[mu] + d + L[mu]) % L[mu];
+  }
 };
-inline void shift(const int L[4], const int c[4], int mu, int d, int out[4]) {
-  for (int i = 0; i < 4; i++) out[i] = c[i];
-  out[mu] = (c[mu] + d + L[mu]) % L[mu];
-}
+inline void shift(const Field& f, const int c[4], int mu, int d, int out[4]) { f.shift(c, mu, d, out); }
 // sum of the four plaquette leaves in the (mu,nu) plane at x, divided by 16 (src/dirac.c:304-358)
 M3 leaves(const Field& f, const int x[4], int mu, int nu) {
   int xpm[4], xpn[4], xmm[4], xmn[4], xpnmm[4], xmmmn[4], xmnpm[4];
-  shift(f.L, x, mu, +1, xpm); shift(f.L, x, nu, +1, xpn);
-  shift(f.L, x, mu, -1, xmm); shift(f.L, x, nu, -1, xmn);
-  shift(f.L, xpn, mu, -1, xpnmm); shift(f.L, xmm, nu, -1, xmmmn); shift(f.L, xmn, mu, +1, xmnpm);
+  shift(f, x, mu, +1, xpm); shift(f, x, nu, +1, xpn);
+  shift(f, x, mu, -1, xmm); shift(f, x, nu, -1, xmn);
+  shift(f, xpn, mu, -1, xpnmm); shift(f, xmm, nu, -1, xmmmn); shift(f, xmn, mu, +1, xmnpm);
   M3 q1 = mul(mul(mul(f.link(x, mu), f.link(xpm, nu)), dag(f.link(xpn, mu))), dag(f.link(x, nu)));
   M3 q2 = mul(mul(mul(f.link(x, nu), dag(f.link(xpnmm, mu))), dag(f.link(xmm, nu))), f.link(xmm, mu));
   M3 q3 = mul(mul(mul(dag(f.link(xmm, mu)), dag(f.link(xmmmn, nu))), f.link(xmmmn, mu)), f.link(xmn, nu));
@@ -77,20 +87,10 @@ void parallel_for(int n, F fn) {
 }
 }  // namespace
 
-double gauge_to_operator(const int L[4], const double* gauge_in, int anti_pbc, double m0, double csw,
-                         double* D_out, double* clover_out) {
+// clover term and plaquette sum of every site of the local lattice from the (possibly halo-extended) field f
+static double clover_and_plaquette(const Field& f, double m0, double csw, double* clover_out) {
+  const int* L = f.L;
   const int V = L[0] * L[1] * L[2] * L[3];
-  std::vector<double> U(gauge_in, gauge_in + (size_t)V * 72);
-  if (anti_pbc) {
-    const int vol3 = L[1] * L[2] * L[3];
-    for (int i = 0; i < vol3; i++) {
-      double* p = U.data() + ((size_t)((L[0] - 1) * vol3 + i) * 4 + DIR_T) * 18;
-      for (int k = 0; k < 18; k++) p[k] = -p[k];
-    }
-  }
-  for (size_t i = 0; i < (size_t)V * 72; i++) D_out[i] = 0.5 * U[i];
-
-  Field f; f.U = U.data(); for (int i = 0; i < 4; i++) f.L[i] = L[i];
   cd gam[4][16];
   for (int mu = 0; mu < 4; mu++) gamma_dense(mu, gam[mu]);
   cd gg[4][4][16];
@@ -112,7 +112,7 @@ double gauge_to_operator(const int L[4], const double* gauge_in, int anti_pbc, d
       for (int nu = mu + 1; nu < 4; nu++) {
         // plaquette (src/dirac.c:589-604)
         int xpm[4], xpn[4];
-        shift(L, x, mu, +1, xpm); shift(L, x, nu, +1, xpn);
+        shift(f, x, mu, +1, xpm); shift(f, x, nu, +1, xpn);
         M3 p = mul(mul(mul(f.link(x, mu), f.link(xpm, nu)), dag(f.link(xpn, mu))), dag(f.link(x, nu)));
         pl += (p.a[0] + p.a[4] + p.a[8]).real();
         if (csw != 0.0) {
@@ -131,13 +131,79 @@ double gauge_to_operator(const int L[4], const double* gauge_in, int anti_pbc, d
       }
     plaq_part[lx] = pl;
   });
-  if (csw == 0.0) {
-    // the reference then keeps only a 12-entry diagonal per site (src/dirac.c:55-57); we keep the
-    // 42-entry form with zero off-diagonals so one code path serves both cases
-  }
+  // csw == 0: the reference keeps only a 12-entry diagonal per site (src/dirac.c:55-57); we keep the 42-entry form
+  // with zero off-diagonals so one code path serves both cases
   double plaq = 0;
   for (int i = 0; i < V; i++) plaq += plaq_part[i];
-  return plaq / ((double)V * 6.0);
+  return plaq;
+}
+
+double gauge_to_operator(const int L[4], const double* gauge_in, int anti_pbc, double m0, double csw,
+                         double* D_out, double* clover_out) {
+  const int V = L[0] * L[1] * L[2] * L[3];
+  std::vector<double> U(gauge_in, gauge_in + (size_t)V * 72);
+  if (anti_pbc) {
+    const int vol3 = L[1] * L[2] * L[3];
+    for (int i = 0; i < vol3; i++) {
+      double* p = U.data() + ((size_t)((L[0] - 1) * vol3 + i) * 4 + DIR_T) * 18;
+      for (int k = 0; k < 18; k++) p[k] = -p[k];
+    }
+  }
+  for (size_t i = 0; i < (size_t)V * 72; i++) D_out[i] = 0.5 * U[i];
+  Field f; f.U = U.data(); for (int i = 0; i < 4; i++) f.L[i] = L[i];
+  return clover_and_plaquette(f, m0, csw, clover_out) / ((double)V * 6.0);
+}
+
+double gauge_to_operator_dist(const Geometry& g, Comm* comm, const double* gauge_in, int anti_pbc, double m0, double csw,
+                              double* D_out, double* clover_out) {
+  const int* L = g.L;
+  const int V = g.V;
+  Field f; for (int i = 0; i < 4; i++) { f.L[i] = L[i]; f.h[i] = g.P[i] > 1 ? 1 : 0; }
+  int E[4]; size_t Ve = 1;
+  for (int mu = 0; mu < 4; mu++) { E[mu] = L[mu] + 2 * f.h[mu]; Ve *= E[mu]; }
+  std::vector<double> Ue(Ve * 72, 0.0);
+  // my own links into the interior of the extended field; anti-periodic sign on the last global time slice
+  for (int lx = 0; lx < V; lx++) {
+    int x[4]; int r = lx;
+    x[3] = r % L[3]; r /= L[3]; x[2] = r % L[2]; r /= L[2]; x[1] = r % L[1]; r /= L[1]; x[0] = r;
+    double* dst = Ue.data() + f.lex(x) * 72;
+    const double* src = gauge_in + (size_t)lx * 72;
+    for (int k = 0; k < 72; k++) dst[k] = src[k];
+    if (anti_pbc && g.pc[0] == g.P[0] - 1 && x[0] == L[0] - 1)
+      for (int k = 0; k < 18; k++) dst[DIR_T * 18 + k] = -dst[DIR_T * 18 + k];
+    for (int k = 0; k < 72; k++) D_out[(size_t)lx * 72 + k] = 0.5 * dst[k];
+  }
+  // halo, one direction after the other so that the corners travel along (a slab spans the full extended range of
+  // the other directions, including the halos received before)
+  for (int mu = 0; mu < 4; mu++) {
+    if (!f.h[mu]) continue;
+    size_t slab = Ve / E[mu];
+    std::vector<double> sbuf(slab * 72), rbuf(slab * 72);
+    for (int side = 0; side < 2; side++) {
+      // side 0: my slice x_mu = L-1 goes to the +mu neighbour (its x_mu = -1); side 1: x_mu = 0 to the -mu neighbour (its x_mu = L)
+      const int src_c = side == 0 ? L[mu] - 1 : 0, dst_c = side == 0 ? -1 : L[mu];
+      size_t k = 0;
+      int c[4];
+      for (c[0] = -f.h[0]; c[0] < L[0] + f.h[0]; c[0]++) for (c[1] = -f.h[1]; c[1] < L[1] + f.h[1]; c[1]++)
+      for (c[2] = -f.h[2]; c[2] < L[2] + f.h[2]; c[2]++) for (c[3] = -f.h[3]; c[3] < L[3] + f.h[3]; c[3]++) {
+        if (c[mu] != src_c) continue;
+        memcpy(sbuf.data() + k * 72, Ue.data() + f.lex(c) * 72, sizeof(double) * 72); k++;
+      }
+      comm_sendrecv_host(comm, sbuf.data(), g.neighbor_rank[side == 0 ? mu : 4 + mu], rbuf.data(), g.neighbor_rank[side == 0 ? 4 + mu : mu],
+                         sizeof(double) * slab * 72, 100 + 2 * mu + side);
+      k = 0;
+      for (c[0] = -f.h[0]; c[0] < L[0] + f.h[0]; c[0]++) for (c[1] = -f.h[1]; c[1] < L[1] + f.h[1]; c[1]++)
+      for (c[2] = -f.h[2]; c[2] < L[2] + f.h[2]; c[2]++) for (c[3] = -f.h[3]; c[3] < L[3] + f.h[3]; c[3]++) {
+        if (c[mu] != src_c) continue;
+        int d[4] = {c[0], c[1], c[2], c[3]}; d[mu] = dst_c;
+        memcpy(Ue.data() + f.lex(d) * 72, rbuf.data() + k * 72, sizeof(double) * 72); k++;
+      }
+    }
+  }
+  f.U = Ue.data();
+  double acc[2] = {clover_and_plaquette(f, m0, csw, clover_out), (double)V * 6.0};
+  comm_allreduce_host(comm, acc, 2);
+  return acc[0] / acc[1];
 }
 
 }  // namespace ddamg

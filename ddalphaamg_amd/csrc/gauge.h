@@ -6,4 +6,11 @@ namespace ddamg {
 // storage; returns the average plaquette in [0,3].
 double gauge_to_operator(const int L[4], const double* gauge_in, int anti_pbc, double m0, double csw,
                          double* D_out, double* clover_out);
+// the same on a process grid: gauge_in is the process's own part; the links of the neighbouring processes that the
+// clover leaves reach (one site deep, corners included) are fetched first (the reference exchanges the ghost shell of
+// the gauge field in dirac_setup, src/dirac.c:88-120); the plaquette is the global average
+struct Geometry;
+struct Comm;
+double gauge_to_operator_dist(const Geometry& g, Comm* comm, const double* gauge_in, int anti_pbc, double m0, double csw,
+                              double* D_out, double* clover_out);
 }

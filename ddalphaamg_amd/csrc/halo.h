@@ -28,6 +28,9 @@ Comm* comm_create_rccl(const Geometry& g, const void* id128);
 Comm* comm_create_host(const Geometry& g, ddamg_hip_exchange_fn fn, ddamg_hip_allreduce_fn reduce_fn, void* user);
 void comm_destroy(Comm* c);
 void rccl_unique_id(void* id128);
+// host-buffer primitives over either transport (setup-time exchanges such as the gauge-field halo): blocking
+void comm_sendrecv_host(Comm* c, const void* send, int send_peer, void* recv, int recv_peer, size_t bytes, int tag);
+void comm_allreduce_host(Comm* c, double* buf, int n);
 
 // send / receive arenas of the 8 face messages of one field type and their exchange (any payload)
 class HaloArena {

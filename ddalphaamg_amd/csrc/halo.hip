@@ -52,6 +52,43 @@ void comm_allreduce(Comm* c, double* d_buf, int n, hipStream_t st) {
   }
 }
 
+void comm_sendrecv_host(Comm* c, const void* send, int send_peer, void* recv, int recv_peer, size_t bytes, int tag) {
+  DDAMG_REQUIRE(c != nullptr, "process grid > 1 but no transport: call ddamg_hip_comm_init_rccl or ddamg_hip_comm_init_host first");
+  if (c->kind == 2) {
+    ddamg_hip_halo_msg m{send_peer, recv_peer, tag, send, recv, (unsigned long long)bytes};
+    c->fn(c->user, 1, &m);
+    return;
+  }
+  char *ds = nullptr, *dr = nullptr;   // RCCL moves device memory: stage
+  DDAMG_HIP_CHECK(hipMalloc(&ds, bytes));
+  DDAMG_HIP_CHECK(hipMalloc(&dr, bytes));
+  DDAMG_HIP_CHECK(hipMemcpyAsync(ds, send, bytes, hipMemcpyHostToDevice, c->stream));
+  DDAMG_NCCL_CHECK(ncclGroupStart());
+  DDAMG_NCCL_CHECK(ncclSend(ds, bytes, ncclChar, send_peer, c->nccl, c->stream));
+  DDAMG_NCCL_CHECK(ncclRecv(dr, bytes, ncclChar, recv_peer, c->nccl, c->stream));
+  DDAMG_NCCL_CHECK(ncclGroupEnd());
+  DDAMG_HIP_CHECK(hipMemcpyAsync(recv, dr, bytes, hipMemcpyDeviceToHost, c->stream));
+  DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
+  DDAMG_HIP_CHECK(hipFree(ds));
+  DDAMG_HIP_CHECK(hipFree(dr));
+}
+
+void comm_allreduce_host(Comm* c, double* buf, int n) {
+  if (!c || c->nranks == 1) return;
+  if (c->kind == 2) {
+    DDAMG_REQUIRE(c->reduce_fn != nullptr, "host transport without an allreduce callback");
+    c->reduce_fn(c->user, buf, n);
+    return;
+  }
+  double* d = nullptr;
+  DDAMG_HIP_CHECK(hipMalloc(&d, sizeof(double) * n));
+  DDAMG_HIP_CHECK(hipMemcpyAsync(d, buf, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
+  DDAMG_NCCL_CHECK(ncclAllReduce(d, d, (size_t)n, ncclDouble, ncclSum, c->nccl, c->stream));
+  DDAMG_HIP_CHECK(hipMemcpyAsync(buf, d, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
+  DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
+  DDAMG_HIP_CHECK(hipFree(d));
+}
+
 void rccl_unique_id(void* id128) {
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
   ncclUniqueId id;

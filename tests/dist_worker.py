@@ -94,6 +94,37 @@ def run_dirac(rank, world, P, prec, transport):
     return err
 
 
+def run_gauge(rank, world, P):
+    """gauge -> operator on the process grid (links of the neighbouring processes fetched, corners included)
+    against the parts of the operator built on the undivided lattice"""
+    import ddalphaamg_amd as dd
+    here = os.path.dirname(os.path.abspath(__file__))
+    g = np.load(os.path.join(here, "golden", "ref_8x8_dirac.npz"))
+    G = [8, 8, 8, 8]
+    L = [G[mu] // P[mu] for mu in range(4)]
+    C = ddist.coords_of(rank, P)
+    p = api.default_params(); p.num_levels = 1
+    for mu in range(4):
+        p.local_lattice[0][mu] = G[mu]; p.block_lattice[0][mu] = 2
+    p.m0, p.csw = -0.5, 1.0
+    whole = dd.Context(p)
+    plaq = whole.set_gauge(g["gauge"], anti_pbc=True)
+    D, cl = whole.get_operator()
+    whole.close()
+    for mu in range(4):
+        p.local_lattice[0][mu] = L[mu]; p.process_grid[mu] = P[mu]; p.process_coords[mu] = C[mu]
+    ctx = dd.Context(p)
+    ddist.attach_host(ctx)
+    plaq_d = ctx.set_gauge(ddist.local_part(g["gauge"].reshape(4096, -1), G, P, C), anti_pbc=True)
+    Dl, cll = ctx.get_operator()
+    assert abs(plaq_d - plaq) < 1e-12 and abs(plaq - float(g["meta_f64"][2])) < 1e-12, (plaq_d, plaq)
+    assert np.array_equal(Dl.reshape(-1), ddist.local_part(D, G, P, C).reshape(-1))
+    err = float(np.linalg.norm(cll.reshape(-1) - ddist.local_part(cl, G, P, C).reshape(-1)) / np.linalg.norm(cll))
+    dist.barrier()
+    ctx.close()
+    return err
+
+
 def run_gmres(rank, world, P, mp):
     """pure GMRES (method 0) on the decomposed 8^4 sample configuration: global reductions + halo exchange;
     against the same solve on the undivided lattice (whose parity with the reference is tests/test_gpu_multigrid.py)"""
@@ -299,6 +330,8 @@ def main():
     assert int(np.prod(P)) == world
     if a.mode == "plan":
         err = run_plan(rank, world, P, [int(x) for x in a.lattice.split(",")])
+    elif a.mode == "gauge":
+        err = run_gauge(rank, world, P)
     elif a.mode == "amg":
         err = run_amg(rank, world, P, a.prec)
     elif a.mode == "sample_np2":

@@ -109,3 +109,11 @@ def test_c_host_program_over_mpi(nproc, grid):
         pytest.skip("no MPI in this image / driver not built (make -C ddalphaamg_amd/csrc mpi)")
     r = subprocess.run([MPIEXEC, "-n", str(nproc), MPI_DRIVER, *grid.split()], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "MPI_DRIVER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,grid", [(2, "1,1,2,1"), (4, "2,1,1,2")])
+def test_gauge_to_operator_on_a_process_grid(nproc, grid):
+    """ddamg_hip_set_gauge with the links of the neighbouring processes (one site deep, corners included): D bit-exact,
+    clover term to rounding, global plaquette equal to the reference's"""
+    launch(nproc, "--mode", "gauge", "--grid", grid, "--tol", "1e-14")
