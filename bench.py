@@ -142,18 +142,13 @@ def solve_leg(ctx_params, U, V, L, world=1, rank=0, transport="rccl", group=None
     else:
         from ddalphaamg_amd import dist as ddist
         grid = ddist.process_grid_for(world); coords = ddist.coords_of(rank, grid)
-        tmp = dd.Context(p)
-        tmp.set_gauge(U, anti_pbc=(coords[0] == grid[0] - 1))
-        D_part, cl_part = tmp.get_operator()
-        tmp.close()
         for mu in range(4):
             p.process_grid[mu] = grid[mu]; p.process_coords[mu] = coords[mu]
         ctx = dd.Context(p)
-        ctx.set_operator(D_part, cl_part)
+        ddist.attach_host(ctx, group)
+        ctx.set_gauge(U, anti_pbc=True)     # global clover term: neighbours' links over the host transport
         if transport == "rccl":
             ddist.attach_rccl(ctx, rank)
-        else:
-            ddist.attach_host(ctx, group)
     t0 = time.perf_counter(); ctx.setup(p.setup_iter[0]); ctx.sync(); t_setup = time.perf_counter() - t0
     b = np.zeros((V, 12, 2)); b[..., 0] = 1.0
     ctx.solve(b, 1e-10)
@@ -214,26 +209,21 @@ def main():
         grid = [1, 1, 1, 1]
     else:
         # domain decomposition: one process per GPU on a Cartesian grid, `--lattice` sites per GPU (weak
-        # scaling), halo exchange over RCCL.  Synthetic data: every process draws its own random links, and
-        # the clover term of its part is built from them alone (periodic in the part) -- the operator has
-        # the reference's structure and cost, which is all a throughput measurement needs.
+        # scaling), halo exchange over RCCL.  Every process draws the random links of its own part; the clover
+        # term is built on the global field (neighbours' links fetched over the host transport).
         from ddalphaamg_amd import dist as ddist
         grid = ddist.process_grid_for(world)
         coords = ddist.coords_of(rank, grid)
-        tmp = dd.Context(p)
-        tmp.set_gauge(U, anti_pbc=(coords[0] == grid[0] - 1))
-        D_part, cl_part = tmp.get_operator()
-        tmp.close()
         for mu in range(4):
             p.process_grid[mu] = grid[mu]; p.process_coords[mu] = coords[mu]
         ctx = dd.Context(p)
-        ctx.set_operator(D_part, cl_part)
+        gloo = dist.new_group(backend="gloo")
+        ddist.attach_host(ctx, gloo)
+        ctx.set_gauge(U, anti_pbc=True)
     x = ctx.vector(0, args.precision).upload(phi)
     y = ctx.vector(0, args.precision)
     if world > 1:
         # the same exchange through the host transport (gloo) first, as a cross-check of the RCCL path
-        gloo = dist.new_group(backend="gloo")
-        ddist.attach_host(ctx, gloo)
         ctx.dirac_apply(y, x)
         y_host = y.download()
         if args.transport == "rccl":
