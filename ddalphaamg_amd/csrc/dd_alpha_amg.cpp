@@ -11,6 +11,7 @@
 #include <ctime>
 #include <string>
 #include <vector>
+#include <dlfcn.h>
 
 extern "C" int ddamg_hip_preconditioner(ddamg_hip_ctx* c, double* out_lex, const double* in_lex);
 
@@ -26,6 +27,8 @@ struct State {
   double mass_for_next_solve = 0, current_mass = 0;
   bool setup_done = false, conf_set = false, fields_dirty = false;
   int V = 0;
+  int P[4] = {1, 1, 1, 1};     // process grid = global / local lattice (T,Z,Y,X)
+  int coords[4] = {0, 0, 0, 0};
 } S;
 
 // error0 of the reference prints and calls MPI_Abort (src/main.h:424-439): fatal, no error codes
@@ -75,12 +78,18 @@ void params_from_ini(const Ini& ini, ddamg_hip_params& hp, int* anti_pbc) {
     snprintf(k, sizeof k, "d%d global lattice:", d);
     if (!ini.geti(k, glob[d], 4)) fatal("parameter \"%s\" missing", k);
     snprintf(k, sizeof k, "d%d local lattice:", d);
-    if (!ini.geti(k, hp.local_lattice[d], 4)) {
+    const bool have_local = ini.geti(k, hp.local_lattice[d], 4);
+    if (have_local && d == 0)
+      for (int mu = 0; mu < 4; mu++) {
+        if (hp.local_lattice[0][mu] <= 0 || glob[0][mu] % hp.local_lattice[0][mu]) fatal("d0 local lattice must divide d0 global lattice");
+        S.P[mu] = glob[0][mu] / hp.local_lattice[0][mu];
+      }
+    if (!have_local) {
       if (d == 0) fatal("parameter \"%s\" missing", k);
-      for (int mu = 0; mu < 4; mu++) hp.local_lattice[d][mu] = glob[d][mu] / (glob[0][mu] / hp.local_lattice[0][mu]);
+      for (int mu = 0; mu < 4; mu++) hp.local_lattice[d][mu] = glob[d][mu] / S.P[mu];   // as src/init.c:56-72
     }
     for (int mu = 0; mu < 4; mu++)
-      if (glob[d][mu] != hp.local_lattice[d][mu]) fatal("global and local lattice differ: one process per GPU holds the whole lattice in this build");
+      if (glob[d][mu] != hp.local_lattice[d][mu] * S.P[mu]) fatal("every level must be distributed over the same process grid");
     snprintf(k, sizeof k, "d%d block lattice:", d); ini.geti(k, hp.block_lattice[d], 4);
     snprintf(k, sizeof k, "d%d post smooth iter:", d); ini.geti(k, &hp.post_smooth_iter[d]);
     snprintf(k, sizeof k, "d%d block iter:", d); ini.geti(k, &hp.block_iter[d]);
@@ -113,8 +122,11 @@ void params_from_struct(const dd_alpha_amg_parameters& a, ddamg_hip_params& hp) 
     for (int mu = 0; mu < 4; mu++) {  // X,Y,Z,T -> T,Z,Y,X (src/init.c:821-823)
       hp.local_lattice[d][mu] = a.local_lattice[d][3 - mu];
       hp.block_lattice[d][mu] = a.block_lattice[d][3 - mu];
-      if (a.global_lattice[d][3 - mu] != a.local_lattice[d][3 - mu])
-        fatal("global and local lattice differ: one process per GPU holds the whole lattice in this build");
+      if (a.local_lattice[d][3 - mu] <= 0 || a.global_lattice[d][3 - mu] % a.local_lattice[d][3 - mu])
+        fatal("local lattice must divide the global lattice");
+      if (d == 0) S.P[mu] = a.global_lattice[0][3 - mu] / a.local_lattice[0][3 - mu];
+      else if (a.global_lattice[d][3 - mu] / a.local_lattice[d][3 - mu] != S.P[mu])
+        fatal("every level must be distributed over the same process grid");
     }
     hp.num_vect[d] = a.mg_basis_vectors[d];
     hp.setup_iter[d] = a.setup_iterations[d];
@@ -138,7 +150,34 @@ void common_init(const dd_alpha_amg_par& p) {
   S.hp.csw = p.csw;           // g.csw = p.csw (src/dd_alpha_amg.c:103)
   S.hp.m0 = p.m0;             // l.real_shift = p.m0
   S.current_mass = S.mass_for_next_solve = p.m0;
+  const int nproc = S.P[0] * S.P[1] * S.P[2] * S.P[3];
+  void* comm = nullptr;
+  int (*comm_init_mpi)(ddamg_hip_ctx*, void*, int) = nullptr;
+  if (nproc > 1) {
+    // several processes: the MPI part lives in libddamg_hip_mpi.so next to this library (the reference builds its
+    // Cartesian communicator from MPI_COMM_WORLD at this point, src/ghost.c:47-66)
+    Dl_info info;
+    std::string dir;
+    if (dladdr((void*)&ddamg_hip_create, &info) && info.dli_fname) { dir = info.dli_fname; dir = dir.substr(0, dir.find_last_of('/') + 1); }
+    void* h = dlopen((dir + "libddamg_hip_mpi.so").c_str(), RTLD_NOW | RTLD_GLOBAL);
+    if (!h) fatal("global lattice != local lattice needs libddamg_hip_mpi.so (make -C ddalphaamg_amd/csrc mpi): %s", dlerror());
+    auto cart = (int (*)(const int*, int*, int*, void**))dlsym(h, "ddamg_hip_mpi_cart");
+    comm_init_mpi = (int (*)(ddamg_hip_ctx*, void*, int))dlsym(h, "ddamg_hip_comm_init_mpi");
+    if (!cart || !comm_init_mpi) fatal("libddamg_hip_mpi.so does not export the expected entry points");
+    int local_rank = 0;
+    const int rc = cart(S.P, S.coords, &local_rank, &comm);
+    if (rc == 1) fatal("MPI is not initialised: the host application calls MPI_Init before dd_alpha_amg_init (as with the reference)");
+    if (rc) fatal("number of MPI processes does not match global / local lattice (src/ghost.c:51-54)");
+    int ndev = 1;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) fatal("no HIP device visible");
+    S.hp.device = local_rank % ndev;
+    for (int mu = 0; mu < 4; mu++) { S.hp.process_grid[mu] = S.P[mu]; S.hp.process_coords[mu] = S.coords[mu]; }
+  }
   check(ddamg_hip_create(&S.hp, &S.ctx), "dd_alpha_amg_init");
+  if (nproc > 1) {
+    const char* t = getenv("DDAMG_HIP_TRANSPORT");   // "host": MPI moves staged buffers; default: RCCL over xGMI
+    if (comm_init_mpi(S.ctx, comm, !(t && std::string(t) == "host"))) fatal("dd_alpha_amg_init: %s", ddamg_hip_last_error());
+  }
   S.V = 1; for (int mu = 0; mu < 4; mu++) S.V *= S.hp.local_lattice[0][mu];
   S.inited = true;
 }
@@ -204,7 +243,7 @@ bool scaled_operator(double se, double so, std::vector<double>& cl) {
   cl = S.ctx->clover_host;
   size_t s = 0;
   for (int t = 0; t < L[0]; t++) for (int z = 0; z < L[1]; z++) for (int y = 0; y < L[2]; y++) for (int x = 0; x < L[3]; x++, s++) {
-    const double f = ((t + z + y + x) % 2 == 1) ? so : se;
+    const double f = ((t + z + y + x + S.ctx->levels[0]->geom.oe_offset) % 2 == 1) ? so : se;   // global parity
     for (int k = 0; k < 84; k++) cl[s * 84 + k] *= f;
   }
   return true;

@@ -18,6 +18,12 @@ extern "C" {
  * src/ghost_generic.c:152-330). */
 int ddamg_hip_comm_init_mpi(ddamg_hip_ctx* ctx, void* comm, int use_rccl);
 
+/* Cartesian communicator over MPI_COMM_WORLD for the given process grid (cart_define, src/ghost.c:47-66): my
+ * coordinates, my rank among the processes of this node (device ordinal), and a handle for
+ * ddamg_hip_comm_init_mpi.  MPI must be initialised by the host application (the reference never calls MPI_Init
+ * itself either).  Used by the dd_alpha_amg_* facade when global and local lattice differ. */
+int ddamg_hip_mpi_cart(const int process_grid[4], int coords[4], int* local_rank, void** comm_out);
+
 #ifdef __cplusplus
 }
 #endif

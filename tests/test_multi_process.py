@@ -117,3 +117,18 @@ def test_gauge_to_operator_on_a_process_grid(nproc, grid):
     """ddamg_hip_set_gauge with the links of the neighbouring processes (one site deep, corners included): D bit-exact,
     clover term to rounding, global plaquette equal to the reference's"""
     launch(nproc, "--mode", "gauge", "--grid", grid, "--tol", "1e-14")
+
+
+@pytest.mark.gpu
+def test_reference_library_interface_over_mpi(tmp_path):
+    """tests/mpi/mpi_facade_driver.c knows only include/dd_alpha_amg.h (init with global/local lattice, set_conf through
+    index callbacks, setup, wilson_solve): 1 process writes the solution, 2 and 4 processes must reproduce plaquette,
+    iteration count (+-2) and solution; host transport (DDAMG_HIP_TRANSPORT=host: all ranks share the one test GPU)"""
+    drv = os.path.join(HERE, "mpi", "mpi_facade_driver")
+    if not (os.path.exists(MPIEXEC) and os.path.exists(drv)):
+        pytest.skip("no MPI in this image / driver not built (make -C ddalphaamg_amd/csrc mpi)")
+    f = str(tmp_path / "solution.bin")
+    env = dict(os.environ, DDAMG_HIP_TRANSPORT="host")
+    for nproc, grid in ((1, "1 1 1 1"), (2, "2 1 1 1"), (4, "2 1 2 1")):
+        r = subprocess.run([MPIEXEC, "-n", str(nproc), drv, *grid.split(), f], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "FACADE_DRIVER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
