@@ -57,7 +57,7 @@ __global__ void restrict_kernel(T* __restrict__ phi_c, size_t out_stride, const 
       for (int t = 0; t < TL; t++) {
         if (t < jt) {
           T p[24];
-          load_site<T, 24>(P + (size_t)(j0 + t) * pstride, V, s0 + i, p);
+          load_site<T, 24, true>(P + (size_t)(j0 + t) * pstride, V, s0 + i, p);
 #pragma unroll
           for (int m = 0; m < NIN; m++) {
             T f[24];
@@ -215,7 +215,7 @@ __global__ void interpolate_kernel(T* __restrict__ phi, const T* __restrict__ ph
     }
     for (int j = 0; j < nvec; j++) {
       T p[24];
-      load_site<T, 24>(P + (size_t)j * pstride, V, s0 + i, p);
+      load_site<T, 24, true>(P + (size_t)j * pstride, V, s0 + i, p);
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const T cr = pc[2 * (h * nvec + j)], ci = pc[2 * (h * nvec + j) + 1];
