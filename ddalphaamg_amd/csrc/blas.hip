@@ -41,6 +41,21 @@ __device__ __forceinline__ size_t chunk_addr(const View& v, size_t c) {
   return v.off + r * v.stride + (c - r * cpr) * CH;
 }
 template <typename T> __device__ __forceinline__ typename Chunk<T>::vec ldv(const T* p) { return *reinterpret_cast<const typename Chunk<T>::vec*>(p); }
+// read-once stream (Krylov basis vectors of the fine level): non-temporal, so that it does not displace reusable lines
+template <typename T, bool NT> __device__ __forceinline__ typename Chunk<T>::vec ldv_stream(const T* p) {
+  if constexpr (!NT) return ldv<T>(p);
+  else {
+    constexpr int CH = Chunk<T>::CH;
+    typedef T vecn __attribute__((ext_vector_type(CH)));
+    vecn w = __builtin_nontemporal_load(reinterpret_cast<const vecn*>(p));
+    typename Chunk<T>::vec v;
+    v.x = w[0]; v.y = w[1];
+    if constexpr (CH == 4) { v.z = w[2]; v.w = w[3]; }
+    return v;
+  }
+}
+// vectors above this size cannot live in the caches anyway
+static inline bool stream_sized(const View& v, size_t elem) { return v.total() * elem > ((size_t)32 << 20); }
 template <typename T> __device__ __forceinline__ void stv(T* p, typename Chunk<T>::vec x) { *reinterpret_cast<typename Chunk<T>::vec*>(p) = x; }
 
 // complex pair views of a chunk
@@ -134,7 +149,7 @@ void vec_convert(TO* y, const TI* x, size_t V, int nreal, hipStream_t st) {
 }
 
 // ---- multi-axpy with device coefficients ---------------------------------------------------
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(BLK) void multi_axpy_kernel(T* __restrict__ w, const T* __restrict__ X, size_t xstride, int m,
                                                          const double* __restrict__ coef, double sign, View v) {
   constexpr int CH = Chunk<T>::CH;
@@ -145,7 +160,7 @@ __global__ __launch_bounds__(BLK) void multi_axpy_kernel(T* __restrict__ w, cons
     vec wv = ldv<T>(w + a);
     for (int i = 0; i < m; i++) {
       const T cr = (T)(sign * coef[2 * i]), ci = (T)(sign * coef[2 * i + 1]);
-      vec xv = ldv<T>(X + (size_t)i * xstride + a);
+      vec xv = ldv_stream<T, NT>(X + (size_t)i * xstride + a);
       if constexpr (CH == 4) {
         wv.x += cr * xv.x - ci * xv.y; wv.y += cr * xv.y + ci * xv.x;
         wv.z += cr * xv.z - ci * xv.w; wv.w += cr * xv.w + ci * xv.z;
@@ -159,7 +174,8 @@ __global__ __launch_bounds__(BLK) void multi_axpy_kernel(T* __restrict__ w, cons
 template <typename T>
 void vec_multi_axpy_dev(T* w, const T* X, size_t xstride, int m, const double* d_coef, double sign, View v, hipStream_t st) {
   if (m <= 0 || v.total() == 0) return;
-  hipLaunchKernelGGL(multi_axpy_kernel<T>, dim3(grid_for(v.total() / Chunk<T>::CH)), dim3(BLK), 0, st, w, X, xstride, m, d_coef, sign, v);
+  if (stream_sized(v, sizeof(T))) hipLaunchKernelGGL((multi_axpy_kernel<T, true>), dim3(grid_for(v.total() / Chunk<T>::CH)), dim3(BLK), 0, st, w, X, xstride, m, d_coef, sign, v);
+  else hipLaunchKernelGGL((multi_axpy_kernel<T, false>), dim3(grid_for(v.total() / Chunk<T>::CH)), dim3(BLK), 0, st, w, X, xstride, m, d_coef, sign, v);
   DDAMG_HIP_CHECK(hipGetLastError());
 }
 
@@ -188,7 +204,7 @@ __device__ __forceinline__ void block_sum(double (&val)[NV], double* lds /* [NV*
 
 static constexpr int DOT_TILE = 4;
 // partial[(blockIdx.x)*(2*mtot) + 2*i..] for i in tile blockIdx.y
-template <typename T>
+template <typename T, bool NT>
 __global__ __launch_bounds__(BLK) void multi_dot_kernel(const T* __restrict__ X, size_t xstride, int m, const T* __restrict__ w,
                                                         View v, double* __restrict__ partial) {
   constexpr int CH = Chunk<T>::CH;
@@ -206,7 +222,7 @@ __global__ __launch_bounds__(BLK) void multi_dot_kernel(const T* __restrict__ X,
 #pragma unroll
     for (int t = 0; t < DOT_TILE; t++) {
       if (t < mt) {
-        vec xv = ldv<T>(X + (size_t)(i0 + t) * xstride + a);
+        vec xv = ldv_stream<T, NT>(X + (size_t)(i0 + t) * xstride + a);
         // conj(x) * w
         if constexpr (CH == 4) {
           acc[2 * t]     += (double)xv.x * wv.x + (double)xv.y * wv.y + (double)xv.z * wv.z + (double)xv.w * wv.w;
@@ -243,7 +259,8 @@ void vec_multi_dot(const T* X, size_t xstride, int m, const T* w, View v, Reduce
   DDAMG_REQUIRE(m >= 1 && m <= rw.max_m, "multi_dot: too many vectors for the reduction workspace");
   const int gx = std::min(grid_for(v.total() / Chunk<T>::CH), 1024);
   const int gy = (m + DOT_TILE - 1) / DOT_TILE;
-  hipLaunchKernelGGL(multi_dot_kernel<T>, dim3(gx, gy), dim3(BLK), 0, st, X, xstride, m, w, v, rw.d_partial);
+  if (stream_sized(v, sizeof(T))) hipLaunchKernelGGL((multi_dot_kernel<T, true>), dim3(gx, gy), dim3(BLK), 0, st, X, xstride, m, w, v, rw.d_partial);
+  else hipLaunchKernelGGL((multi_dot_kernel<T, false>), dim3(gx, gy), dim3(BLK), 0, st, X, xstride, m, w, v, rw.d_partial);
   hipLaunchKernelGGL(final_sum_kernel, dim3(2 * m), dim3(BLK), 0, st, rw.d_partial, gx, 2 * m, d_out, 0);
   DDAMG_HIP_CHECK(hipGetLastError());
   if (rw.comm) comm_allreduce(rw.comm, d_out, 2 * m, st);
