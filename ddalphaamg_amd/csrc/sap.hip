@@ -466,10 +466,10 @@ __global__ __launch_bounds__((BS < 64 ? 64 : BS), (sizeof(T) == 4 ? 2 : 1)) void
     ob.cl = make_site_buf(odd ? op.clover_inv : op.clover, V, sizeof(T) * 72 * V);
     ob.voff = (unsigned)(s * 16);
     const unsigned lrow = (unsigned)(18 * sizeof(T)) * (ob.D.row / 16);   // bytes between two directions' links
-    load_site_b<T, 18>(ob.D, 0, ob.voff, U0);
-    load_site_b<T, 18>(ob.D, lrow, ob.voff, U1);
-    load_site_b<T, 18>(ob.D, 2 * lrow, ob.voff, U2);
-    load_site_b<T, 18>(ob.D, 3 * lrow, ob.voff, U3);
+    load_site_b<T, 18, 2>(ob.D, 0, ob.voff, U0);
+    load_site_b<T, 18, 2>(ob.D, lrow, ob.voff, U1);
+    load_site_b<T, 18, 2>(ob.D, 2 * lrow, ob.voff, U2);
+    load_site_b<T, 18, 2>(ob.D, 3 * lrow, ob.voff, U3);
     load_site_b<T, 72, 2>(ob.cl, 0, ob.voff, C);
   }
 
