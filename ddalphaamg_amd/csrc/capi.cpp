@@ -132,8 +132,8 @@ static void upload_operator(ddamg_hip_ctx* c) {
   c->fop64.upload(g, c->D_host.data(), c->clover_host.data(), c->stream);
   c->fop32.upload(g, c->D_host.data(), c->clover_host.data(), c->stream);
   c->have_operator = true;
-  if (c->mg32 && c->setup_done) c->mg32->operator_changed();
-  if (c->mg64 && c->setup_done) c->mg64->operator_changed();
+  if (c->mg32 && c->setup_done) { c->mg32->operator_changed(); c->mg32->release_setup_workspace(); }
+  if (c->mg64 && c->setup_done) { c->mg64->operator_changed(); c->mg64->release_setup_workspace(); }
 }
 
 int ddamg_hip_set_gauge(ddamg_hip_ctx* c, const double* gauge_lex, int anti_pbc, double* plaquette) {

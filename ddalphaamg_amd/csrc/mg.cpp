@@ -114,6 +114,8 @@ Multigrid<T>::~Multigrid() {
   if (d_lex0_) (void)hipFree(d_lex0_);
   if (d_stage_) (void)hipFree(d_stage_);
   if (W_) (void)hipFree(W_);
+  if (gal_W_) (void)hipFree(gal_W_);
+  if (gal_C_) (void)hipFree(gal_C_);
   if (cwork_) (void)hipFree(cwork_);
 }
 
@@ -280,13 +282,18 @@ void Multigrid<T>::build_coarse_operator(int l) {
     // batched form: D P for a whole batch of columns (5 fields each), then ONE restriction on the matrix cores
     const size_t ws = (size_t)24 * lv.g->V;             // one fine vector
     const size_t cs = (size_t)nx.g->V * nx.n * 2;       // one coarse vector
-    size_t free_b = 0, total_b = 0;
-    DDAMG_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-    int batch = 2 * N;
-    while (batch > 1 && (5 * batch > 256 || sizeof(T) * 5 * batch * (ws + cs) > free_b / 2)) batch = (batch + 1) / 2;
-    T *Wb = nullptr, *Cb = nullptr;
-    DDAMG_HIP_CHECK(hipMalloc(&Wb, sizeof(T) * 5 * batch * ws));
-    DDAMG_HIP_CHECK(hipMalloc(&Cb, sizeof(T) * 5 * batch * cs));
+    // the batch workspace is allocated once per setup and kept until release_setup_workspace(): allocating and
+    // freeing tens of GB for every build costs more than the build itself
+    if (!gal_W_) {
+      size_t free_b = 0, total_b = 0;
+      DDAMG_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+      gal_batch_ = 2 * N;
+      while (gal_batch_ > 1 && (5 * gal_batch_ > 256 || sizeof(T) * 5 * gal_batch_ * (ws + cs) > free_b / 2)) gal_batch_ = (gal_batch_ + 1) / 2;
+      DDAMG_HIP_CHECK(hipMalloc(&gal_W_, sizeof(T) * 5 * gal_batch_ * ws));
+      DDAMG_HIP_CHECK(hipMalloc(&gal_C_, sizeof(T) * 5 * gal_batch_ * cs));
+    }
+    const int batch = gal_batch_;
+    T *Wb = gal_W_, *Cb = gal_C_;
     for (int c0 = 0; c0 < 2 * N; c0 += batch) {
       const int nb = std::min(batch, 2 * N - c0);
       for (int c = 0; c < nb; c++)
@@ -294,9 +301,6 @@ void Multigrid<T>::build_coarse_operator(int l) {
       lv.fip.restrict_batch(Cb, cs, Wb, ws, 5 * nb, st_);
       for (int c = 0; c < nb; c++) galerkin_store_column<T>(nx.cop, Cb + (size_t)5 * c * cs, c0 + c, st_);
     }
-    DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
-    DDAMG_HIP_CHECK(hipFree(Wb));
-    DDAMG_HIP_CHECK(hipFree(Cb));
   } else if (l == 0) {
     for (int chir = 0; chir < 2; chir++)
       for (int j = 0; j < N; j++) {
@@ -323,6 +327,13 @@ void Multigrid<T>::build_coarse_operator(int l) {
   if (nx.coarsest) nx.cop.compute_self_inverse(st_);
   DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
   tick("Galerkin coarse operator", t_start);
+}
+
+template <typename T>
+void Multigrid<T>::release_setup_workspace() {
+  DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
+  if (gal_W_) { DDAMG_HIP_CHECK(hipFree(gal_W_)); gal_W_ = nullptr; }
+  if (gal_C_) { DDAMG_HIP_CHECK(hipFree(gal_C_)); gal_C_ = nullptr; }
 }
 
 template <typename T>

@@ -61,6 +61,7 @@ class Multigrid {
   void import_interpolation(const double* P_lex_host);   // level-0 interpolation vectors as they are
   void operator_changed();              // fine operator re-uploaded: rebuild the coarse operators
   void set_kcycle_tol(double tol);
+  void release_setup_workspace();       // large temporaries of the Galerkin construction (kept across the builds of one setup)
   void set_comm(Comm* c) { comm_ = c; for (auto& lv : lv_) { lv->rw.comm = c; lv->cop.set_comm(c); } }
 
   // ---- hot path -----------------------------------------------------------------------------
@@ -82,6 +83,8 @@ class Multigrid {
   hipStream_t st_;
   Comm* comm_ = nullptr;
   unsigned long long rng_stream_ = 0;
+  T *gal_W_ = nullptr, *gal_C_ = nullptr;   // batched Galerkin workspace
+  int gal_batch_ = 0;
  public:
   // wall-clock seconds per setup phase (stream-synchronised), filled when DDAMG_SETUP_TIMING is set
   std::vector<std::pair<std::string, double>> setup_times;

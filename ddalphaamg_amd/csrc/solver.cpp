@@ -144,6 +144,7 @@ int ddamg_hip_setup(ddamg_hip_ctx* c, int setup_iterations, int* coarse_iteratio
   if (c->mg32) { c->mg32->coarse_iter_count = 0; c->mg32->initial_setup(); c->mg32->iterative_setup(iters); if (coarse_iterations) *coarse_iterations = c->mg32->coarse_iter_count; }
   else { c->mg64->coarse_iter_count = 0; c->mg64->initial_setup(); c->mg64->iterative_setup(iters); if (coarse_iterations) *coarse_iterations = c->mg64->coarse_iter_count; }
   c->setup_done = true;
+  if (c->mg32) c->mg32->release_setup_workspace(); else c->mg64->release_setup_workspace();
   auto report = [](const std::vector<std::pair<std::string, double>>& t) {
     for (auto& e : t) fprintf(stderr, "[ddamg setup] %-28s %8.3f s\n", e.first.c_str(), e.second);
   };
@@ -157,6 +158,7 @@ int ddamg_hip_setup_update(ddamg_hip_ctx* c, int iterations, int* coarse_iterati
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
   if (c->mg32) { c->mg32->coarse_iter_count = 0; c->mg32->iterative_setup(iterations); if (coarse_iterations) *coarse_iterations = c->mg32->coarse_iter_count; }
   else { c->mg64->coarse_iter_count = 0; c->mg64->iterative_setup(iterations); if (coarse_iterations) *coarse_iterations = c->mg64->coarse_iter_count; }
+  if (c->mg32) c->mg32->release_setup_workspace(); else c->mg64->release_setup_workspace();
   DDAMG_API_END
 }
 
@@ -167,6 +169,7 @@ int ddamg_hip_set_test_vectors(ddamg_hip_ctx* c, const double* tv_lex, int ortho
   ensure_mg(c);
   if (c->mg32) { if (orthonormalised) c->mg32->import_interpolation(tv_lex); else c->mg32->import_test_vectors(tv_lex); }
   else { if (orthonormalised) c->mg64->import_interpolation(tv_lex); else c->mg64->import_test_vectors(tv_lex); }
+  if (c->mg32) c->mg32->release_setup_workspace(); else c->mg64->release_setup_workspace();
   c->setup_done = true;
   DDAMG_API_END
 }
