@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/solve_profile.py -- set up once, then run N solves (for rocprofv3 --kernel-trace --stats: the solve kernels
-dominate the trace when N is large enough).  python3 tools/solve_profile.py [N]"""
+dominate the trace when N is large enough).  python3 tools/solve_profile.py [N [mixed_precision [extent [levels]]]]"""
 import os, sys, time, json
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,11 +10,16 @@ import ddalphaamg_amd as dd  # noqa: E402
 from ddalphaamg_amd import api  # noqa: E402
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 mp = int(sys.argv[2]) if len(sys.argv) > 2 else 1
-L = [32] * 4; V = 32 ** 4
-p = api.default_params(); p.num_levels = 2
+ext = int(sys.argv[3]) if len(sys.argv) > 3 else 32
+levels = int(sys.argv[4]) if len(sys.argv) > 4 else 2
+L = [ext] * 4; V = ext ** 4
+p = api.default_params(); p.num_levels = levels
 for mu in range(4):
-    p.local_lattice[0][mu] = 32; p.block_lattice[0][mu] = 4; p.local_lattice[1][mu] = 8
+    p.local_lattice[0][mu] = ext; p.block_lattice[0][mu] = 4; p.local_lattice[1][mu] = ext // 4
+    if levels == 3:
+        p.block_lattice[1][mu] = 2; p.local_lattice[2][mu] = ext // 8
 p.num_vect[0] = 24; p.post_smooth_iter[0] = 2; p.block_iter[0] = 4; p.setup_iter[0] = 4
+p.num_vect[1] = 28; p.post_smooth_iter[1] = 2; p.block_iter[1] = 4; p.setup_iter[1] = 2
 p.restart, p.max_restart, p.tol = 50, 20, 1e-10
 p.coarse_iter, p.coarse_restart, p.coarse_tol = 100, 5, 5e-2
 p.mixed_precision, p.method, p.odd_even = mp, 2, 1
