@@ -49,6 +49,9 @@ class FineOp {
   // fill the receive arena with the boundary half spinors of `v` (for kernels other than apply() that couple
   // to off-process neighbours through FineOpDev::halo: Schwarz residual updates, Galerkin products)
   void halo_exchange(const T* v, hipStream_t st) const;
+  // split form: kernels enqueued between begin and finish overlap with the exchange; those after finish see the halo
+  void halo_begin(const T* v, hipStream_t st) const;
+  void halo_finish(hipStream_t st) const;
   bool distributed() const { return halo_.active(); }
 
  private:

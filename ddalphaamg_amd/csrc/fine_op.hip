@@ -213,11 +213,19 @@ void FineOp<T>::apply(T* eta, const T* phi, hipStream_t st) const {
 }
 
 template <typename T>
-void FineOp<T>::halo_exchange(const T* v, hipStream_t st) const {
+void FineOp<T>::halo_begin(const T* v, hipStream_t st) const {
   if (!halo_.active()) return;
   halo_.pack(v, D_, V_, st);
   halo_.exchange_begin(comm_, st);
-  halo_.exchange_finish(comm_, st);
+}
+template <typename T>
+void FineOp<T>::halo_finish(hipStream_t st) const {
+  if (halo_.active()) halo_.exchange_finish(comm_, st);
+}
+template <typename T>
+void FineOp<T>::halo_exchange(const T* v, hipStream_t st) const {
+  halo_begin(v, st);
+  halo_finish(st);
 }
 
 template <typename T>

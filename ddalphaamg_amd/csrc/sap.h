@@ -45,6 +45,7 @@ class SapSmoother {
   const FineOp<T>* op_ = nullptr;
   int V_ = 0, BS_ = 0, HS_ = 0, nblocks_ = 0, block_iter_ = 4;
   int ncol_[2] = {0, 0};
+  int ncol_interior_[2] = {0, 0};                  // the first ncol_interior_[c] blocks of a colour list have no site next to another process
   int* d_blk_nb_ = nullptr;
   int* d_block_list_ = nullptr;
   int* d_color_blocks_[2] = {nullptr, nullptr};  // block indices per colour

@@ -589,9 +589,17 @@ void SapSmoother<T>::setup(const Geometry& g, const FineOp<T>* op, int block_ite
   DDAMG_HIP_CHECK(hipMemcpyAsync(d_blk_nb_, g.blk_nb.data(), sizeof(int) * 8 * BS_, hipMemcpyHostToDevice, st));
   DDAMG_HIP_CHECK(hipMalloc(&d_block_list_, sizeof(int) * nblocks_));
   DDAMG_HIP_CHECK(hipMemcpyAsync(d_block_list_, g.block_list.data(), sizeof(int) * nblocks_, hipMemcpyHostToDevice, st));
-  std::vector<int> cb[2];
-  for (int b = 0; b < nblocks_; b++) cb[g.block_color[b]].push_back(b);
+  // per colour: blocks without a neighbour on another process first (their solves overlap with the halo exchange)
+  std::vector<int> cb[2], cbb[2];
+  for (int b = 0; b < nblocks_; b++) {
+    bool boundary = false;
+    for (int i = 0; i < BS_ && !boundary; i++)
+      for (int d = 0; d < 8; d++) if (g.nb[(size_t)d * V_ + (size_t)b * BS_ + i] < 0) { boundary = true; break; }
+    (boundary ? cbb : cb)[g.block_color[b]].push_back(b);
+  }
   for (int c = 0; c < 2; c++) {
+    ncol_interior_[c] = (int)cb[c].size();
+    cb[c].insert(cb[c].end(), cbb[c].begin(), cbb[c].end());
     ncol_[c] = (int)cb[c].size();
     DDAMG_REQUIRE(ncol_[c] > 0, "red-black SAP needs blocks of both colours");
     DDAMG_HIP_CHECK(hipMalloc(&d_color_blocks_[c], sizeof(int) * ncol_[c]));
@@ -632,18 +640,31 @@ void SapSmoother<T>::launch(int color, int mode, unsigned skip_mask, const T* et
   a.mode = mode < 0 ? MODE_NBOUNDARY : mode; a.skip_mask = skip_mask; a.solve = mode < 0 ? 0 : 1;
   // couplings to blocks on neighbouring processes: the reference exchanges the ghost shell of latest_iter
   // (or of x for the full residual) between the colour sweeps (src/schwarz_generic.c:1334-1339,1402-1420)
-  if (op_->distributed() && a.mode != MODE_NONE) op_->halo_exchange(a.mode == MODE_FULLRES ? x : latest, st);
-  switch (HS_) {
-    case 8: launch_hs<T, 8>(a, st); break;
-    case 16: launch_hs<T, 16>(a, st); break;
-    case 32: launch_hs<T, 32>(a, st); break;
-    case 64: launch_hs<T, 64>(a, st); break;
-    case 128: launch_hs<T, 128>(a, st); break;
-    case 256:
-      if constexpr (sizeof(T) == 4) { launch_hs<T, 256>(a, st); break; }
-      DDAMG_REQUIRE(false, "512-site Schwarz blocks are only supported in fp32 (LDS budget)");
-      break;
-    default: DDAMG_REQUIRE(false, "unsupported Schwarz block volume");
+  auto run = [&](const int* blocks, int n) {
+    if (n <= 0) return;
+    a.blocks = blocks; a.nblocks = n;
+    switch (HS_) {
+      case 8: launch_hs<T, 8>(a, st); break;
+      case 16: launch_hs<T, 16>(a, st); break;
+      case 32: launch_hs<T, 32>(a, st); break;
+      case 64: launch_hs<T, 64>(a, st); break;
+      case 128: launch_hs<T, 128>(a, st); break;
+      case 256:
+        if constexpr (sizeof(T) == 4) { launch_hs<T, 256>(a, st); break; }
+        DDAMG_REQUIRE(false, "512-site Schwarz blocks are only supported in fp32 (LDS budget)");
+        break;
+      default: DDAMG_REQUIRE(false, "unsupported Schwarz block volume");
+    }
+  };
+  if (op_->distributed() && a.mode != MODE_NONE) {
+    // exchange in flight while the blocks away from the process boundary are solved; blocks of one colour are
+    // independent of each other, so the split changes nothing in the result
+    op_->halo_begin(a.mode == MODE_FULLRES ? x : latest, st);
+    run(d_color_blocks_[color], ncol_interior_[color]);
+    op_->halo_finish(st);
+    run(d_color_blocks_[color] + ncol_interior_[color], ncol_[color] - ncol_interior_[color]);
+  } else {
+    run(d_color_blocks_[color], ncol_[color]);
   }
 }
 
