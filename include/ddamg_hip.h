@@ -152,18 +152,23 @@ int ddamg_hip_residual_history(ddamg_hip_ctx* ctx, double* history, int max_len,
  * reference's translation_table, src/data_layout.c:152-251) */
 int ddamg_hip_get_site_order(ddamg_hip_ctx* ctx, int level, int* lex_of_site);
 
-/* ---- multi-GPU halo exchange (replaces ghost_sendrecv_PRECISION / ghost_wait_PRECISION and the
- * plus/minus_dir_param phases of d_plus_clover_PRECISION, src/ghost_generic.c:152-330,
- * src/dirac_generic.c:178-262) --------------------------------------------------------------------
- * With process_grid != 1111 ddamg_hip_dirac_apply runs: pack the projected boundary half spinors
- * (6 complex per face site and direction, as the reference sends) -> exchange -> interior
- * tiles (overlapped with the exchange) -> boundary tiles.  Two transports:
+/* ---- several GPUs: one process per GPU on the process grid of ddamg_hip_params -------------------------
+ * Replaces the reference's MPI layer on the hot path: ghost_sendrecv_PRECISION / ghost_wait_PRECISION /
+ * ghost_update_PRECISION (src/ghost_generic.c:152-330), the boundary phases of d_plus_clover_PRECISION
+ * (src/dirac_generic.c:178-262), of the Schwarz smoother (src/schwarz_generic.c:1334-1420) and of the coarse
+ * operator (src/coarse_oddeven_generic.c:447-729), and the MPI_Allreduce of the inner products
+ * (src/linalg_generic.c:29-120).  Every entry point of this header works on a process grid once a transport is
+ * installed: ddamg_hip_set_gauge (fetches the neighbours' links for the clover term), dirac_apply, smoother,
+ * restrict/interpolate, coarse_apply, coarse_solve, vcycle, setup, solve; host arrays are the process's own part.
+ * ddamg_hip_dirac_apply runs: pack the projected boundary half spinors (6 complex per face site and direction,
+ * as the reference sends) -> exchange -> interior tiles (overlapped with the exchange) -> boundary tiles; the
+ * smoother overlaps its exchange with the blocks away from the process boundary.  Two transports:
  *  - RCCL: ncclSend/ncclRecv on device buffers over xGMI.  Rank 0 obtains an id with
  *    ddamg_hip_rccl_unique_id (128 bytes), the host application broadcasts it (MPI_Bcast /
  *    torch.distributed) and every rank calls ddamg_hip_comm_init_rccl;
  *  - host: the boundary data is staged through pinned host buffers and handed to a callback of the
- *    host application, which moves the nmsg messages with its own MPI (MPI_Sendrecv per message).
- *    send/recv peers are ranks in the process grid above. */
+ *    host application, which moves the nmsg messages with its own MPI (MPI_Irecv/MPI_Isend per message);
+ *    send/recv peers are ranks in the process grid above.  include/ddamg_hip_mpi.h wraps both for MPI hosts. */
 typedef struct ddamg_hip_halo_msg {
   int send_peer, recv_peer;  /* send `send` to send_peer, receive `recv` from recv_peer                 */
   int tag;                   /* 0..3: data travelling in +mu, 4..7: data travelling in -mu              */
