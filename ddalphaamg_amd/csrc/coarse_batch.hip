@@ -1,0 +1,148 @@
+// coarse_batch.hip -- see coarse_batch.h
+#include "coarse_batch.h"
+
+namespace ddamg {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int NB = COARSE_BATCH_COLS;
+
+bool coarse_galerkin_batch_available(int n, int ncols, bool distributed, size_t elem_size) {
+  return elem_size == 4 && !distributed && ncols <= NB && n <= 64 && n % 4 == 0;
+}
+
+// V[x][k][j] = P_{j mod N}(x,k) if k belongs to chirality j / N (k < n/2 <-> chirality 0), else 0; columns >= 2N are 0
+__global__ void batch_input_kernel(float2* __restrict__ Vb, const float* __restrict__ P, size_t pstride, int V, int n, int N) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // (x, k, j)
+  if (e >= (size_t)V * n * NB) return;
+  const int j = (int)(e % NB), k = (int)((e / NB) % n);
+  const size_t x = e / ((size_t)NB * n);
+  float2 v = make_float2(0.f, 0.f);
+  if (j < 2 * N && (k >= n / 2) == (j >= N)) {
+    const float* p = P + (size_t)(j % N) * pstride + (x * n + k) * 2;
+    v = make_float2(p[0], p[1]);
+  }
+  Vb[e] = v;
+}
+
+__device__ __forceinline__ size_t tile_off_c(int nt, int i, int j) { return ((size_t)((i >> 3) * nt + (j >> 3)) * 64 + (i & 7) * 8 + (j & 7)); }
+
+// acc (+)= sign * A * B over all k, A = the coupling matrix (or G5 A^H G5 for a backward coupling), B = the batch at site y.
+// One wavefront: 16 columns (col0 .. col0+15), NRT row tiles of 16.
+template <int NRT, bool DAG>
+__device__ __forceinline__ void product(const float2* __restrict__ M, int nt, int n, const float2* __restrict__ By, int col0, float sign,
+                                        f32x4 (&accR)[NRT], f32x4 (&accI)[NRT]) {
+  const int l = threadIdx.x & 63, r16 = l & 15, kq = l >> 4;
+  const int half = n >> 1;
+  for (int ks = 0; ks < n; ks += 4) {
+    const int k = ks + kq;                       // k < n because n % 4 == 0
+    const float2 b = By[(size_t)k * NB + col0 + r16];
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) {
+      const int i = rt * 16 + r16;
+      float2 a = make_float2(0.f, 0.f);
+      if (i < n) {
+        if constexpr (!DAG) a = M[tile_off_c(nt, i, k)];
+        else {
+          const float2 m = M[tile_off_c(nt, k, i)];
+          const float s = ((i >= half) != (k >= half)) ? -1.f : 1.f;   // G5 A^H G5
+          a = make_float2(s * m.x, -s * m.y);
+        }
+      }
+      a.x *= sign; a.y *= sign;
+      accR[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, accR[rt], 0, 0, 0);
+      accR[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-a.y, b.y, accR[rt], 0, 0, 0);
+      accI[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.y, accI[rt], 0, 0, 0);
+      accI[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.x, accI[rt], 0, 0, 0);
+    }
+  }
+}
+
+template <int NRT>
+__device__ __forceinline__ void store_tile(float2* __restrict__ out, int n, int col0, const f32x4 (&accR)[NRT], const f32x4 (&accI)[NRT]) {
+  const int l = threadIdx.x & 63, r16 = l & 15, kq = l >> 4;
+#pragma unroll
+  for (int rt = 0; rt < NRT; rt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int i = rt * 16 + 4 * kq + r;      // result row of register r
+      if (i < n) out[(size_t)i * NB + col0 + r16] = make_float2(accR[rt][r], accI[rt][r]);
+    }
+}
+
+// out[0][x] = M0 B(x) - sum over couplings that stay inside the aggregate;  out[1+mu][x] = + forward coupling in mu if
+// it leaves the aggregate, else 0.  One workgroup (4 wavefronts x 16 columns) per site.
+template <int NRT>
+__global__ __launch_bounds__(256) void coarse_batch_apply_kernel(float2* __restrict__ out, size_t out_stride, const float2* __restrict__ Vb,
+                                                                 CoarseOpDev<float> op, const unsigned char* __restrict__ agg_face) {
+  const int x = blockIdx.x, n = op.n, nt = op.nt;
+  const int col0 = (threadIdx.x >> 6) * 16;
+  const unsigned face = agg_face[x];
+  const float2* Mx = reinterpret_cast<const float2*>(op.M) + (size_t)x * 5 * op.msize;
+  f32x4 a0R[NRT], a0I[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; rt++) { a0R[rt] = f32x4{0, 0, 0, 0}; a0I[rt] = f32x4{0, 0, 0, 0}; }
+  product<NRT, false>(Mx, nt, n, Vb + (size_t)x * n * NB, col0, 1.f, a0R, a0I);
+  for (int mu = 0; mu < 4; mu++) {
+    const int yf = op.nb[(size_t)mu * op.V + x], yb = op.nb[(size_t)(4 + mu) * op.V + x];
+    f32x4 aR[NRT], aI[NRT];
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) { aR[rt] = f32x4{0, 0, 0, 0}; aI[rt] = f32x4{0, 0, 0, 0}; }
+    if (face & (1u << mu)) product<NRT, false>(Mx + (size_t)(1 + mu) * op.msize, nt, n, Vb + (size_t)yf * n * NB, col0, 1.f, aR, aI);
+    else product<NRT, false>(Mx + (size_t)(1 + mu) * op.msize, nt, n, Vb + (size_t)yf * n * NB, col0, -1.f, a0R, a0I);
+    store_tile<NRT>(out + (size_t)(1 + mu) * out_stride + (size_t)x * n * NB, n, col0, aR, aI);
+    if (!(face & (1u << (4 + mu))))
+      product<NRT, true>(reinterpret_cast<const float2*>(op.M) + ((size_t)yb * 5 + 1 + mu) * op.msize, nt, n, Vb + (size_t)yb * n * NB, col0, -1.f, a0R, a0I);
+  }
+  store_tile<NRT>(out + (size_t)x * n * NB, n, col0, a0R, a0I);
+}
+
+// restriction of the five batches with this level's P and direct store into the next level's matrices:
+// M_part(X)[i'][j] = sum over the aggregate X and the dofs of the chirality of i' of conj(P_{i' mod N}(x,k)) Y_part[x][k][j]
+__global__ __launch_bounds__(256) void coarse_batch_restrict_store_kernel(float* __restrict__ Mnext, int nt2, size_t msize2, const float2* __restrict__ Y,
+                                                                          size_t y_stride, const float* __restrict__ P, size_t pstride, int n, int N,
+                                                                          int agg_sites, const int* __restrict__ agg_csite) {
+  const int X = blockIdx.x, part = blockIdx.y;
+  const int j = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const int half = n >> 1, nc = 2 * N;
+  const float2* Yp = Y + (size_t)part * y_stride + (size_t)X * agg_sites * n * NB;
+  float2* Mp = reinterpret_cast<float2*>(Mnext) + ((size_t)agg_csite[X] * 5 + part) * msize2;
+  for (int ip = q; ip < nc; ip += 4) {
+    const int h = ip >= N, jj = ip - h * N;
+    const float* p = P + (size_t)jj * pstride + (size_t)X * agg_sites * n * 2;
+    float sr = 0.f, si = 0.f;
+    for (int xs = 0; xs < agg_sites; xs++)
+      for (int kk = 0; kk < half; kk++) {
+        const int k = h * half + kk;
+        const float pr = p[((size_t)xs * n + k) * 2], pi = p[((size_t)xs * n + k) * 2 + 1];
+        const float2 y = Yp[((size_t)xs * n + k) * NB + j];
+        sr += pr * y.x + pi * y.y;
+        si += pr * y.y - pi * y.x;
+      }
+    if (j < nc) Mp[tile_off_c(nt2, ip, j)] = make_float2(sr, si);
+  }
+}
+
+void coarse_galerkin_batched(CoarseOp<float>& next, const CoarseOp<float>& op, const CoarseTransfer<float>& ip,
+                             const unsigned char* d_agg_face, float* work, hipStream_t st) {
+  const int V = op.V(), n = op.n(), N = ip.nvec;
+  DDAMG_REQUIRE(coarse_galerkin_batch_available(n, 2 * N, op.distributed(), sizeof(float)), "batched coarse Galerkin: unsupported shape");
+  DDAMG_REQUIRE(next.n() == 2 * N && next.V() == ip.num_aggs, "batched coarse Galerkin: next level does not match the transfer operator");
+  const size_t bs = (size_t)V * n * NB;           // complex numbers per batch
+  float2* Vb = reinterpret_cast<float2*>(work);
+  float2* Y = Vb + bs;
+  hipLaunchKernelGGL(batch_input_kernel, dim3((unsigned)((bs + 255) / 256)), dim3(256), 0, st, Vb, ip.P, ip.pstride, V, n, N);
+  const CoarseOpDev<float> dev = op.dev();
+  const int nrt = (n + 15) / 16;
+  switch (nrt) {
+    case 1: hipLaunchKernelGGL((coarse_batch_apply_kernel<1>), dim3(V), dim3(256), 0, st, Y, bs, Vb, dev, d_agg_face); break;
+    case 2: hipLaunchKernelGGL((coarse_batch_apply_kernel<2>), dim3(V), dim3(256), 0, st, Y, bs, Vb, dev, d_agg_face); break;
+    case 3: hipLaunchKernelGGL((coarse_batch_apply_kernel<3>), dim3(V), dim3(256), 0, st, Y, bs, Vb, dev, d_agg_face); break;
+    default: hipLaunchKernelGGL((coarse_batch_apply_kernel<4>), dim3(V), dim3(256), 0, st, Y, bs, Vb, dev, d_agg_face); break;
+  }
+  DDAMG_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(coarse_batch_restrict_store_kernel, dim3(ip.num_aggs, 5), dim3(256), 0, st, next.matrices(), next.nt(), next.msize(), Y, bs,
+                     ip.P, ip.pstride, n, N, ip.agg_sites, ip.agg_csite);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace ddamg

@@ -1,5 +1,6 @@
 // mg.cpp -- see mg.h
 #include "mg.h"
+#include "coarse_batch.h"
 #include <chrono>
 #include <cstdlib>
 #include "setup_kernels.h"
@@ -116,6 +117,7 @@ Multigrid<T>::~Multigrid() {
   if (W_) (void)hipFree(W_);
   if (gal_W_) (void)hipFree(gal_W_);
   if (gal_C_) (void)hipFree(gal_C_);
+  if (gal_cwork_) (void)hipFree(gal_cwork_);
   if (cwork_) (void)hipFree(cwork_);
 }
 
@@ -307,7 +309,18 @@ void Multigrid<T>::build_coarse_operator(int l) {
         aggregate_dirac<T>(W_, lv.fip.interp_vector(j), chir, *lv.fop, lv.d_agg_face, st_);
         galerkin_column<T>(nx.cop, lv.fip, W_, chir * N + j, cwork_, st_);
       }
-  } else {
+  } else if constexpr (sizeof(T) == 4) {
+    if (!no_batch && coarse_galerkin_batch_available(lv.n, 2 * N, lv.cop.distributed(), sizeof(T))) {
+      // all 2*Nvec columns at once on the matrix cores (coarse_batch.hip)
+      if (!gal_cwork_) DDAMG_HIP_CHECK(hipMalloc(&gal_cwork_, sizeof(T) * coarse_galerkin_batch_work(lv_[1]->g->V, lv_[1]->n)));
+      coarse_galerkin_batched(nx.cop, lv.cop, lv.cip, lv.d_agg_face, gal_cwork_, st_);
+      if (nx.coarsest) nx.cop.compute_self_inverse(st_);
+      DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
+      tick("Galerkin coarse operator", t_start);
+      return;
+    }
+  }
+  if (l > 0) {
     // coarse_aggregate_self_couplings / coarse_aggregate_neighbor_couplings (src/coarse_operator_generic.c:238-285):
     // the same masked gather kernel as the operator itself, restricted with this level's P
     const int V = lv.g->V;
@@ -334,6 +347,7 @@ void Multigrid<T>::release_setup_workspace() {
   DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
   if (gal_W_) { DDAMG_HIP_CHECK(hipFree(gal_W_)); gal_W_ = nullptr; }
   if (gal_C_) { DDAMG_HIP_CHECK(hipFree(gal_C_)); gal_C_ = nullptr; }
+  if (gal_cwork_) { DDAMG_HIP_CHECK(hipFree(gal_cwork_)); gal_cwork_ = nullptr; }
 }
 
 template <typename T>

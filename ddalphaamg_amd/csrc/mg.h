@@ -84,6 +84,7 @@ class Multigrid {
   Comm* comm_ = nullptr;
   unsigned long long rng_stream_ = 0;
   T *gal_W_ = nullptr, *gal_C_ = nullptr;   // batched Galerkin workspace
+  T* gal_cwork_ = nullptr;                  // the same for coarse levels (sized for level 1, the largest)
   int gal_batch_ = 0;
  public:
   // wall-clock seconds per setup phase (stream-synchronised), filled when DDAMG_SETUP_TIMING is set
