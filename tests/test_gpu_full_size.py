@@ -99,3 +99,27 @@ def test_solve_host_and_device_vectors(ctx32):
     assert np.array_equal(yv.download(), x)
     for v in (xv, Dx, bv, yv):
         v.free()
+
+
+def test_four_level_hierarchy():
+    """MAX_MG_LEVELS = 4 (src/dd_alpha_amg_parameters.h:23): 16^4 -> 8^4 -> 4^4 -> 2^4 with K-cycles on both
+    intermediate levels converges like the shallower hierarchies"""
+    from bench import near_unit_gauge
+    Vl = 16 ** 4
+    p = api.default_params(); p.num_levels = 4
+    for mu in range(4):
+        for d in range(4):
+            p.local_lattice[d][mu] = 16 >> d; p.block_lattice[d][mu] = 2
+    for d in range(3):
+        p.num_vect[d] = 20 + 4 * d; p.post_smooth_iter[d] = 2; p.block_iter[d] = 4; p.setup_iter[d] = [3, 2, 2][d]
+    p.restart, p.max_restart, p.tol = 50, 20, 1e-10
+    p.coarse_iter, p.coarse_restart, p.coarse_tol = 100, 5, 5e-2
+    p.mixed_precision, p.method, p.m0, p.csw = 1, 2, -0.3, 1.0
+    p.test_vector_rng, p.rng_seed = 1, 3
+    ctx = dd.Context(p)
+    ctx.set_gauge(near_unit_gauge(Vl, 0.35, 5), anti_pbc=True)
+    ctx.setup(3)
+    b = np.zeros((Vl, 12, 2)); b[..., 0] = 1.0
+    x, it, cit, rr = ctx.solve(b, 1e-10)
+    assert rr < 1e-10 and it <= 16
+    ctx.close()
