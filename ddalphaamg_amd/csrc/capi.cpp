@@ -66,7 +66,7 @@ int ddamg_hip_create(const ddamg_hip_params* p, ddamg_hip_ctx** out) {
   DDAMG_HIP_CHECK(hipSetDevice(p->device));
   std::unique_ptr<ddamg_hip_ctx> c(new ddamg_hip_ctx);
   c->par = *p;
-  for (int mu = 0; mu < 4; mu++) if (c->par.process_grid[mu] < 1) { c->par.process_grid[mu] = 1; c->par.process_coords[mu] = 0; }
+  for (int mu = 0; mu < 4; mu++) if (c->par.process_grid[mu] < 1 && c->par.process_grid[mu] != -1) { c->par.process_grid[mu] = 1; c->par.process_coords[mu] = 0; }
   c->device = p->device;
   DDAMG_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   DDAMG_HIP_CHECK(hipEventCreate(&c->ev0));

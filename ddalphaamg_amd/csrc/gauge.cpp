@@ -158,7 +158,7 @@ double gauge_to_operator_dist(const Geometry& g, Comm* comm, const double* gauge
                               double* D_out, double* clover_out) {
   const int* L = g.L;
   const int V = g.V;
-  Field f; for (int i = 0; i < 4; i++) { f.L[i] = L[i]; f.h[i] = g.P[i] > 1 ? 1 : 0; }
+  Field f; for (int i = 0; i < 4; i++) { f.L[i] = L[i]; f.h[i] = g.split[i] ? 1 : 0; }
   int E[4]; size_t Ve = 1;
   for (int mu = 0; mu < 4; mu++) { E[mu] = L[mu] + 2 * f.h[mu]; Ve *= E[mu]; }
   std::vector<double> Ue(Ve * 72, 0.0);

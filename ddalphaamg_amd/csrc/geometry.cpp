@@ -8,7 +8,8 @@ void Geometry::build(const int L_[4], const int B_[4], const int A_[4], const in
   V = 1; block_sites = 1; agg_sites = 1; num_blocks = 1; num_aggs = 1;
   for (int mu = 0; mu < 4; mu++) {
     L[mu] = L_[mu]; B[mu] = B_[mu]; A[mu] = A_[mu];
-    P[mu] = P_ ? P_[mu] : 1; pc[mu] = pc_ ? pc_[mu] : 0;
+    P[mu] = P_ ? (P_[mu] == -1 ? 1 : P_[mu]) : 1; pc[mu] = pc_ ? pc_[mu] : 0;
+    split[mu] = P_ && (P_[mu] > 1 || P_[mu] == -1);
     DDAMG_REQUIRE(P[mu] >= 1 && pc[mu] >= 0 && pc[mu] < P[mu], "process coordinates outside the process grid");
     DDAMG_REQUIRE(L[mu] > 0 && B[mu] > 0 && A[mu] > 0, "lattice extents must be positive");
     DDAMG_REQUIRE(L[mu] % A[mu] == 0, "aggregate lattice must divide the local lattice");
@@ -91,7 +92,7 @@ void Geometry::build(const int L_[4], const int B_[4], const int A_[4], const in
         const bool leaves = nxt < 0 || nxt >= nblk[mu];
         q[mu] = (nxt + nblk[mu]) % nblk[mu];
         block_nb[(size_t)(sgn * 4 + mu) * num_blocks + bi] =
-            (leaves && P[mu] > 1) ? -1 : blk_of_coord[((q[0] * nblk[1] + q[1]) * nblk[2] + q[2]) * nblk[3] + q[3]];
+            (leaves && split[mu]) ? -1 : blk_of_coord[((q[0] * nblk[1] + q[1]) * nblk[2] + q[2]) * nblk[3] + q[3]];
       }
 
   // neighbour tables: periodic wrap inside the local volume where the direction is not split over
@@ -99,7 +100,7 @@ void Geometry::build(const int L_[4], const int B_[4], const int A_[4], const in
   nb.assign((size_t)8 * V, -1);
   for (int d = 0; d < 8; d++) face_sites[d].clear();
   for (int mu = 0; mu < 4; mu++)
-    if (P[mu] > 1) { face_sites[mu].assign(face_size(mu), -1); face_sites[4 + mu].assign(face_size(mu), -1); }
+    if (split[mu]) { face_sites[mu].assign(face_size(mu), -1); face_sites[4 + mu].assign(face_size(mu), -1); }
   std::vector<unsigned char> tile_is_boundary((V + 255) / 256, 0);
   for (int st = 0; st < V; st++) {
     for (int mu = 0; mu < 4; mu++) {
@@ -110,7 +111,7 @@ void Geometry::build(const int L_[4], const int B_[4], const int A_[4], const in
       nb[(size_t)mu * V + st] = site_of_lex[lex(cc)];
       cc[mu] = (x - 1 + L[mu]) % L[mu];
       nb[(size_t)(4 + mu) * V + st] = site_of_lex[lex(cc)];
-      if (P[mu] > 1) {
+      if (split[mu]) {
         if (x == L[mu] - 1) { nb[(size_t)mu * V + st] = -1 - slot; face_sites[mu][slot] = st; tile_is_boundary[st / 256] = 1; }
         if (x == 0) { nb[(size_t)(4 + mu) * V + st] = -1 - slot; face_sites[4 + mu][slot] = st; tile_is_boundary[st / 256] = 1; }
       }

@@ -19,6 +19,8 @@ struct Geometry {
   int A[4];   // aggregate (coarsening) lattice; == L on the coarsest level
   int P[4];   // process grid (1,1,1,1 on a single GPU)
   int pc[4];  // my process coordinates
+  bool split[4] = {false, false, false, false};  // couplings across the +-mu faces go through the halo transport: P[mu] > 1, or
+                                                 // forced with one process (a process grid entry of -1: the process is its own neighbour)
   int V = 0, block_sites = 0, num_blocks = 0, agg_sites = 0, num_aggs = 0;
   int nblk[4];  // blocks per direction in the local lattice
   int nagg[4];  // aggregates per direction in the local lattice
@@ -47,7 +49,7 @@ struct Geometry {
   std::vector<unsigned char> agg_face;  // [V] bit d set: the neighbour in direction d lies outside the site's aggregate
 
   void build(const int L_[4], const int B_[4], const int A_[4], const int* P_ = nullptr, const int* pc_ = nullptr);
-  bool distributed() const { return nranks > 1; }
+  bool distributed() const { return split[0] || split[1] || split[2] || split[3]; }
   int face_size(int mu) const { return V / L[mu]; }
   int slot_of(const int c[4], int mu) const {  // lexicographic index over the three directions != mu
     int idx = 0;

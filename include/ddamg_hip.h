@@ -50,7 +50,9 @@ typedef struct ddamg_hip_params {
   int device;                                  /* HIP device ordinal                          */
   /* domain decomposition over GPUs: one process per GPU on a Cartesian grid (reference: g.process_grid and
    * the MPI_Cart communicator, src/init.c:455-520 + src/data_layout.c:23-60).  rank = ((pt*Pz+pz)*Py+py)*Px+px.
-   * local_lattice[] is the per-process lattice.  All 1 / 0: single GPU. */
+   * local_lattice[] is the per-process lattice.  All 1 / 0: single GPU.  An entry of -1 means one process in that
+   * direction whose +-mu faces nevertheless go through the transport (the process is its own neighbour): the complete
+   * multi-GPU code path, RCCL included, on a single GPU -- for tests. */
   int process_grid[4];
   int process_coords[4];
   /* random test vectors of the setup: 0 = libc rand() consumed in the reference's order (src/data_generic.c:42-56;

@@ -1,0 +1,95 @@
+"""The multi-GPU code path on ONE GPU (-m gpu): a process-grid entry of -1 makes the process its own neighbour in that
+direction, so every coupling across the lattice boundary goes through pack -> transport -> halo kernels instead of the
+periodic wrap.  With the RCCL transport this exercises ncclCommInitRank, grouped ncclSend/ncclRecv, ncclAllReduce and
+the stream/event ordering for real (the multi-process tests have to use the host transport, because RCCL refuses two
+ranks on one device).  Results must equal the ordinary single-GPU ones."""
+import os, subprocess, sys
+import numpy as np
+import pytest
+from conftest import relerr
+from ddalphaamg_amd import api
+import ddalphaamg_amd as dd
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def params(gold8, grid, levels=1, mp=1):
+    p = api.default_params(); p.num_levels = levels
+    for mu in range(4):
+        p.local_lattice[0][mu] = 8; p.block_lattice[0][mu] = 2
+        p.local_lattice[1][mu] = 4; p.block_lattice[1][mu] = 2
+        p.local_lattice[2][mu] = 2
+        p.process_grid[mu] = grid[mu]
+    p.num_vect[0] = p.num_vect[1] = 16
+    p.setup_iter[0] = 2; p.setup_iter[1] = 2
+    p.restart, p.max_restart, p.tol = 30, 20, 1e-10
+    p.coarse_iter, p.coarse_restart, p.coarse_tol = 50, 10, 5e-2
+    p.mixed_precision, p.method = mp, 2
+    p.m0, p.csw = float(gold8["meta_f64"][0]), float(gold8["meta_f64"][1])
+    p.test_vector_rng, p.rng_seed = 1, 11
+    return p
+
+
+@pytest.mark.parametrize("grid", [[-1, 1, 1, 1], [1, -1, 1, -1], [-1, -1, -1, -1]])
+def test_dirac_and_gauge_through_rccl_self_exchange(gold8, grid):
+    ctx = dd.Context(params(gold8, grid))
+    ctx.comm_init_rccl(api.rccl_unique_id())
+    plaq = ctx.set_gauge(gold8["gauge"], anti_pbc=True)          # halo of links (corners included) through RCCL
+    assert abs(plaq - float(gold8["meta_f64"][2])) < 1e-12
+    D, cl = ctx.get_operator()
+    assert np.array_equal(D[::97], gold8["D_sample"]) and relerr(cl[::97], gold8["clover_sample"]) < 1e-14
+    for prec, ref, tol in ((64, "dirac_out_f64", 1e-13), (32, "dirac_out_f32_as_f64", 2e-6)):
+        x = ctx.vector(0, prec).upload(gold8["dirac_in"]); y = ctx.vector(0, prec)
+        for _ in range(3):
+            ctx.dirac_apply(y, x)
+        assert relerr(y.download(), gold8[ref]) < tol
+        x.free(); y.free()
+    ctx.close()
+
+
+@pytest.mark.parametrize("levels", [2, 3])
+def test_amg_solve_through_rccl_self_exchange(gold8, levels):
+    """smoother, Galerkin construction, coarse operator, K-cycle, coarsest solve and the reductions, all through RCCL"""
+    b = np.zeros((4096, 12, 2)); b[..., 0] = 1.0
+    res = []
+    for grid in ([1, 1, 1, 1], [-1, -1, -1, -1]):
+        ctx = dd.Context(params(gold8, grid, levels))
+        if grid[0] == -1:
+            ctx.comm_init_rccl(api.rccl_unique_id())
+        ctx.set_gauge(gold8["gauge"], anti_pbc=True)
+        ctx.setup(2)
+        x, it, cit, rr = ctx.solve(b, 1e-10)
+        res.append((x, it, cit, rr))
+        ctx.close()
+    (x0, it0, cit0, rr0), (x1, it1, cit1, rr1) = res
+    assert rr1 < 1e-10 and abs(it1 - it0) <= 1
+    assert relerr(x1, x0) < 1e-7
+
+
+def test_rccl_self_exchange_inside_a_torch_process():
+    """the same with torch imported first: libddamg_hip.so then resolves to the HIP runtime and the RCCL that torch
+    bundles (the configuration bench.py runs in)"""
+    code = f"""
+import sys, numpy as np, torch
+sys.path.insert(0, {os.path.dirname(HERE)!r}); sys.path.insert(0, {HERE!r})
+from conftest import load_golden, relerr
+from ddalphaamg_amd import api
+import ddalphaamg_amd as dd
+g = load_golden("ref_8x8_dirac.npz")
+p = api.default_params(); p.num_levels = 1
+for mu in range(4):
+    p.local_lattice[0][mu] = 8; p.block_lattice[0][mu] = 4; p.process_grid[mu] = -1
+p.m0, p.csw = float(g["meta_f64"][0]), float(g["meta_f64"][1])
+ctx = dd.Context(p)
+ctx.comm_init_rccl(api.rccl_unique_id())
+ctx.set_gauge(g["gauge"], anti_pbc=True)
+x = ctx.vector(0, 64).upload(g["dirac_in"]); y = ctx.vector(0, 64)
+ctx.dirac_apply(y, x)
+err = relerr(y.download(), g["dirac_out_f64"])
+maps = open("/proc/self/maps").read()
+print("TORCH_RCCL_OK" if err < 1e-13 else "MISMATCH", err, "torch rccl" if "torch/lib/librccl" in maps else "system rccl")
+ctx.close()
+"""
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "TORCH_RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
