@@ -174,6 +174,10 @@ def main():
     ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
                     help="halo transport for --gpus > 1; 'host' (gloo, staged through pinned memory) lets several "
                          "processes share one card for a rehearsal and is never the reported configuration")
+    ap.add_argument("--self-exchange", default=None,
+                    help="single GPU only, e.g. -1,-1,-1,1: run the fine operator through the multi-GPU machinery with the process "
+                         "as its own neighbour in the directions marked -1 (RCCL transport): cost of pack + exchange + "
+                         "interior/boundary split, not a reported configuration")
     args = ap.parse_args()
 
     import torch
@@ -204,7 +208,12 @@ def main():
     phi = splitmix_uniform(V * 24, 1234 + rank).reshape(V, 12, 2)
     halo_check = None
     if world == 1:
+        if args.self_exchange:
+            for mu, v in enumerate(int(x) for x in args.self_exchange.split(",")):
+                p.process_grid[mu] = v
         ctx = dd.Context(p)
+        if args.self_exchange:
+            ctx.comm_init_rccl(api.rccl_unique_id())
         ctx.set_gauge(U, anti_pbc=True)
         grid = [1, 1, 1, 1]
     else:
@@ -266,7 +275,7 @@ def main():
                                    "random SU(3) gauge, csw=1.0, anti-periodic T",
                        "flop_per_site": FLOP_PER_SITE,
                        "parallelism": ("domain decomposition, process grid " + "x".join(map(str, grid)) + " (T,Z,Y,X), " + args.transport.upper() + " halo exchange "
-                                       "overlapped with the interior tiles") if world > 1 else "single",
+                                       "overlapped with the interior tiles") if world > 1 else ("single" if not args.self_exchange else "single GPU, self-exchange " + args.self_exchange + " through RCCL"),
                        "halo_check_vs_host_transport": halo_check},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.precision),
