@@ -93,7 +93,7 @@ __device__ __forceinline__ int tile_neighbor(const int* __restrict__ nb, size_t 
   }
 }
 
-template <typename T, int MU, bool ARITH>
+template <typename T, int MU, bool ARITH, bool DEFER>
 __device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOpDev<T>& op, size_t s, bool live, int tile0, const uint4& q,
                                          const T (&p)[24], T (&e)[24], T* __restrict__ sp, T* __restrict__ hb) {
   const size_t V = op.V;
@@ -121,7 +121,7 @@ __device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOp
       }
       hop_accumulate<T, MU, true>(U, pn, e);
     } else {
-      halo_forward<T, MU>(op, -1 - j, U, e);
+      if constexpr (!DEFER) halo_forward<T, MU>(op, -1 - j, U, e);   // DEFER: added by halo_fixup_kernel after the exchange
     }
   }
   __syncthreads();
@@ -129,7 +129,7 @@ __device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOp
   if (live) {
     const int j = tile_neighbor<ARITH>(op.nb, V, s, 4 + MU, tile0, q, op.tile_nb, (int)(V >> 8));
     if (j < 0) {
-      halo_backward<T, MU>(op, -1 - j, e);
+      if constexpr (!DEFER) halo_backward<T, MU>(op, -1 - j, e);
     } else if (j - tile0 >= 0 && j - tile0 < 256) {
       T g[12];
 #pragma unroll
@@ -145,7 +145,7 @@ __device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOp
   __syncthreads();
 }
 
-template <typename T, bool ARITH>
+template <typename T, bool ARITH, bool DEFER>
 __global__ __launch_bounds__(256, 3) void dirac_apply_lds_kernel(T* __restrict__ eta, const T* __restrict__ phi, FineOpDev<T> op, int ntiles,
                                                                   const int* __restrict__ tile_list) {
   __shared__ T sp[24 * 256];
@@ -177,11 +177,39 @@ __global__ __launch_bounds__(256, 3) void dirac_apply_lds_kernel(T* __restrict__
     herm6_mul<T>(cl, p + 12, e + 12);
   }
   __syncthreads();
-  tile_dir<T, 0, ARITH>(phi, op, s, live, tile0, q, p, e, sp, hb);
-  tile_dir<T, 1, ARITH>(phi, op, s, live, tile0, q, p, e, sp, hb);
-  tile_dir<T, 2, ARITH>(phi, op, s, live, tile0, q, p, e, sp, hb);
-  tile_dir<T, 3, ARITH>(phi, op, s, live, tile0, q, p, e, sp, hb);
+  tile_dir<T, 0, ARITH, DEFER>(phi, op, s, live, tile0, q, p, e, sp, hb);
+  tile_dir<T, 1, ARITH, DEFER>(phi, op, s, live, tile0, q, p, e, sp, hb);
+  tile_dir<T, 2, ARITH, DEFER>(phi, op, s, live, tile0, q, p, e, sp, hb);
+  tile_dir<T, 3, ARITH, DEFER>(phi, op, s, live, tile0, q, p, e, sp, hb);
   if (live) store_site<T, 24, DDAMG_NT_STORE>(eta, V, s, e);
+}
+
+// the couplings to sites on other GPUs, added after the exchange: one thread per boundary site (a site on an edge or
+// corner of the local lattice takes all its off-process directions here, so no two threads touch the same site)
+template <typename T, int MU>
+__device__ __forceinline__ void fixup_dir(const FineOpDev<T>& op, size_t s, T (&e)[24]) {
+  const size_t V = op.V;
+  const int jf = op.nb[(size_t)MU * V + s];
+  if (jf < 0) {
+    T U[18];
+    load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, s, U);
+    halo_forward<T, MU>(op, -1 - jf, U, e);
+  }
+  const int jb = op.nb[(size_t)(4 + MU) * V + s];
+  if (jb < 0) halo_backward<T, MU>(op, -1 - jb, e);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void halo_fixup_kernel(T* __restrict__ eta, FineOpDev<T> op, const int* __restrict__ sites, int nsites) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= nsites) return;
+  const size_t s = (size_t)sites[i];
+  T e[24];
+  load_site<T, 24>(eta, op.V, s, e);
+  fixup_dir<T, 0>(op, s, e);
+  fixup_dir<T, 1>(op, s, e);
+  fixup_dir<T, 2>(op, s, e);
+  fixup_dir<T, 3>(op, s, e);
+  store_site<T, 24>(eta, op.V, s, e);
 }
 
 static int g_dirac_variant = -1;  // 0: gather/cache kernel, 1: LDS-tiled kernel (default)
@@ -196,8 +224,8 @@ void FineOp<T>::apply(T* eta, const T* phi, hipStream_t st) const {
   auto launch = [&](int ntiles, const int* tile_list) {
     if (ntiles == 0) return;
     if (g_dirac_variant == 0) hipLaunchKernelGGL(dirac_apply_kernel<T>, dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), tile_list);
-    else if (tnb_ && g_dirac_variant != 4) hipLaunchKernelGGL((dirac_apply_lds_kernel<T, true>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, tile_list);
-    else hipLaunchKernelGGL((dirac_apply_lds_kernel<T, false>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, tile_list);
+    else if (tnb_ && g_dirac_variant != 4) hipLaunchKernelGGL((dirac_apply_lds_kernel<T, true, false>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, tile_list);
+    else hipLaunchKernelGGL((dirac_apply_lds_kernel<T, false, false>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, tile_list);
     DDAMG_HIP_CHECK(hipGetLastError());
   };
   if (!halo_.active()) {
@@ -205,8 +233,25 @@ void FineOp<T>::apply(T* eta, const T* phi, hipStream_t st) const {
     return;
   }
   // reference order of events: src/dirac_generic.c:178-262 (project+send, interior work, wait, boundary)
+  static const bool defer = getenv("DDAMG_HALO_DEFER") != nullptr;
   halo_.pack(phi, D_, V_, st);
   halo_.exchange_begin(comm_, st);
+  if (g_dirac_variant != 0 && defer) {
+    // alternative (DDAMG_HALO_DEFER): the whole lattice in one launch with the off-process couplings left out -- it
+    // overlaps with the complete exchange -- then a short pass over the boundary sites adds them.  Measured with the
+    // self-exchange mode at 32^4, three directions: 249 us against 237 us for the split below (the transport's copy
+    // kernel competes with the full-lattice launch for CUs and ends after it), so the split is the default.
+    const int ntiles = (V_ + 255) / 256;
+    if (tnb_ && g_dirac_variant != 4) hipLaunchKernelGGL((dirac_apply_lds_kernel<T, true, true>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, (const int*)nullptr);
+    else hipLaunchKernelGGL((dirac_apply_lds_kernel<T, false, true>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, (const int*)nullptr);
+    DDAMG_HIP_CHECK(hipGetLastError());
+    halo_.exchange_finish(comm_, st);
+    const int nbs = halo_.n_boundary_sites();
+    hipLaunchKernelGGL(halo_fixup_kernel<T>, dim3((nbs + 255) / 256), dim3(256), 0, st, eta, dev(), halo_.boundary_sites(), nbs);
+    DDAMG_HIP_CHECK(hipGetLastError());
+    return;
+  }
+  // default: tiles without an off-process neighbour during the exchange, the others after it
   launch(halo_.n_interior(), halo_.interior_tiles());
   halo_.exchange_finish(comm_, st);
   launch(halo_.n_boundary(), halo_.boundary_tiles());

@@ -71,6 +71,8 @@ class Halo {
   const int* boundary_tiles() const { return d_boundary_; }
   int n_interior() const { return n_interior_; }
   int n_boundary() const { return n_boundary_; }
+  const int* boundary_sites() const { return d_bsites_; }   // sites with at least one neighbour on another process
+  int n_boundary_sites() const { return n_bsites_; }
   // pack kernel: fills the send arena from phi (needs the links: D = FineOpDev::D)
   void pack(const T* phi, const T* D, int V, hipStream_t st);
   void exchange_begin(Comm* c, hipStream_t st) { arena_.exchange_begin(c, st); }
@@ -81,6 +83,7 @@ class Halo {
   HaloArena arena_;
   int* d_interior_ = nullptr; int* d_boundary_ = nullptr;
   int n_interior_ = 0, n_boundary_ = 0;
+  int* d_bsites_ = nullptr; int n_bsites_ = 0;
 };
 
 }  // namespace ddamg

@@ -52,6 +52,14 @@ void comm_allreduce(Comm* c, double* d_buf, int n, hipStream_t st) {
   }
 }
 
+// the transport stream gets the highest priority: its (few, small) kernels must not queue behind the operator kernels
+// they overlap with
+static void create_transport_stream(hipStream_t* st) {
+  int lo = 0, hi = 0;
+  DDAMG_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+  DDAMG_HIP_CHECK(hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi));
+}
+
 void comm_sendrecv_host(Comm* c, const void* send, int send_peer, void* recv, int recv_peer, size_t bytes, int tag) {
   DDAMG_REQUIRE(c != nullptr, "process grid > 1 but no transport: call ddamg_hip_comm_init_rccl or ddamg_hip_comm_init_host first");
   if (c->kind == 2) {
@@ -101,7 +109,7 @@ Comm* comm_create_rccl(const Geometry& g, const void* id128) {
   c->kind = 1; c->rank = g.rank; c->nranks = g.nranks;
   ncclUniqueId id;
   memcpy(&id, id128, sizeof id);
-  DDAMG_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  create_transport_stream(&c->stream);
   DDAMG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
   DDAMG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
   DDAMG_NCCL_CHECK(ncclCommInitRank(&c->nccl, g.nranks, id, g.rank));
@@ -111,7 +119,7 @@ Comm* comm_create_host(const Geometry& g, ddamg_hip_exchange_fn fn, ddamg_hip_al
   DDAMG_REQUIRE(fn != nullptr, "exchange callback is null");
   Comm* c = new Comm;
   c->kind = 2; c->rank = g.rank; c->nranks = g.nranks; c->fn = fn; c->reduce_fn = reduce_fn; c->user = user;
-  DDAMG_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  create_transport_stream(&c->stream);
   return c;
 }
 void comm_destroy(Comm* c) {
@@ -274,12 +282,19 @@ void Halo<T>::init(const Geometry& g) {
     DDAMG_HIP_CHECK(hipMalloc(&d_boundary_, sizeof(int) * n_boundary_));
     DDAMG_HIP_CHECK(hipMemcpy(d_boundary_, g.boundary_tiles.data(), sizeof(int) * n_boundary_, hipMemcpyHostToDevice));
   }
+  std::vector<int> bs;
+  for (int s = 0; s < g.V; s++)
+    for (int d = 0; d < 8; d++) if (g.nb[(size_t)d * g.V + s] < 0) { bs.push_back(s); break; }
+  n_bsites_ = (int)bs.size();
+  DDAMG_HIP_CHECK(hipMalloc(&d_bsites_, sizeof(int) * n_bsites_));
+  DDAMG_HIP_CHECK(hipMemcpy(d_bsites_, bs.data(), sizeof(int) * n_bsites_, hipMemcpyHostToDevice));
 }
 
 template <typename T>
 Halo<T>::~Halo() {
   if (d_interior_) (void)hipFree(d_interior_);
   if (d_boundary_) (void)hipFree(d_boundary_);
+  if (d_bsites_) (void)hipFree(d_bsites_);
 }
 
 template <typename T>
