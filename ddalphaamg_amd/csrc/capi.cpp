@@ -68,7 +68,12 @@ int ddamg_hip_create(const ddamg_hip_params* p, ddamg_hip_ctx** out) {
   c->par = *p;
   for (int mu = 0; mu < 4; mu++) if (c->par.process_grid[mu] < 1 && c->par.process_grid[mu] != -1) { c->par.process_grid[mu] = 1; c->par.process_coords[mu] = 0; }
   c->device = p->device;
-  DDAMG_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  {
+    bool grid = false;
+    for (int mu = 0; mu < 4; mu++) grid = grid || p->process_grid[mu] > 1 || p->process_grid[mu] == -1;
+    if (grid && comm_cus_from_env() > 0) DDAMG_HIP_CHECK(create_cu_masked_stream(&c->stream, comm_cus_from_env(), false));
+    else DDAMG_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+  }
   DDAMG_HIP_CHECK(hipEventCreate(&c->ev0));
   DDAMG_HIP_CHECK(hipEventCreate(&c->ev1));
   for (int d = 0; d < p->num_levels; d++) {

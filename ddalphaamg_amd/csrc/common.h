@@ -37,6 +37,31 @@
 
 namespace ddamg {
 
+// Streams confined to a subset of the compute units, used on a process grid: the transport stream gets n CUs of its own
+// and the compute stream the rest, so that the transport's copy kernels do not wait for CU slots behind the kernels they
+// are meant to overlap with.  Measured with the self-exchange mode (32^4, three directions through RCCL): the RCCL
+// kernel drops from 94 to 48 us and the operator apply from 237 to ~205 us with 24-32 reserved CUs; fewer than 16 or
+// more than 40 is worse.  DDAMG_COMM_CUS overrides the count (0: plain streams).
+// reserved == true: the n reserved CUs; false: all others.
+inline hipError_t create_cu_masked_stream(hipStream_t* st, int n_reserved, bool reserved) {
+  hipDeviceProp_t prop;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return e;
+  e = hipGetDeviceProperties(&prop, dev);
+  if (e != hipSuccess) return e;
+  const int ncu = prop.multiProcessorCount;
+  const int words = (ncu + 31) / 32;
+  uint32_t mask[32] = {0};
+  for (int cu = 0; cu < ncu; cu++) {
+    const bool is_res = cu < n_reserved;     // the mask bits are dealt round-robin over the XCDs: the first n bits spread evenly
+    if (is_res == reserved) mask[cu / 32] |= 1u << (cu % 32);
+  }
+  return hipExtStreamCreateWithCUMask(st, (uint32_t)words, mask);
+}
+inline int comm_cus_from_env() { const char* e = getenv("DDAMG_COMM_CUS"); return e ? atoi(e) : 24; }
+
+
 enum { DIR_T = 0, DIR_Z = 1, DIR_Y = 2, DIR_X = 3 };  // reference src/clifford.h:33
 
 template <typename T> struct Chunk;

@@ -55,6 +55,7 @@ void comm_allreduce(Comm* c, double* d_buf, int n, hipStream_t st) {
 // the transport stream gets the highest priority: its (few, small) kernels must not queue behind the operator kernels
 // they overlap with
 static void create_transport_stream(hipStream_t* st) {
+  if (comm_cus_from_env() > 0) { DDAMG_HIP_CHECK(create_cu_masked_stream(st, comm_cus_from_env(), true)); return; }
   int lo = 0, hi = 0;
   DDAMG_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
   DDAMG_HIP_CHECK(hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi));
