@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--nvec1", type=int, default=28)
     ap.add_argument("--mixed-precision", type=int, default=1)
     ap.add_argument("--gauge", default="near_unit", choices=["near_unit", "random"])
+    ap.add_argument("--self-exchange", default=None, help="e.g. -1,-1,-1,1: the process is its own neighbour in these directions (RCCL)")
     ap.add_argument("--rng", type=int, default=1, help="0: libc rand() in the reference's order, 1: device generator")
     args = ap.parse_args()
     import ddalphaamg_amd as dd
@@ -46,7 +47,12 @@ def main():
     p.mixed_precision, p.method, p.odd_even = args.mixed_precision, 2, 1
     p.m0, p.csw = args.m0, args.csw
     p.test_vector_rng, p.rng_seed = args.rng, 20260101
+    if args.self_exchange:
+        for mu, v in enumerate(int(x) for x in args.self_exchange.split(",")):
+            p.process_grid[mu] = v
     ctx = dd.Context(p)
+    if args.self_exchange:
+        ctx.comm_init_rccl(api.rccl_unique_id())
     t0 = time.time()
     if args.gauge == "near_unit":
         U = near_unit_gauge(V, args.eps, 20260101)
@@ -61,7 +67,9 @@ def main():
     print(f"setup: {t1-t0:.2f}s (coarse its {ci})", flush=True)
     b = np.zeros((V, 12, 2)); b[..., 0] = 1.0
     for s in range(args.solves):
-        t0 = time.time(); x, it, cit, rr = ctx.solve(b, 1e-10); t1 = time.time()
+        bv = ctx.vector(0, 64).upload(b); xv = ctx.vector(0, 64)
+        t0 = time.time(); it, cit, rr = ctx.solve_vec(xv, bv, 1e-10); t1 = time.time()
+        bv.free(); xv.free()
         print(json.dumps({"solve_s": t1 - t0, "iters": it, "coarse_iters": cit, "coarse_avg": cit / max(it, 1), "relres": rr}), flush=True)
     print("history", " ".join(f"{h:.3e}" for h in ctx.residual_history()))
     ctx.close()
