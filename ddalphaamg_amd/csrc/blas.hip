@@ -16,10 +16,10 @@ static inline int grid_for(size_t nchunks) {
 
 void ReduceWork::init(int max_m_) {
   max_m = max_m_; max_blocks = MAX_GRID;
-  DDAMG_HIP_CHECK(hipMalloc(&d_partial, sizeof(double) * (size_t)max_blocks * 2 * (max_m + 2)));
-  DDAMG_HIP_CHECK(hipMalloc(&d_result, sizeof(double) * (2 * max_m + 8)));
+  DDAMG_HIP_CHECK(device_alloc(&d_partial, sizeof(double) * (size_t)max_blocks * 2 * (max_m + 2)));
+  DDAMG_HIP_CHECK(device_alloc(&d_result, sizeof(double) * (2 * max_m + 8)));
   DDAMG_HIP_CHECK(hipHostMalloc(&h_result, sizeof(double) * (2 * max_m + 8), hipHostMallocDefault));
-  DDAMG_HIP_CHECK(hipMalloc(&d_coef, sizeof(double) * (2 * max_m + 8)));
+  DDAMG_HIP_CHECK(device_alloc(&d_coef, sizeof(double) * (2 * max_m + 8)));
   DDAMG_HIP_CHECK(hipHostMalloc(&h_coef, sizeof(double) * (2 * max_m + 8), hipHostMallocDefault));
 }
 void ReduceWork::destroy() {

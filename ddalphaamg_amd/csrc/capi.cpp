@@ -25,7 +25,7 @@ thread_local std::string g_ddamg_last_error;
 double* ddamg_hip_ctx::stage(size_t bytes) {
   if (bytes > stage_bytes) {
     if (d_stage) DDAMG_HIP_CHECK(hipFree(d_stage));
-    DDAMG_HIP_CHECK(hipMalloc(&d_stage, bytes));
+    DDAMG_HIP_CHECK(device_alloc(&d_stage, bytes));
     stage_bytes = bytes;
   }
   return d_stage;
@@ -102,7 +102,7 @@ int ddamg_hip_create(const ddamg_hip_params* p, ddamg_hip_ctx** out) {
       }
     }
     lv->geom.build(p->local_lattice[d], B, A, c->par.process_grid, c->par.process_coords);
-    DDAMG_HIP_CHECK(hipMalloc(&lv->d_lex_of_site, sizeof(int) * lv->geom.V));
+    DDAMG_HIP_CHECK(device_alloc(&lv->d_lex_of_site, sizeof(int) * lv->geom.V));
     DDAMG_HIP_CHECK(hipMemcpy(lv->d_lex_of_site, lv->geom.lex_of_site.data(), sizeof(int) * lv->geom.V, hipMemcpyHostToDevice));
     c->levels.push_back(std::move(lv));
   }
@@ -238,7 +238,7 @@ int ddamg_hip_vec_create(ddamg_hip_ctx* c, int level, int precision, ddamg_hip_v
   v->V = c->levels[level]->geom.V;
   v->aos = level > 0 ? 1 : 0;
   v->bytes = (size_t)v->V * v->ndof * 2 * (precision / 8);
-  DDAMG_HIP_CHECK(hipMalloc(&v->data, v->bytes));
+  DDAMG_HIP_CHECK(device_alloc(&v->data, v->bytes));
   DDAMG_HIP_CHECK(hipMemsetAsync(v->data, 0, v->bytes, c->stream));
   *out = v.release();
   DDAMG_API_END

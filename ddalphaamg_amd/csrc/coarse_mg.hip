@@ -35,10 +35,10 @@ void CoarseTransfer<T>::alloc(const Geometry& g, const Geometry& gc, int n_, int
   V = g.V; n = n_; nvec = nvec_; num_aggs = g.num_aggs; agg_sites = g.agg_sites;
   DDAMG_REQUIRE(gc.V == g.num_aggs, "coarse lattice does not match the aggregate decomposition");
   pstride = (size_t)V * n * 2;
-  DDAMG_HIP_CHECK(hipMalloc(&agg_csite, sizeof(int) * num_aggs));
+  DDAMG_HIP_CHECK(device_alloc(&agg_csite, sizeof(int) * num_aggs));
   DDAMG_HIP_CHECK(hipMemcpy(agg_csite, gc.site_of_lex.data(), sizeof(int) * num_aggs, hipMemcpyHostToDevice));
-  DDAMG_HIP_CHECK(hipMalloc(&tv, sizeof(T) * pstride * nvec));
-  DDAMG_HIP_CHECK(hipMalloc(&P, sizeof(T) * pstride * nvec));
+  DDAMG_HIP_CHECK(device_alloc(&tv, sizeof(T) * pstride * nvec));
+  DDAMG_HIP_CHECK(device_alloc(&P, sizeof(T) * pstride * nvec));
   DDAMG_HIP_CHECK(hipMemset(tv, 0, sizeof(T) * pstride * nvec));
   DDAMG_HIP_CHECK(hipMemset(P, 0, sizeof(T) * pstride * nvec));
 }
@@ -227,7 +227,7 @@ void CoarseSap<T>::setup(const Geometry& g, const CoarseOp<T>* op, int block_ite
   op_ = op; V_ = g.V; n_ = op->n(); BS_ = g.block_sites; block_iter_ = block_iter;
   for (int mu = 0; mu < 4; mu++) DDAMG_REQUIRE((g.nblk[mu] * g.P[mu]) % 2 == 0, "red-black SAP needs an even number of blocks per direction of the global lattice");
   const size_t nel = (size_t)V_ * n_ * 2;
-  for (T** p : {&r, &latest, &x, &tmp}) { DDAMG_HIP_CHECK(hipMalloc(p, sizeof(T) * nel)); DDAMG_HIP_CHECK(hipMemsetAsync(*p, 0, sizeof(T) * nel, st)); }
+  for (T** p : {&r, &latest, &x, &tmp}) { DDAMG_HIP_CHECK(device_alloc(p, sizeof(T) * nel)); DDAMG_HIP_CHECK(hipMemsetAsync(*p, 0, sizeof(T) * nel, st)); }
   std::vector<int> bl[3], sl[3];
   for (int b = 0; b < g.num_blocks; b++) {
     const int c = g.block_color[b];
@@ -238,13 +238,13 @@ void CoarseSap<T>::setup(const Geometry& g, const CoarseOp<T>* op, int block_ite
     for (int b : bl[i]) for (int k = 0; k < BS_; k++) sl[i].push_back(b * BS_ + k);
     nblk_[i] = (int)bl[i].size();
     if (nblk_[i] == 0) continue;
-    DDAMG_HIP_CHECK(hipMalloc(&d_blocks_[i], sizeof(int) * bl[i].size()));
+    DDAMG_HIP_CHECK(device_alloc(&d_blocks_[i], sizeof(int) * bl[i].size()));
     DDAMG_HIP_CHECK(hipMemcpyAsync(d_blocks_[i], bl[i].data(), sizeof(int) * bl[i].size(), hipMemcpyHostToDevice, st));
-    DDAMG_HIP_CHECK(hipMalloc(&d_sites_[i], sizeof(int) * sl[i].size()));
+    DDAMG_HIP_CHECK(device_alloc(&d_sites_[i], sizeof(int) * sl[i].size()));
     DDAMG_HIP_CHECK(hipMemcpyAsync(d_sites_[i], sl[i].data(), sizeof(int) * sl[i].size(), hipMemcpyHostToDevice, st));
   }
   DDAMG_REQUIRE(nblk_[0] > 0 && nblk_[1] > 0, "red-black SAP needs blocks of both colours");
-  DDAMG_HIP_CHECK(hipMalloc(&d_blk_face_, V_));
+  DDAMG_HIP_CHECK(device_alloc(&d_blk_face_, V_));
   DDAMG_HIP_CHECK(hipMemcpyAsync(d_blk_face_, g.blk_face.data(), V_, hipMemcpyHostToDevice, st));
   DDAMG_HIP_CHECK(hipStreamSynchronize(st));
 }

@@ -37,6 +37,20 @@
 
 namespace ddamg {
 
+// Every device allocation of the library goes through here.  DDAMG_POISON=1 fills fresh allocations with 0xFF bytes
+// (NaN as float/double, -1 as int): a read of memory the library has not written itself then poisons the result
+// instead of going unnoticed (device memory handed out by the driver is usually zero, sometimes recycled).
+template <typename P>
+inline hipError_t device_alloc(P** p, size_t bytes) {
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(p), bytes);
+  static const bool poison = getenv("DDAMG_POISON") != nullptr;
+  if (e == hipSuccess && poison && bytes) {
+    e = hipMemset(*p, 0xFF, bytes);
+    if (e == hipSuccess) e = hipDeviceSynchronize();   // the library's streams do not synchronise with the null stream
+  }
+  return e;
+}
+
 // Streams confined to a subset of the compute units, used on a process grid: the transport stream gets n CUs of its own
 // and the compute stream the rest, so that the transport's copy kernels do not wait for CU slots behind the kernels they
 // are meant to overlap with.  Measured with the self-exchange mode (32^4, three directions through RCCL): the RCCL

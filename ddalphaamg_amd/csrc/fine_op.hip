@@ -340,18 +340,18 @@ void FineOp<T>::upload(const Geometry& g, const double* D_ref, const double* clo
     }
   }
   if (!D_) {
-    DDAMG_HIP_CHECK(hipMalloc(&D_, sizeof(T) * 72 * V));
-    DDAMG_HIP_CHECK(hipMalloc(&clover_, sizeof(T) * 72 * V));
-    DDAMG_HIP_CHECK(hipMalloc(&clover_inv_, sizeof(T) * 72 * V));
-    DDAMG_HIP_CHECK(hipMalloc(&nb_, sizeof(int) * 8 * V));
+    DDAMG_HIP_CHECK(device_alloc(&D_, sizeof(T) * 72 * V));
+    DDAMG_HIP_CHECK(device_alloc(&clover_, sizeof(T) * 72 * V));
+    DDAMG_HIP_CHECK(device_alloc(&clover_inv_, sizeof(T) * 72 * V));
+    DDAMG_HIP_CHECK(device_alloc(&nb_, sizeof(int) * 8 * V));
   }
   DDAMG_HIP_CHECK(hipMemcpyAsync(D_, hD.data(), sizeof(T) * 72 * V, hipMemcpyHostToDevice, st));
   DDAMG_HIP_CHECK(hipMemcpyAsync(clover_, hC.data(), sizeof(T) * 72 * V, hipMemcpyHostToDevice, st));
   DDAMG_HIP_CHECK(hipMemcpyAsync(clover_inv_, hI.data(), sizeof(T) * 72 * V, hipMemcpyHostToDevice, st));
   DDAMG_HIP_CHECK(hipMemcpyAsync(nb_, g.nb.data(), sizeof(int) * 8 * V, hipMemcpyHostToDevice, st));
   if (g.block_sites == 256 && !tnb_) {   // one tile of the LDS kernel == one Schwarz block: arithmetic neighbours
-    DDAMG_HIP_CHECK(hipMalloc(&tile_nb_, sizeof(int) * 8 * g.num_blocks));
-    DDAMG_HIP_CHECK(hipMalloc(&tnb_, sizeof(unsigned short) * 8 * 256));
+    DDAMG_HIP_CHECK(device_alloc(&tile_nb_, sizeof(int) * 8 * g.num_blocks));
+    DDAMG_HIP_CHECK(device_alloc(&tnb_, sizeof(unsigned short) * 8 * 256));
     DDAMG_HIP_CHECK(hipMemcpyAsync(tile_nb_, g.block_nb.data(), sizeof(int) * 8 * g.num_blocks, hipMemcpyHostToDevice, st));
     DDAMG_HIP_CHECK(hipMemcpyAsync(tnb_, g.blk_wrap_nb.data(), sizeof(unsigned short) * 8 * 256, hipMemcpyHostToDevice, st));
   }

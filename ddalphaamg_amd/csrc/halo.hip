@@ -69,8 +69,8 @@ void comm_sendrecv_host(Comm* c, const void* send, int send_peer, void* recv, in
     return;
   }
   char *ds = nullptr, *dr = nullptr;   // RCCL moves device memory: stage
-  DDAMG_HIP_CHECK(hipMalloc(&ds, bytes));
-  DDAMG_HIP_CHECK(hipMalloc(&dr, bytes));
+  DDAMG_HIP_CHECK(device_alloc(&ds, bytes));
+  DDAMG_HIP_CHECK(device_alloc(&dr, bytes));
   DDAMG_HIP_CHECK(hipMemcpyAsync(ds, send, bytes, hipMemcpyHostToDevice, c->stream));
   DDAMG_NCCL_CHECK(ncclGroupStart());
   DDAMG_NCCL_CHECK(ncclSend(ds, bytes, ncclChar, send_peer, c->nccl, c->stream));
@@ -90,7 +90,7 @@ void comm_allreduce_host(Comm* c, double* buf, int n) {
     return;
   }
   double* d = nullptr;
-  DDAMG_HIP_CHECK(hipMalloc(&d, sizeof(double) * n));
+  DDAMG_HIP_CHECK(device_alloc(&d, sizeof(double) * n));
   DDAMG_HIP_CHECK(hipMemcpyAsync(d, buf, sizeof(double) * n, hipMemcpyHostToDevice, c->stream));
   DDAMG_NCCL_CHECK(ncclAllReduce(d, d, (size_t)n, ncclDouble, ncclSum, c->nccl, c->stream));
   DDAMG_HIP_CHECK(hipMemcpyAsync(buf, d, sizeof(double) * n, hipMemcpyDeviceToHost, c->stream));
@@ -196,11 +196,11 @@ void HaloArena::init(const Geometry& g, size_t bytes_per_face_site) {
   }
   if (total_sites_ == 0) return;
   for (int s : fs) DDAMG_REQUIRE(s >= 0 && s < g.V, "face table holds an invalid site");
-  DDAMG_HIP_CHECK(hipMalloc(&d_face_sites_, sizeof(int) * total_sites_));
+  DDAMG_HIP_CHECK(device_alloc(&d_face_sites_, sizeof(int) * total_sites_));
   DDAMG_HIP_CHECK(hipMemcpy(d_face_sites_, fs.data(), sizeof(int) * total_sites_, hipMemcpyHostToDevice));
   const size_t bytes = bpfs_ * (size_t)total_sites_;
-  DDAMG_HIP_CHECK(hipMalloc(&send_, bytes));
-  DDAMG_HIP_CHECK(hipMalloc(&recv_, bytes));
+  DDAMG_HIP_CHECK(device_alloc(&send_, bytes));
+  DDAMG_HIP_CHECK(device_alloc(&recv_, bytes));
   DDAMG_HIP_CHECK(hipMemset(recv_, 0, bytes));
   DDAMG_HIP_CHECK(hipEventCreateWithFlags(&ev_packed_, hipEventDisableTiming));
   DDAMG_HIP_CHECK(hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
@@ -276,18 +276,18 @@ void Halo<T>::init(const Geometry& g) {
   n_interior_ = (int)g.interior_tiles.size();
   n_boundary_ = (int)g.boundary_tiles.size();
   if (n_interior_) {
-    DDAMG_HIP_CHECK(hipMalloc(&d_interior_, sizeof(int) * n_interior_));
+    DDAMG_HIP_CHECK(device_alloc(&d_interior_, sizeof(int) * n_interior_));
     DDAMG_HIP_CHECK(hipMemcpy(d_interior_, g.interior_tiles.data(), sizeof(int) * n_interior_, hipMemcpyHostToDevice));
   }
   if (n_boundary_) {
-    DDAMG_HIP_CHECK(hipMalloc(&d_boundary_, sizeof(int) * n_boundary_));
+    DDAMG_HIP_CHECK(device_alloc(&d_boundary_, sizeof(int) * n_boundary_));
     DDAMG_HIP_CHECK(hipMemcpy(d_boundary_, g.boundary_tiles.data(), sizeof(int) * n_boundary_, hipMemcpyHostToDevice));
   }
   std::vector<int> bs;
   for (int s = 0; s < g.V; s++)
     for (int d = 0; d < 8; d++) if (g.nb[(size_t)d * g.V + s] < 0) { bs.push_back(s); break; }
   n_bsites_ = (int)bs.size();
-  DDAMG_HIP_CHECK(hipMalloc(&d_bsites_, sizeof(int) * n_bsites_));
+  DDAMG_HIP_CHECK(device_alloc(&d_bsites_, sizeof(int) * n_bsites_));
   DDAMG_HIP_CHECK(hipMemcpy(d_bsites_, bs.data(), sizeof(int) * n_bsites_, hipMemcpyHostToDevice));
 }
 

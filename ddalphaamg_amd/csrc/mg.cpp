@@ -29,18 +29,18 @@ Multigrid<T>::Multigrid(const ddamg_hip_params& par, const std::vector<const Geo
   for (int d = 0; d < L; d++) {
     MGLevel<T>& lv = *lv_[d];
     const Geometry& g = *lv.g;
-    for (int i = 0; i < 4; i++) { DDAMG_HIP_CHECK(hipMalloc(&lv.buf[i], sizeof(T) * lv.nel)); DDAMG_HIP_CHECK(hipMemset(lv.buf[i], 0, sizeof(T) * lv.nel)); }
+    for (int i = 0; i < 4; i++) { DDAMG_HIP_CHECK(device_alloc(&lv.buf[i], sizeof(T) * lv.nel)); DDAMG_HIP_CHECK(hipMemset(lv.buf[i], 0, sizeof(T) * lv.nel)); }
     if (d == 0) lv.fop = fop;
     else lv.cop.alloc(g, lv.n);
     if (!lv.coarsest) {
       if (d == 0) { lv.fsap.setup(g, fop, par.block_iter[0], st_); lv.fip.alloc(g, *geoms[1], lv.nvec); }
       else { lv.csap.setup(g, &lv.cop, par.block_iter[d], st_); lv.cip.alloc(g, *geoms[d + 1], lv.n, lv.nvec); }
-      DDAMG_HIP_CHECK(hipMalloc(&lv.d_agg_face, g.V));
+      DDAMG_HIP_CHECK(device_alloc(&lv.d_agg_face, g.V));
       DDAMG_HIP_CHECK(hipMemcpy(lv.d_agg_face, g.agg_face.data(), g.V, hipMemcpyHostToDevice));
       for (int mu = 0; mu < 4; mu++) {
         std::vector<unsigned char> m(g.V);
         for (int s = 0; s < g.V; s++) m[s] = g.agg_face[s] & (unsigned char)(1u << mu);
-        DDAMG_HIP_CHECK(hipMalloc(&lv.d_dir_mask[mu], g.V));
+        DDAMG_HIP_CHECK(device_alloc(&lv.d_dir_mask[mu], g.V));
         DDAMG_HIP_CHECK(hipMemcpy(lv.d_dir_mask[mu], m.data(), g.V, hipMemcpyHostToDevice));
       }
     }
@@ -90,13 +90,13 @@ Multigrid<T>::Multigrid(const ddamg_hip_params& par, const std::vector<const Geo
   const Geometry& g0 = *geoms[0];
   std::vector<int> id(g0.V);
   for (int i = 0; i < g0.V; i++) id[i] = i;
-  DDAMG_HIP_CHECK(hipMalloc(&d_identity0_, sizeof(int) * g0.V));
+  DDAMG_HIP_CHECK(device_alloc(&d_identity0_, sizeof(int) * g0.V));
   DDAMG_HIP_CHECK(hipMemcpy(d_identity0_, id.data(), sizeof(int) * g0.V, hipMemcpyHostToDevice));
-  DDAMG_HIP_CHECK(hipMalloc(&d_lex0_, sizeof(int) * g0.V));
+  DDAMG_HIP_CHECK(device_alloc(&d_lex0_, sizeof(int) * g0.V));
   DDAMG_HIP_CHECK(hipMemcpy(d_lex0_, g0.lex_of_site.data(), sizeof(int) * g0.V, hipMemcpyHostToDevice));
-  DDAMG_HIP_CHECK(hipMalloc(&d_stage_, sizeof(double) * std::max(lv_[0]->nel, max_coarse)));
-  DDAMG_HIP_CHECK(hipMalloc(&W_, sizeof(T) * lv_[0]->nel * 5));
-  DDAMG_HIP_CHECK(hipMalloc(&cwork_, sizeof(T) * max_coarse * 5));
+  DDAMG_HIP_CHECK(device_alloc(&d_stage_, sizeof(double) * std::max(lv_[0]->nel, max_coarse)));
+  DDAMG_HIP_CHECK(device_alloc(&W_, sizeof(T) * lv_[0]->nel * 5));
+  DDAMG_HIP_CHECK(device_alloc(&cwork_, sizeof(T) * max_coarse * 5));
 }
 
 template <typename T>
@@ -291,8 +291,8 @@ void Multigrid<T>::build_coarse_operator(int l) {
       DDAMG_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
       gal_batch_ = 2 * N;
       while (gal_batch_ > 1 && (5 * gal_batch_ > 256 || sizeof(T) * 5 * gal_batch_ * (ws + cs) > free_b / 2)) gal_batch_ = (gal_batch_ + 1) / 2;
-      DDAMG_HIP_CHECK(hipMalloc(&gal_W_, sizeof(T) * 5 * gal_batch_ * ws));
-      DDAMG_HIP_CHECK(hipMalloc(&gal_C_, sizeof(T) * 5 * gal_batch_ * cs));
+      DDAMG_HIP_CHECK(device_alloc(&gal_W_, sizeof(T) * 5 * gal_batch_ * ws));
+      DDAMG_HIP_CHECK(device_alloc(&gal_C_, sizeof(T) * 5 * gal_batch_ * cs));
     }
     const int batch = gal_batch_;
     T *Wb = gal_W_, *Cb = gal_C_;
@@ -312,7 +312,7 @@ void Multigrid<T>::build_coarse_operator(int l) {
   } else if constexpr (sizeof(T) == 4) {
     if (!no_batch && coarse_galerkin_batch_available(lv.n, 2 * N, lv.cop.distributed(), sizeof(T))) {
       // all 2*Nvec columns at once on the matrix cores (coarse_batch.hip)
-      if (!gal_cwork_) DDAMG_HIP_CHECK(hipMalloc(&gal_cwork_, sizeof(T) * coarse_galerkin_batch_work(lv_[1]->g->V, lv_[1]->n)));
+      if (!gal_cwork_) DDAMG_HIP_CHECK(device_alloc(&gal_cwork_, sizeof(T) * coarse_galerkin_batch_work(lv_[1]->g->V, lv_[1]->n)));
       coarse_galerkin_batched(nx.cop, lv.cop, lv.cip, lv.d_agg_face, gal_cwork_, st_);
       if (nx.coarsest) nx.cop.compute_self_inverse(st_);
       DDAMG_HIP_CHECK(hipStreamSynchronize(st_));

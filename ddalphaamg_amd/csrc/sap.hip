@@ -579,15 +579,15 @@ void SapSmoother<T>::setup(const Geometry& g, const FineOp<T>* op, int block_ite
   for (int mu = 0; mu < 4; mu++)
     DDAMG_REQUIRE((g.nblk[mu] * g.P[mu]) % 2 == 0, "red-black SAP needs an even number of blocks per direction of the global lattice");
   const size_t n = (size_t)24 * V_;
-  DDAMG_HIP_CHECK(hipMalloc(&r, sizeof(T) * n));
-  DDAMG_HIP_CHECK(hipMalloc(&latest, sizeof(T) * n));
-  DDAMG_HIP_CHECK(hipMalloc(&x, sizeof(T) * n));
+  DDAMG_HIP_CHECK(device_alloc(&r, sizeof(T) * n));
+  DDAMG_HIP_CHECK(device_alloc(&latest, sizeof(T) * n));
+  DDAMG_HIP_CHECK(device_alloc(&x, sizeof(T) * n));
   DDAMG_HIP_CHECK(hipMemsetAsync(r, 0, sizeof(T) * n, st));
   DDAMG_HIP_CHECK(hipMemsetAsync(latest, 0, sizeof(T) * n, st));
   DDAMG_HIP_CHECK(hipMemsetAsync(x, 0, sizeof(T) * n, st));
-  DDAMG_HIP_CHECK(hipMalloc(&d_blk_nb_, sizeof(int) * 8 * BS_));
+  DDAMG_HIP_CHECK(device_alloc(&d_blk_nb_, sizeof(int) * 8 * BS_));
   DDAMG_HIP_CHECK(hipMemcpyAsync(d_blk_nb_, g.blk_nb.data(), sizeof(int) * 8 * BS_, hipMemcpyHostToDevice, st));
-  DDAMG_HIP_CHECK(hipMalloc(&d_block_list_, sizeof(int) * nblocks_));
+  DDAMG_HIP_CHECK(device_alloc(&d_block_list_, sizeof(int) * nblocks_));
   DDAMG_HIP_CHECK(hipMemcpyAsync(d_block_list_, g.block_list.data(), sizeof(int) * nblocks_, hipMemcpyHostToDevice, st));
   // per colour: blocks without a neighbour on another process first (their solves overlap with the halo exchange)
   std::vector<int> cb[2], cbb[2];
@@ -602,7 +602,7 @@ void SapSmoother<T>::setup(const Geometry& g, const FineOp<T>* op, int block_ite
     cb[c].insert(cb[c].end(), cbb[c].begin(), cbb[c].end());
     ncol_[c] = (int)cb[c].size();
     DDAMG_REQUIRE(ncol_[c] > 0, "red-black SAP needs blocks of both colours");
-    DDAMG_HIP_CHECK(hipMalloc(&d_color_blocks_[c], sizeof(int) * ncol_[c]));
+    DDAMG_HIP_CHECK(device_alloc(&d_color_blocks_[c], sizeof(int) * ncol_[c]));
     DDAMG_HIP_CHECK(hipMemcpyAsync(d_color_blocks_[c], cb[c].data(), sizeof(int) * ncol_[c], hipMemcpyHostToDevice, st));
   }
   DDAMG_HIP_CHECK(hipStreamSynchronize(st));
@@ -613,7 +613,11 @@ static int g_sap_variant = -1;  // 1: site-pair kernel (v1), 2: thread-per-site 
 template <typename T, int HS>
 static void launch_hs(const SapArgs<T>& a, hipStream_t st) {
   if (g_sap_variant < 0) { const char* e = getenv("DDAMG_SAP_VARIANT"); g_sap_variant = e ? atoi(e) : 2; }
-  if (g_sap_variant == 1 || 2 * HS > 256) {
+  // the resident-operator kernel addresses the operator through buffer descriptors (32-bit offsets, 2 GiB of records):
+  // the largest field (72 reals per site) must stay below that, i.e. V < 7.4e6 sites in fp32 -- beyond it (e.g. 64^4 on
+  // one GPU) the site-pair kernel with 64-bit addressing takes over
+  const bool fits_descriptor = (size_t)a.s.op.V * 72 * sizeof(T) < ((size_t)1 << 31);
+  if (g_sap_variant == 1 || 2 * HS > 256 || !fits_descriptor) {
     constexpr int NT = HS < 64 ? 64 : HS;
     constexpr int BPW = NT / HS;
     const int grid = (a.nblocks + BPW - 1) / BPW;

@@ -54,8 +54,8 @@ static void ensure_outer(ddamg_hip_ctx* c) {
     if (c->par.mixed_precision == 0) {
       c->outer.prec = [c](double* phi, double* Dphi, const double* eta, int res) { c->mg64->vcycle(0, phi, Dphi, eta, res); };
     } else {
-      DDAMG_HIP_CHECK(hipMalloc(&c->p32_in, sizeof(float) * n));
-      DDAMG_HIP_CHECK(hipMalloc(&c->p32_out, sizeof(float) * n));
+      DDAMG_HIP_CHECK(device_alloc(&c->p32_in, sizeof(float) * n));
+      DDAMG_HIP_CHECK(device_alloc(&c->p32_out, sizeof(float) * n));
       // preconditioner(): trans_float -> vcycle_float -> trans_back_float (src/preconditioner.c:31-33)
       c->outer.prec = [c](double* phi, double* Dphi, const double* eta, int res) {
         const size_t V = c->levels[0]->geom.V;
@@ -88,7 +88,7 @@ static void ensure_mp(ddamg_hip_ctx* c) {
     c->mp_inner.prec = [c](float* phi, float* Dphi, const float* eta, int res) { c->mg32->vcycle(0, phi, Dphi, eta, res); };
     c->mp_inner.prec_gives_Dphi = true;
   }
-  for (double** p : {&c->mp_x, &c->mp_b, &c->mp_r}) DDAMG_HIP_CHECK(hipMalloc(p, sizeof(double) * n));
+  for (double** p : {&c->mp_x, &c->mp_b, &c->mp_r}) DDAMG_HIP_CHECK(device_alloc(p, sizeof(double) * n));
   if (!c->rw_blas_ready) { c->rw_blas.init(8); c->rw_blas_ready = true; }
   c->mp_ready = true;
 }

@@ -18,11 +18,11 @@ void Interpolation<T>::alloc(const Geometry& g, const Geometry& gc, int nvec_) {
   DDAMG_REQUIRE(gc.V == g.num_aggs, "coarse lattice does not match the aggregate decomposition");
   // aggregate a (lexicographic in aggregate coordinates) is coarse lattice point with the same
   // coordinates; its index in the coarse level's own site ordering:
-  DDAMG_HIP_CHECK(hipMalloc(&agg_csite, sizeof(int) * num_aggs));
+  DDAMG_HIP_CHECK(device_alloc(&agg_csite, sizeof(int) * num_aggs));
   DDAMG_HIP_CHECK(hipMemcpy(agg_csite, gc.site_of_lex.data(), sizeof(int) * num_aggs, hipMemcpyHostToDevice));
   pstride = (size_t)24 * V;
-  DDAMG_HIP_CHECK(hipMalloc(&tv, sizeof(T) * pstride * nvec));
-  DDAMG_HIP_CHECK(hipMalloc(&P, sizeof(T) * pstride * nvec));
+  DDAMG_HIP_CHECK(device_alloc(&tv, sizeof(T) * pstride * nvec));
+  DDAMG_HIP_CHECK(device_alloc(&P, sizeof(T) * pstride * nvec));
   DDAMG_HIP_CHECK(hipMemset(tv, 0, sizeof(T) * pstride * nvec));
   DDAMG_HIP_CHECK(hipMemset(P, 0, sizeof(T) * pstride * nvec));
 }
