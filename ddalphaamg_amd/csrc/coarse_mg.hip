@@ -39,8 +39,8 @@ void CoarseTransfer<T>::alloc(const Geometry& g, const Geometry& gc, int n_, int
   DDAMG_HIP_CHECK(hipMemcpy(agg_csite, gc.site_of_lex.data(), sizeof(int) * num_aggs, hipMemcpyHostToDevice));
   DDAMG_HIP_CHECK(device_alloc(&tv, sizeof(T) * pstride * nvec));
   DDAMG_HIP_CHECK(device_alloc(&P, sizeof(T) * pstride * nvec));
-  DDAMG_HIP_CHECK(hipMemset(tv, 0, sizeof(T) * pstride * nvec));
-  DDAMG_HIP_CHECK(hipMemset(P, 0, sizeof(T) * pstride * nvec));
+  DDAMG_HIP_CHECK(device_zero(tv, sizeof(T) * pstride * nvec));
+  DDAMG_HIP_CHECK(device_zero(P, sizeof(T) * pstride * nvec));
 }
 template <typename T>
 void CoarseTransfer<T>::release() {

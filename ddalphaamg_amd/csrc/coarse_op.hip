@@ -274,8 +274,8 @@ void CoarseOp<T>::alloc(const Geometry& g, int n) {
   DDAMG_REQUIRE(n % 2 == 0 && nt_ <= 8, "coarse dof per site must be even and at most 64");
   DDAMG_HIP_CHECK(device_alloc(&M_, sizeof(T) * 2 * msize_ * 5 * V_));
   DDAMG_HIP_CHECK(device_alloc(&Minv_, sizeof(T) * 2 * msize_ * V_));
-  DDAMG_HIP_CHECK(hipMemset(M_, 0, sizeof(T) * 2 * msize_ * 5 * V_));
-  DDAMG_HIP_CHECK(hipMemset(Minv_, 0, sizeof(T) * 2 * msize_ * V_));
+  DDAMG_HIP_CHECK(device_zero(M_, sizeof(T) * 2 * msize_ * 5 * V_));
+  DDAMG_HIP_CHECK(device_zero(Minv_, sizeof(T) * 2 * msize_ * V_));
   DDAMG_HIP_CHECK(device_alloc(&nb_, sizeof(int) * 8 * V_));
   DDAMG_HIP_CHECK(hipMemcpy(nb_, g.nb.data(), sizeof(int) * 8 * V_, hipMemcpyHostToDevice));
   if (g.distributed()) arena_.init(g, sizeof(T) * 2 * n);

@@ -51,6 +51,15 @@ inline hipError_t device_alloc(P** p, size_t bytes) {
   return e;
 }
 
+// zero-fill at allocation time.  hipMemset runs on the null stream, which the library's non-blocking streams do NOT
+// wait for: without the synchronisation a long fill (a Krylov slab of many GB) overlaps with the first kernels that
+// write into the same memory and wipes their results.
+inline hipError_t device_zero(void* p, size_t bytes) {
+  hipError_t e = hipMemset(p, 0, bytes);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  return e;
+}
+
 // Streams confined to a subset of the compute units, used on a process grid: the transport stream gets n CUs of its own
 // and the compute stream the rest, so that the transport's copy kernels do not wait for CU slots behind the kernels they
 // are meant to overlap with.  Measured with the self-exchange mode (32^4, three directions through RCCL): the RCCL

@@ -201,7 +201,7 @@ void HaloArena::init(const Geometry& g, size_t bytes_per_face_site) {
   const size_t bytes = bpfs_ * (size_t)total_sites_;
   DDAMG_HIP_CHECK(device_alloc(&send_, bytes));
   DDAMG_HIP_CHECK(device_alloc(&recv_, bytes));
-  DDAMG_HIP_CHECK(hipMemset(recv_, 0, bytes));
+  DDAMG_HIP_CHECK(device_zero(recv_, bytes));
   DDAMG_HIP_CHECK(hipEventCreateWithFlags(&ev_packed_, hipEventDisableTiming));
   DDAMG_HIP_CHECK(hipEventCreateWithFlags(&ev_done_, hipEventDisableTiming));
 }

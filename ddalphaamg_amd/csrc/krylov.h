@@ -51,7 +51,7 @@ struct Gmres {
     vstride = (vec_elems + 63) / 64 * 64;
     size_t nvec = 4 + (restart_length + 1) + (with_Z ? restart_length + 1 : 0);
     DDAMG_HIP_CHECK(device_alloc(&slab, sizeof(T) * vstride * nvec));
-    DDAMG_HIP_CHECK(hipMemset(slab, 0, sizeof(T) * vstride * nvec));
+    DDAMG_HIP_CHECK(device_zero(slab, sizeof(T) * vstride * nvec));
     x = slab; b = x + vstride; r = b + vstride; w = r + vstride;
     Vb = w + vstride;
     Zb = with_Z ? Vb + vstride * (restart_length + 1) : nullptr;

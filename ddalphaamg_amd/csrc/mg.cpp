@@ -29,7 +29,7 @@ Multigrid<T>::Multigrid(const ddamg_hip_params& par, const std::vector<const Geo
   for (int d = 0; d < L; d++) {
     MGLevel<T>& lv = *lv_[d];
     const Geometry& g = *lv.g;
-    for (int i = 0; i < 4; i++) { DDAMG_HIP_CHECK(device_alloc(&lv.buf[i], sizeof(T) * lv.nel)); DDAMG_HIP_CHECK(hipMemset(lv.buf[i], 0, sizeof(T) * lv.nel)); }
+    for (int i = 0; i < 4; i++) { DDAMG_HIP_CHECK(device_alloc(&lv.buf[i], sizeof(T) * lv.nel)); DDAMG_HIP_CHECK(device_zero(lv.buf[i], sizeof(T) * lv.nel)); }
     if (d == 0) lv.fop = fop;
     else lv.cop.alloc(g, lv.n);
     if (!lv.coarsest) {

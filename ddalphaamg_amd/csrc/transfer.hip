@@ -23,8 +23,8 @@ void Interpolation<T>::alloc(const Geometry& g, const Geometry& gc, int nvec_) {
   pstride = (size_t)24 * V;
   DDAMG_HIP_CHECK(device_alloc(&tv, sizeof(T) * pstride * nvec));
   DDAMG_HIP_CHECK(device_alloc(&P, sizeof(T) * pstride * nvec));
-  DDAMG_HIP_CHECK(hipMemset(tv, 0, sizeof(T) * pstride * nvec));
-  DDAMG_HIP_CHECK(hipMemset(P, 0, sizeof(T) * pstride * nvec));
+  DDAMG_HIP_CHECK(device_zero(tv, sizeof(T) * pstride * nvec));
+  DDAMG_HIP_CHECK(device_zero(P, sizeof(T) * pstride * nvec));
 }
 template <typename T>
 void Interpolation<T>::release() {
