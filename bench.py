@@ -168,6 +168,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--lattice", type=int, nargs=4, default=[32, 32, 32, 32])
+    ap.add_argument("--global-lattice", type=int, nargs=4, default=None,
+                    help="strong scaling: fixed global lattice divided over the process grid (overrides --lattice, which is "
+                         "the per-GPU lattice of the default weak-scaling run)")
     ap.add_argument("--precision", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solve", action="store_true")
@@ -198,6 +201,13 @@ def main():
     from ddalphaamg_amd import api
     from conftest import splitmix_uniform
 
+    strong = args.global_lattice is not None
+    if strong:
+        from ddalphaamg_amd import dist as _d
+        _g = _d.process_grid_for(world)
+        if any(args.global_lattice[mu] % (_g[mu] * 8) for mu in range(4)):
+            raise SystemExit("--global-lattice: every extent must be a multiple of 8 x the process grid " + str(_g))
+        args.lattice = [args.global_lattice[mu] // _g[mu] for mu in range(4)]
     L = list(args.lattice); V = int(np.prod(L))
     p = api.default_params()
     p.num_levels = 1
@@ -269,7 +279,7 @@ def main():
         out = {
             "metric": "fine_wilson_clover_gflops", "value": FLOP_PER_SITE * V * world * args.steps / dt / 1e9,
             "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
             "vs_baseline": None, "dtype": f"f{args.precision}", "data": "synthetic",
             "config": {"workload": f"fine Wilson-Clover apply (d_plus_clover), {'x'.join(map(str, L))} local lattice per GPU, "
                                    "random SU(3) gauge, csw=1.0, anti-periodic T",
