@@ -10,7 +10,8 @@ case, not a bandwidth case).  Inputs are resident in HBM before the timed region
 ONE JSON line: metric fine_wilson_clover_gflops (reference flop model: 1920 flop/site,
 src/init_generic.c:59,61), plus `roofline` (algorithmic 816 B/site, HIP-event time per launch on
 the library's stream) and `cpu_baseline` (the oracle port, or the real reference when it runs,
-timed on the host cores of the same box).
+timed on the host cores of the same box), plus `small_lattice` (BASELINE configs[1], the reference's 8^4 configuration:
+cache-resident, reported but not used for the roofline) and `solve` (configs[2]: two-level FGMRES+AMG at 32^4).
 """
 import argparse, json, os, sys, time
 import numpy as np
@@ -129,6 +130,33 @@ def pmc_traffic(precision):
         return d["dirac_apply_lds_kernel<float>"]["bytes_per_launch"] if precision == 32 else None
     except Exception:
         return None
+
+
+def small_lattice_leg(device):
+    """BASELINE configs[1]: the reference's own 8^4 sample configuration (gauge field from tests/golden), fine operator
+    only, fp32, 1000 timed applies after 50 warm-ups.  Its 3 MB working set lives in the caches, so it is reported
+    next to the headline and not used for the HBM roofline."""
+    import ddalphaamg_amd as dd
+    from ddalphaamg_amd import api
+    g = np.load(os.path.join(REPO, "tests", "golden", "ref_8x8_dirac.npz"))
+    p = api.default_params(); p.num_levels = 1
+    for mu in range(4):
+        p.local_lattice[0][mu] = 8; p.block_lattice[0][mu] = 4
+    p.m0, p.csw, p.device = float(g["meta_f64"][0]), float(g["meta_f64"][1]), device
+    ctx = dd.Context(p)
+    ctx.set_gauge(g["gauge"], anti_pbc=True)
+    x = ctx.vector(0, 32).upload(g["dirac_in"]); y = ctx.vector(0, 32)
+    for _ in range(50):
+        ctx.dirac_apply(y, x)
+    ctx.sync(); ctx.timer_begin()
+    for _ in range(1000):
+        ctx.dirac_apply(y, x)
+    us = ctx.timer_end()   # milliseconds for 1000 applies == microseconds per apply
+    err = float(np.linalg.norm(y.download() - g["dirac_out_f32_as_f64"]) / np.linalg.norm(g["dirac_out_f32_as_f64"]))
+    ctx.close()
+    return {"workload": "8^4 conf/8x8x8x8b6.0000id3n1 (BASELINE configs[1]), fine Wilson-Clover apply, fp32, cache-resident",
+            "us_per_apply": us, "gflops": FLOP_PER_SITE * 4096 / us / 1e3, "algorithmic_gbs": BYTES_PER_SITE_F32 * 4096 / us / 1e3,
+            "rel_err_vs_reference_output": err}
 
 
 def solve_leg(ctx_params, U, V, L, world=1, rank=0, transport="rccl", group=None):
@@ -296,6 +324,11 @@ def main():
             D, cl = ctx.get_operator()
             if world == 1:   # "on rank 0 at N=1 only"
                 out["cpu_baseline"] = cpu_baseline(L, D, cl, phi)
+        if world == 1 and not args.self_exchange:
+            try:
+                out["small_lattice"] = small_lattice_leg(local_rank)
+            except Exception as e:
+                out["small_lattice"] = {"error": str(e)[:200]}
     ctx.close()
     if not args.no_solve and all(x % 8 == 0 for x in L):
         q = api.default_params(); q.num_levels = 2
