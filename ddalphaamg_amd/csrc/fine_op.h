@@ -59,6 +59,7 @@ class FineOp {
   T* clover_ = nullptr;
   T* clover_inv_ = nullptr;
   int* nb_ = nullptr;
+  int* lex_ = nullptr;      // lexicographic index of every device site (for the layout kernel)
   int* tile_nb_ = nullptr;
   unsigned short* tnb_ = nullptr;
   int V_ = 0;

@@ -281,73 +281,112 @@ FineOp<T>::~FineOp() {
   if (nb_) (void)hipFree(nb_);
   if (tile_nb_) (void)hipFree(tile_nb_);
   if (tnb_) (void)hipFree(tnb_);
+  if (lex_) (void)hipFree(lex_);
 }
 
-// inverse of a Hermitian positive definite-ish 6x6 matrix (Gauss-Jordan with partial pivoting)
-static void invert6(std::complex<double> a[6][6], std::complex<double> inv[6][6]) {
-  std::complex<double> m[6][12];
-  for (int i = 0; i < 6; i++)
-    for (int j = 0; j < 6; j++) { m[i][j] = a[i][j]; m[i][6 + j] = (i == j) ? 1.0 : 0.0; }
-  for (int c = 0; c < 6; c++) {
-    int p = c;
-    for (int r = c + 1; r < 6; r++) if (std::abs(m[r][c]) > std::abs(m[p][c])) p = r;
-    if (p != c) for (int j = 0; j < 12; j++) std::swap(m[c][j], m[p][j]);
-    std::complex<double> d = 1.0 / m[c][c];
-    for (int j = 0; j < 12; j++) m[c][j] *= d;
-    for (int r = 0; r < 6; r++) if (r != c) {
-      std::complex<double> f = m[r][c];
-      if (f != 0.0) for (int j = 0; j < 12; j++) m[r][j] -= f * m[c][j];
+// ---- operator data: reference storage (lexicographic fp64) -> device layouts, on the device -----------------------
+// One thread per site: links into the chunked-SoA rows, both Hermitian 6x6 clover blocks into the packed form (real
+// diagonal + strict upper triangle) and their inverses (Gauss-Jordan with partial pivoting in fp64, as the host code
+// did before; the reference keeps Cholesky factors, src/oddeven_generic.c:24-150).  set_operator is on the path of every
+// mass shift and clover scaling of the library interface (src/dirac.c:624-668), so it must not cost host seconds.
+template <typename T>
+__device__ __forceinline__ size_t soa_index_dev(int NR, size_t V, size_t s, int r) {
+  constexpr int CH = Chunk<T>::CH;
+  const int NF = NR / CH;
+  if (r < NF * CH) return ((size_t)(r / CH) * V + s) * CH + (r % CH);
+  const int TL = NR % CH;
+  return (size_t)NF * V * CH + s * TL + (r - NF * CH);
+}
+
+template <typename T>
+__global__ __launch_bounds__(128) void operator_layout_kernel(T* __restrict__ D, T* __restrict__ clover, T* __restrict__ clover_inv,
+                                                              const double* __restrict__ D_lex, const double* __restrict__ clover_lex,
+                                                              const int* __restrict__ lex_of_site, int V) {
+  const size_t s = (size_t)blockIdx.x * 128 + threadIdx.x;
+  if (s >= (size_t)V) return;
+  const size_t lx = lex_of_site[s];
+  for (int mu = 0; mu < 4; mu++)
+    for (int r = 0; r < 18; r++)
+      D[(size_t)mu * 18 * V + soa_index_dev<T>(18, V, s, r)] = (T)D_lex[(lx * 36 + mu * 9) * 2 + r];
+  const double* c = clover_lex + lx * 42 * 2;
+  for (int b = 0; b < 2; b++) {
+    double mr[6][12], mi[6][12];   // [A | 1] -> [1 | A^-1]
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 12; j++) { mr[i][j] = (j == 6 + i) ? 1.0 : 0.0; mi[i][j] = 0.0; }
+    for (int i = 0; i < 6; i++) mr[i][i] = c[2 * (6 * b + i)];
+    int k = 12 + 15 * b;
+    for (int i = 0; i < 6; i++)
+      for (int j = i + 1; j < 6; j++, k++) {
+        mr[i][j] = c[2 * k]; mi[i][j] = c[2 * k + 1];
+        mr[j][i] = c[2 * k]; mi[j][i] = -c[2 * k + 1];
+      }
+    int r0 = 36 * b;
+    for (int i = 0; i < 6; i++) clover[soa_index_dev<T>(72, V, s, r0 + i)] = (T)mr[i][i];
+    r0 += 6;
+    for (int i = 0; i < 6; i++)
+      for (int j = i + 1; j < 6; j++) {
+        clover[soa_index_dev<T>(72, V, s, r0)] = (T)mr[i][j];
+        clover[soa_index_dev<T>(72, V, s, r0 + 1)] = (T)mi[i][j];
+        r0 += 2;
+      }
+    for (int col = 0; col < 6; col++) {
+      int piv = col;
+      double best = mr[col][col] * mr[col][col] + mi[col][col] * mi[col][col];
+      for (int r = col + 1; r < 6; r++) {
+        const double a2 = mr[r][col] * mr[r][col] + mi[r][col] * mi[r][col];
+        if (a2 > best) { best = a2; piv = r; }
+      }
+      if (piv != col)
+        for (int j = 0; j < 12; j++) {
+          double t = mr[col][j]; mr[col][j] = mr[piv][j]; mr[piv][j] = t;
+          t = mi[col][j]; mi[col][j] = mi[piv][j]; mi[piv][j] = t;
+        }
+      const double dr = mr[col][col] / best, di = -mi[col][col] / best;   // 1 / pivot
+      for (int j = 0; j < 12; j++) {
+        const double xr = mr[col][j], xi = mi[col][j];
+        mr[col][j] = xr * dr - xi * di; mi[col][j] = xr * di + xi * dr;
+      }
+      for (int r = 0; r < 6; r++) {
+        if (r == col) continue;
+        const double fr = mr[r][col], fi = mi[r][col];
+        if (fr == 0.0 && fi == 0.0) continue;
+        for (int j = 0; j < 12; j++) {
+          mr[r][j] -= fr * mr[col][j] - fi * mi[col][j];
+          mi[r][j] -= fr * mi[col][j] + fi * mr[col][j];
+        }
+      }
     }
+    r0 = 36 * b;
+    for (int i = 0; i < 6; i++) clover_inv[soa_index_dev<T>(72, V, s, r0 + i)] = (T)mr[i][6 + i];
+    r0 += 6;
+    for (int i = 0; i < 6; i++)
+      for (int j = i + 1; j < 6; j++) {
+        clover_inv[soa_index_dev<T>(72, V, s, r0)] = (T)mr[i][6 + j];
+        clover_inv[soa_index_dev<T>(72, V, s, r0 + 1)] = (T)mi[i][6 + j];
+        r0 += 2;
+      }
   }
-  for (int i = 0; i < 6; i++) for (int j = 0; j < 6; j++) inv[i][j] = m[i][6 + j];
 }
 
 template <typename T>
 void FineOp<T>::upload(const Geometry& g, const double* D_ref, const double* clover_ref, hipStream_t st) {
   const size_t V = g.V;
   V_ = g.V;
-  std::vector<T> hD(72 * V), hC(72 * V), hI(72 * V);
-  for (size_t s = 0; s < V; s++) {
-    const size_t lx = g.lex_of_site[s];
-    for (int mu = 0; mu < 4; mu++)
-      for (int r = 0; r < 18; r++)
-        hD[(size_t)mu * 18 * V + soa_index<T>(18, V, s, r)] = (T)D_ref[(lx * 36 + mu * 9) * 2 + r];
-    const double* c = clover_ref + lx * 42 * 2;
-    for (int b = 0; b < 2; b++) {
-      std::complex<double> a[6][6], inv[6][6];
-      for (int i = 0; i < 6; i++) a[i][i] = c[2 * (6 * b + i)];
-      int k = 12 + 15 * b;
-      for (int i = 0; i < 6; i++)
-        for (int j = i + 1; j < 6; j++, k++) {
-          a[i][j] = std::complex<double>(c[2 * k], c[2 * k + 1]);
-          a[j][i] = std::conj(a[i][j]);
-        }
-      invert6(a, inv);
-      int r = 36 * b;
-      for (int i = 0; i < 6; i++) {
-        hC[soa_index<T>(72, V, s, r + i)] = (T)a[i][i].real();
-        hI[soa_index<T>(72, V, s, r + i)] = (T)inv[i][i].real();
-      }
-      r += 6;
-      for (int i = 0; i < 6; i++)
-        for (int j = i + 1; j < 6; j++) {
-          hC[soa_index<T>(72, V, s, r)] = (T)a[i][j].real();
-          hC[soa_index<T>(72, V, s, r + 1)] = (T)a[i][j].imag();
-          hI[soa_index<T>(72, V, s, r)] = (T)inv[i][j].real();
-          hI[soa_index<T>(72, V, s, r + 1)] = (T)inv[i][j].imag();
-          r += 2;
-        }
-    }
-  }
   if (!D_) {
     DDAMG_HIP_CHECK(device_alloc(&D_, sizeof(T) * 72 * V));
     DDAMG_HIP_CHECK(device_alloc(&clover_, sizeof(T) * 72 * V));
     DDAMG_HIP_CHECK(device_alloc(&clover_inv_, sizeof(T) * 72 * V));
     DDAMG_HIP_CHECK(device_alloc(&nb_, sizeof(int) * 8 * V));
+    DDAMG_HIP_CHECK(device_alloc(&lex_, sizeof(int) * V));
+    DDAMG_HIP_CHECK(hipMemcpyAsync(lex_, g.lex_of_site.data(), sizeof(int) * V, hipMemcpyHostToDevice, st));
   }
-  DDAMG_HIP_CHECK(hipMemcpyAsync(D_, hD.data(), sizeof(T) * 72 * V, hipMemcpyHostToDevice, st));
-  DDAMG_HIP_CHECK(hipMemcpyAsync(clover_, hC.data(), sizeof(T) * 72 * V, hipMemcpyHostToDevice, st));
-  DDAMG_HIP_CHECK(hipMemcpyAsync(clover_inv_, hI.data(), sizeof(T) * 72 * V, hipMemcpyHostToDevice, st));
+  double *dD = nullptr, *dC = nullptr;   // staging of the lexicographic fp64 arrays
+  DDAMG_HIP_CHECK(device_alloc(&dD, sizeof(double) * 72 * V));
+  DDAMG_HIP_CHECK(device_alloc(&dC, sizeof(double) * 84 * V));
+  DDAMG_HIP_CHECK(hipMemcpyAsync(dD, D_ref, sizeof(double) * 72 * V, hipMemcpyHostToDevice, st));
+  DDAMG_HIP_CHECK(hipMemcpyAsync(dC, clover_ref, sizeof(double) * 84 * V, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(operator_layout_kernel<T>, dim3((unsigned)((V + 127) / 128)), dim3(128), 0, st, D_, clover_, clover_inv_, dD, dC, lex_, (int)V);
+  DDAMG_HIP_CHECK(hipGetLastError());
   DDAMG_HIP_CHECK(hipMemcpyAsync(nb_, g.nb.data(), sizeof(int) * 8 * V, hipMemcpyHostToDevice, st));
   if (g.block_sites == 256 && !tnb_) {   // one tile of the LDS kernel == one Schwarz block: arithmetic neighbours
     DDAMG_HIP_CHECK(device_alloc(&tile_nb_, sizeof(int) * 8 * g.num_blocks));
@@ -356,6 +395,8 @@ void FineOp<T>::upload(const Geometry& g, const double* D_ref, const double* clo
     DDAMG_HIP_CHECK(hipMemcpyAsync(tnb_, g.blk_wrap_nb.data(), sizeof(unsigned short) * 8 * 256, hipMemcpyHostToDevice, st));
   }
   DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+  DDAMG_HIP_CHECK(hipFree(dD));
+  DDAMG_HIP_CHECK(hipFree(dC));
   if (g.distributed() && !halo_.active()) halo_.init(g);
 }
 
