@@ -48,13 +48,14 @@ def test_dirac_and_gauge_through_rccl_self_exchange(gold8, grid):
     ctx.close()
 
 
-@pytest.mark.parametrize("levels", [2, 3])
-def test_amg_solve_through_rccl_self_exchange(gold8, levels):
-    """smoother, Galerkin construction, coarse operator, K-cycle, coarsest solve and the reductions, all through RCCL"""
+@pytest.mark.parametrize("levels,mp", [(2, 1), (3, 1), (3, 0), (3, 2)])
+def test_amg_solve_through_rccl_self_exchange(gold8, levels, mp):
+    """smoother, Galerkin construction, coarse operator, K-cycle, coarsest solve and the reductions, all through RCCL;
+    mixed precision 0 (all fp64), 1 (fp64 outer / fp32 V-cycle) and 2 (fgmres_MP)"""
     b = np.zeros((4096, 12, 2)); b[..., 0] = 1.0
     res = []
     for grid in ([1, 1, 1, 1], [-1, -1, -1, -1]):
-        ctx = dd.Context(params(gold8, grid, levels))
+        ctx = dd.Context(params(gold8, grid, levels, mp))
         if grid[0] == -1:
             ctx.comm_init_rccl(api.rccl_unique_id())
         ctx.set_gauge(gold8["gauge"], anti_pbc=True)
