@@ -146,7 +146,7 @@ __device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOp
 }
 
 template <typename T, bool ARITH, bool DEFER>
-__global__ __launch_bounds__(256, 3) void dirac_apply_lds_kernel(T* __restrict__ eta, const T* __restrict__ phi, FineOpDev<T> op, int ntiles,
+__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) void dirac_apply_lds_kernel(T* __restrict__ eta, const T* __restrict__ phi, FineOpDev<T> op, int ntiles,
                                                                   const int* __restrict__ tile_list) {
   __shared__ T sp[24 * 256];
   __shared__ T hb[12 * 256];
