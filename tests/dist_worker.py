@@ -267,7 +267,7 @@ def run_sample_np2(rank, world, P):
     import ddalphaamg_amd as dd
     here = os.path.dirname(os.path.abspath(__file__))
     g = np.load(os.path.join(here, "golden", "ref_8x8_dirac.npz"))
-    ref = json.load(open(os.path.join(here, "golden", "ref_8x8_3lvl_np2.json")))
+    ref = json.load(open(os.path.join(here, "golden", f"ref_8x8_3lvl_np{world}.json")))
     assert P == ref["process_grid"]
     G = [8, 8, 8, 8]
     C = ddist.coords_of(rank, P)
@@ -304,7 +304,7 @@ def run_sample_np2(rank, world, P):
     dist.barrier()
     ctx.close()
     if rank == 0:
-        print(f"sample.ini on 2 processes: {it} iterations, {cit} coarse, relres {rr:.6e}  (reference: {ref['iterations']}, "
+        print(f"sample.ini on {world} processes: {it} iterations, {cit} coarse, relres {rr:.6e}  (reference: {ref['iterations']}, "
               f"{ref['coarse_iterations']}, {ref['exact_relative_residual']:.6e})", flush=True)
         print("history", " ".join(f"{h:.6e}" for h in hist), flush=True)
     assert abs(it - ref["iterations"]) <= 1, (it, ref["iterations"])

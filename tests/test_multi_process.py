@@ -88,11 +88,13 @@ def test_decomposed_three_level_amg(nproc, grid, lattice):
 
 
 @pytest.mark.gpu
-def test_sample_configuration_on_two_processes_vs_reference_on_two_ranks():
-    """the reference itself, run on 2 MPI ranks (oracle/run_reference_np2.sh -> tests/golden/ref_8x8_3lvl_np2.json):
-    11 iterations, 1.55e-11; the decomposed GPU run must give the same count (+-1) and convergence curve"""
-    out = launch(2, "--mode", "sample_np2", "--grid", "2,1,1,1", "--tol", "1", timeout=600)
-    assert "sample.ini on 2 processes: 11 iterations" in out or "sample.ini on 2 processes: 1" in out
+@pytest.mark.parametrize("nproc,grid", [(2, "2,1,1,1"), (4, "2,2,1,1")])
+def test_sample_configuration_vs_reference_on_the_same_process_grid(nproc, grid):
+    """the reference itself, run on 2 and on 4 MPI ranks (oracle/run_reference_np2.sh -> tests/golden/ref_8x8_3lvl_np2.json,
+    ..._np4.json): 11 iterations (1.55e-11 / 1.46e-11); the decomposed GPU run must give the same count (+-1) and
+    convergence curve"""
+    out = launch(nproc, "--mode", "sample_np2", "--grid", grid, "--tol", "1", timeout=600)
+    assert f"sample.ini on {nproc} processes: 1" in out
 
 
 MPIEXEC = "/opt/conda/bin/mpiexec"
