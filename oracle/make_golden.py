@@ -64,6 +64,12 @@ CASES = {
     # (coarse lattice 2x2x2x2), seeded random SU(3) links, m0 = 0.3
     "ragged": dict(conf="", synthetic=4711, levels=2, L="8 4 4 8", B="4 2 2 2", nvec=12, setup=2, m0=0.3,
                    extra="d1 global lattice: 2 2 2 2\nd1 local lattice: 2 2 2 2", method=2, mp=1),
+    # 4^4 Schwarz blocks (256 sites: the block shape of the production configurations and of the optimised kernels) on the
+    # reference's 8^4 configuration: smoother dumps and the rhs=ones solve after the reference's own setup
+    "8x8_b4": dict(conf="conf/8x8x8x8b6.0000id3n1", levels=2, L="8 8 8 8", B="4 4 4 4", nvec=20, setup=3,
+                   extra="d1 global lattice: 2 2 2 2\nd1 local lattice: 2 2 2 2", method=2, mp=1,
+                   keep=["meta_int", "meta_f64", "smoother_eta", "smoother_phi0", "smoother_nores_out_c1", "smoother_nores_out_c2",
+                         "smoother_nores_out_c3", "smoother_res_out_c2", "ones_solve_iters", "ones_solve_norm_res"]),
     "8x8_gmres_mp2": dict(conf="conf/8x8x8x8b6.0000id3n1", levels=1, L="8 8 8 8", B="2 2 2 2", nvec=4, setup=0, extra="", method=0, mp=2,
                           keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),
 }

@@ -319,3 +319,68 @@ def test_pure_gmres_mixed_precision_2(gold8):
     k = k[k < len(hist)]
     assert np.all(np.abs(np.log10(hist[k] / ref[:len(k)])) < 0.3)
     ctx.close()
+
+
+# ---- the block shape of the production configurations: 4^4 Schwarz blocks (256 sites, the resident-operator kernel) ------
+@pytest.fixture(scope="module")
+def gold_b4():
+    from conftest import load_golden
+    return load_golden("ref_8x8_b4.npz")
+
+
+def make_ctx_b4(gold_b4, gold8):
+    p = api.default_params(); p.num_levels = 2
+    for mu in range(4):
+        p.local_lattice[0][mu] = 8; p.block_lattice[0][mu] = 4; p.local_lattice[1][mu] = 2
+    p.num_vect[0] = int(gold_b4["meta_int"][9]); p.post_smooth_iter[0] = 2; p.block_iter[0] = 4; p.setup_iter[0] = 3
+    p.restart, p.max_restart, p.tol = 50, 20, 1e-10
+    p.coarse_iter, p.coarse_restart, p.coarse_tol = 100, 5, 5e-2
+    p.mixed_precision, p.method, p.odd_even = 1, 2, 1
+    p.m0, p.csw = float(gold_b4["meta_f64"][0]), float(gold_b4["meta_f64"][1])
+    ctx = dd.Context(p)
+    ctx.set_gauge(gold8["gauge"], anti_pbc=True)
+    return ctx
+
+
+@pytest.mark.parametrize("variant", ["2", "1"])
+def test_smoother_with_256_site_blocks_vs_reference(gold_b4, gold8, variant, monkeypatch):
+    """red_black_schwarz on 4^4 blocks, both block-solver kernels (resident operator / site pairs), against the
+    reference's dumps: from zero with 1-3 cycles (list-4/5 rule: with 2 blocks per direction every block touches both
+    lattice boundaries) and with an initial guess"""
+    import subprocess, sys, os, textwrap
+    # the kernel variant is read once per process: run the comparison in a child with the variable set
+    code = textwrap.dedent(f"""
+        import sys, os, numpy as np
+        sys.path.insert(0, {os.path.dirname(os.path.dirname(os.path.abspath(__file__)))!r}); sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r})
+        import test_gpu_multigrid as t
+        from conftest import load_golden, relerr
+        g = load_golden("ref_8x8_b4.npz"); g8 = load_golden("ref_8x8_dirac.npz")
+        ctx = t.make_ctx_b4(g, g8)
+        ctx.setup(0)
+        eta = ctx.vector(0, 32).upload(g["smoother_eta"]); phi = ctx.vector(0, 32)
+        for c in (1, 2, 3):
+            ctx.smoother(phi, eta, c, initial_guess_zero=True)
+            assert relerr(phi.download(), g[f"smoother_nores_out_c{{c}}"]) < t.TOL_SWEEP, c
+        phi.upload(g["smoother_phi0"])
+        ctx.smoother(phi, eta, 2, initial_guess_zero=False)
+        assert relerr(phi.download(), g["smoother_res_out_c2"]) < t.TOL_SWEEP
+        print("B4_SMOOTHER_OK")
+    """)
+    env = dict(os.environ, DDAMG_SAP_VARIANT=variant)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "B4_SMOOTHER_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_setup_and_solve_with_256_site_blocks_vs_reference(gold_b4, gold8):
+    """the reference's run with 4^4 blocks / aggregates on its 8^4 configuration (setup 3, Nvec 20, rhs = ones): same
+    iteration count and convergence curve after our own setup on the same rand() stream"""
+    ctx = make_ctx_b4(gold_b4, gold8)
+    ctx.setup(3)
+    b = np.zeros((4096, 12, 2)); b[..., 0] = 1.0
+    x, it, cit, rr = ctx.solve(b, 1e-10)
+    ref_hist = gold_b4["ref_log_ones_history"]
+    assert it == int(gold_b4["ones_solve_iters"][0]) == len(ref_hist)
+    assert abs(cit - int(gold_b4["ones_solve_iters"][1])) <= 8 and rr < 1e-10
+    hist = ctx.residual_history()
+    assert np.all(np.abs(hist / ref_hist - 1.0) < 0.05)
+    ctx.close()
