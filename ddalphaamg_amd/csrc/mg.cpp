@@ -79,6 +79,9 @@ Multigrid<T>::Multigrid(const ddamg_hip_params& par, const std::vector<const Geo
       lv.gm.num_restart = par.coarse_restart;
       lv.gm.tol = par.coarse_tol;
       lv.gm.st = st_; lv.gm.rw = &lv.rw;
+      // odd-even preconditioning needs a bipartite lattice: even global extents (the reference's check, src/init.c:1012)
+      for (int mu = 0; mu < 4; mu++)
+        DDAMG_REQUIRE((g.L[mu] * g.P[mu]) % 2 == 0, "the coarsest lattice must have even global extents (odd-even preconditioning)");
       int n_even = 0;
       for (int s = 0; s < g.V; s++) if (g.parity[s] == 0) n_even++;
       DDAMG_REQUIRE(n_even * 2 == g.V, "coarsest lattice needs as many even as odd sites");

@@ -55,7 +55,9 @@ def test_vector_roundtrip():
     ctx.close()
 
 
-@pytest.mark.parametrize("L,B", [([4, 6, 8, 4], [2, 2, 4, 2]), ([8, 4, 4, 16], [4, 4, 2, 4])])
+@pytest.mark.parametrize("L,B", [([4, 6, 8, 4], [2, 2, 4, 2]), ([8, 4, 4, 16], [4, 4, 2, 4]),
+                                 # volumes that do not fill whole 256-site tiles, odd numbers of blocks, a single partial tile
+                                 ([4, 4, 4, 6], [2, 2, 2, 2]), ([6, 6, 6, 6], [2, 2, 2, 2]), ([2, 4, 6, 4], [2, 2, 2, 2]), ([2, 2, 2, 2], [2, 2, 2, 2])])
 def test_dirac_apply_vs_oracle_ragged(L, B):
     """non-cubic lattices / blocks, random gauge, against the oracle"""
     from oracle import orc
