@@ -1,5 +1,6 @@
-"""GPU parity (-m gpu) against the pinned numpy/scipy restatement (oracle/mg_oracle.py) on a lattice that is in no
-golden set: 4x8x4x4 (T,Z,Y,X), Schwarz blocks 2x4x2x2 = aggregates, seeded random links.  The hierarchy comes from
+"""GPU parity (-m gpu) against the pinned numpy/scipy restatement (oracle/mg_oracle.py) on lattices that are in no
+golden set, seeded random links: 4x8x4x4 (T,Z,Y,X) with Schwarz blocks 2x4x2x2 = aggregates; 4x4x4x8 with blocks
+2x2x2x4; and 4x4x8x8 with 2^4 blocks inside 2x2x4x4 aggregates (several blocks per aggregate).  The hierarchy comes from
 the GPU setup (device generator); the oracle receives the same interpolation vectors and coarse operator."""
 import numpy as np
 import pytest
@@ -9,12 +10,16 @@ import ddalphaamg_amd as dd
 
 pytestmark = pytest.mark.gpu
 
-L = [4, 8, 4, 4]; B = [2, 4, 2, 2]; LC = [2, 2, 2, 2]
-V = int(np.prod(L))
+SHAPES = {"blocks=aggregates": ([4, 8, 4, 4], [2, 4, 2, 2], [2, 2, 2, 2]),
+          "long-x": ([4, 4, 4, 8], [2, 2, 2, 4], [2, 2, 2, 2]),
+          "blocks-in-aggregates": ([4, 4, 8, 8], [2, 2, 2, 2], [2, 2, 2, 2])}
 
 
-@pytest.fixture(scope="module")
-def pair():
+@pytest.fixture(scope="module", params=list(SHAPES), ids=list(SHAPES))
+def pair(request):
+    global L, B, LC, V
+    L, B, LC = SHAPES[request.param]
+    V = int(np.prod(L))
     from oracle import mg_oracle as mo
     p = api.default_params(); p.num_levels = 2
     for mu in range(4):
