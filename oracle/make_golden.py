@@ -57,6 +57,10 @@ CASES = {
     "8x8_3lvl": dict(conf="conf/8x8x8x8b6.0000id3n1", levels=3, L="8 8 8 8", B="2 2 2 2", nvec=28, setup=4,
                      extra="d1 global lattice: 4 4 4 4\nd1 post smooth iter: 2\nd1 block iter: 4\nd1 test vectors: 28\nd1 setup iter: 3",
                      method=2, mp=1, keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),
+    # the same hierarchy with mixed precision 2 (fgmres_MP outside the K-cycle)
+    "8x8_3lvl_mp2": dict(conf="conf/8x8x8x8b6.0000id3n1", levels=3, L="8 8 8 8", B="2 2 2 2", nvec=28, setup=4,
+                         extra="d1 global lattice: 4 4 4 4\nd1 post smooth iter: 2\nd1 block iter: 4\nd1 test vectors: 28\nd1 setup iter: 3",
+                         method=2, mp=2, keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),
     # mixed precision 2 (fgmres_MP): AMG-preconditioned on 4^4 and pure GMRES(50) on 8^4 (383 iterations)
     "4x4_mp2": dict(conf="conf/4x4x4x4b6.0000id3n1", levels=2, L="4 4 4 4", B="2 2 2 2", nvec=20, setup=4, extra="", method=2, mp=2,
                     keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),

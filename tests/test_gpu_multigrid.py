@@ -240,12 +240,13 @@ def test_pure_gmres_method0(gold4):
     ctx.close()
 
 
-def test_three_level_kcycle_solve(gold8):
+@pytest.mark.parametrize("mp,fixture", [(1, "ref_8x8_3lvl.npz"), (2, "ref_8x8_3lvl_mp2.npz")])
+def test_three_level_kcycle_solve(gold8, mp, fixture):
     """BASELINE config: the reference's sample.ini on conf/8x8x8x8b6.0000id3n1 -- 3 levels (8^4 -> 4^4 -> 2^4),
-    Nvec 28/28, 2^4 blocks, K-cycle(5,2,0.1), setup 4 (+3 on level 1), rhs = ones.
-    Reference: 11 FGMRES iterations, true residual 1.3e-11 (tests/golden/ref_8x8_3lvl.npz)."""
+    Nvec 28/28, 2^4 blocks, K-cycle(5,2,0.1), setup 4 (+3 on level 1), rhs = ones, with mixed precision 1 and 2.
+    Reference: 11 FGMRES iterations, true residual 1.3e-11 (tests/golden/ref_8x8_3lvl.npz, ref_8x8_3lvl_mp2.npz)."""
     from conftest import load_golden
-    g3 = load_golden("ref_8x8_3lvl.npz")
+    g3 = load_golden(fixture)
     p = api.default_params()
     p.num_levels = 3
     for mu in range(4):
@@ -258,7 +259,7 @@ def test_three_level_kcycle_solve(gold8):
     p.restart, p.max_restart, p.tol = 50, 20, 1e-10
     p.coarse_iter, p.coarse_restart, p.coarse_tol = 100, 5, 5e-2
     p.kcycle, p.kcycle_restart, p.kcycle_max_restart, p.kcycle_tol = 1, 5, 2, 1e-1
-    p.mixed_precision, p.method, p.odd_even = 1, 2, 1
+    p.mixed_precision, p.method, p.odd_even = mp, 2, 1
     p.m0, p.csw = float(g3["meta_f64"][0]), float(g3["meta_f64"][1])
     ctx = dd.Context(p)
     plaq = ctx.set_gauge(gold8["gauge"], anti_pbc=True)
