@@ -73,10 +73,25 @@ void params_from_ini(const Ini& ini, ddamg_hip_params& hp, int* anti_pbc) {
   ddamg_hip_default_params(&hp);
   ini.geti("number of levels:", &hp.num_levels);
   int glob[DDAMG_HIP_MAX_LEVELS][4] = {};
+  ini.geti("odd even preconditioning:", &hp.odd_even);
+  // read_geometry_data (src/init.c:659-760): a level whose lattices are not given takes the previous level's lattice
+  // divided by its block lattice; if that leaves fewer than 2 sites the method silently becomes shallower
   for (int d = 0; d < hp.num_levels; d++) {
     char k[64];
     snprintf(k, sizeof k, "d%d global lattice:", d);
-    if (!ini.geti(k, glob[d], 4)) fatal("parameter \"%s\" missing", k);
+    if (!ini.geti(k, glob[d], 4)) {
+      if (d == 0) fatal("parameter \"%s\" missing", k);
+      int nls = 1;
+      for (int mu = 0; mu < 4; mu++) {
+        if (hp.block_lattice[d - 1][mu] <= 0) fatal("d%d block lattice is needed to derive d%d global lattice", d - 1, d);
+        glob[d][mu] = glob[d - 1][mu] / hp.block_lattice[d - 1][mu]; nls *= glob[d][mu];
+      }
+      if (hp.odd_even && nls < 2) {
+        fprintf(stderr, "warning: lattice dimensions not valid for a %d-level method, choosing a %d-level method\n", hp.num_levels, d);
+        hp.num_levels = d;
+        break;
+      }
+    }
     snprintf(k, sizeof k, "d%d local lattice:", d);
     const bool have_local = ini.geti(k, hp.local_lattice[d], 4);
     if (have_local && d == 0)
@@ -90,7 +105,20 @@ void params_from_ini(const Ini& ini, ddamg_hip_params& hp, int* anti_pbc) {
     }
     for (int mu = 0; mu < 4; mu++)
       if (glob[d][mu] != hp.local_lattice[d][mu] * S.P[mu]) fatal("every level must be distributed over the same process grid");
-    snprintf(k, sizeof k, "d%d block lattice:", d); ini.geti(k, hp.block_lattice[d], 4);
+    snprintf(k, sizeof k, "d%d block lattice:", d);
+    if (!ini.geti(k, hp.block_lattice[d], 4)) {
+      if (d == 0) fatal("parameter \"%s\" missing", k);
+      // default on coarse levels: 2 where it divides, else 3, else the method ends here (src/init.c:718-750)
+      for (int mu = 0; mu < 4; mu++) {
+        if (glob[d][mu] % 2 == 0) hp.block_lattice[d][mu] = 2;
+        else if (glob[d][mu] % 3 == 0) hp.block_lattice[d][mu] = 3;
+        else {
+          fprintf(stderr, "warning: lattice dimensions not valid for a %d-level method, choosing a %d-level method\n", hp.num_levels, d + 1);
+          hp.num_levels = d + 1; hp.block_lattice[d][mu] = 1;
+          break;
+        }
+      }
+    }
     snprintf(k, sizeof k, "d%d post smooth iter:", d); ini.geti(k, &hp.post_smooth_iter[d]);
     snprintf(k, sizeof k, "d%d block iter:", d); ini.geti(k, &hp.block_iter[d]);
     snprintf(k, sizeof k, "d%d test vectors:", d); ini.geti(k, &hp.num_vect[d]);

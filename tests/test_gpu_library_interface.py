@@ -67,3 +67,65 @@ def test_library_interface_solve(gold4):
         assert np.linalg.norm(r) < 0.3 * np.linalg.norm(b)
     finally:
         lib.dd_alpha_amg_free()
+
+
+def test_parameter_file_path_baseline_config_1(gold4, tmp_path):
+    """BASELINE configs[0]: the reference's sample.ini with the lattice lines changed to the 4^4 configuration, through
+    dd_alpha_amg_init (parameter file).  As in the reference the 3-level request is not realisable (4^4 -> 2^4 -> 1^4) and
+    a 2-level method with Nvec 28 runs (src/init.c:677-681).  Reference: 10 iterations, coarse average 7.00,
+    relative residual 1.476963e-11."""
+    ini = tmp_path / "sample_4x4.ini"
+    ini.write_text("""configuration: (links are handed over through dd_alpha_amg_set_conf)
+format: 0
+right hand side: 0
+antiperiodic boundary conditions: 1
+number of levels: 3
+number of openmp threads: 1
+d0 global lattice: 4 4 4 4
+d0 local lattice: 4 4 4 4
+d0 block lattice: 2 2 2 2
+d0 post smooth iter: 2
+d0 block iter: 4
+d0 test vectors: 28
+d0 setup iter: 4
+d1 global lattice: 2 2 2 2
+d1 post smooth iter: 2
+d1 block iter: 4
+d1 test vectors: 28
+d1 setup iter: 3
+m0: -0.5
+csw: 1.0
+tolerance for relative residual: 1E-10
+iterations between restarts: 50
+maximum of restarts: 20
+coarse grid tolerance: 5E-2
+coarse grid iterations: 100
+coarse grid restarts: 5
+print mode: 1
+method: 2
+mixed precision: 1
+randomize test vectors: 0
+""")
+    lib = libiface.bind()
+    par = libiface.Par()
+    par.param_file_path = str(ini).encode()
+    conf_idx = libiface.CONF_INDEX_FCT(lambda t, z, y, x, mu: ((((t * 4 + z) * 4 + y) * 4 + x) * 4 + mu) * 18)
+    vec_idx = libiface.VECTOR_INDEX_FCT(lambda t, z, y, x: (((t * 4 + z) * 4 + y) * 4 + x) * 24)
+    gtime = libiface.GLOBAL_TIME_FCT(lambda t: t)
+    par.conf_index_fct, par.vector_index_fct, par.global_time = conf_idx, vec_idx, gtime
+    par.bc, par.m0, par.csw, par.setup_m0 = 2, -0.5, 1.0, -0.5
+    lib.dd_alpha_amg_init(par)
+    try:
+        U = gold4["gauge"].copy()
+        U[-64:, 0] *= -1.0      # anti-periodic boundary condition: the caller's links carry it
+        dp = ctypes.POINTER(ctypes.c_double)
+        lib.dd_alpha_amg_set_conf(U.ctypes.data_as(dp))
+        status = (ctypes.c_int * 2)()
+        lib.dd_alpha_amg_setup(4, status)
+        b = np.zeros((256, 12, 2)); b[..., 0] = 1.0
+        x = np.zeros_like(b)
+        rr = lib.dd_alpha_amg_wilson_solve(x.ctypes.data_as(dp), b.ctypes.data_as(dp), 1e-10, 1.0, 1.0, status)
+        assert status[0] == 10 and abs(status[1] - 70) <= 4
+        assert rr < 1e-10 and abs(rr / 1.476963e-11 - 1.0) < 0.3   # same count; the final residual within 30 % (measured: 1.16e-11)
+    finally:
+        lib.dd_alpha_amg_free()
