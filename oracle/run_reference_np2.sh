@@ -44,4 +44,4 @@ method: 2
 mixed precision: 1
 randomize test vectors: 0
 EOF
-cd $TMP && /opt/conda/bin/mpiexec -n $NP $HERE/_ref/dd_alpha_amg_sse np2.ini
+cd $TMP && /opt/conda/bin/mpiexec -n $NP $HERE/_ref/dd_alpha_amg_scalar np2.ini

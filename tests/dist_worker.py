@@ -307,11 +307,11 @@ def run_sample_np2(rank, world, P):
         print(f"sample.ini on {world} processes: {it} iterations, {cit} coarse, relres {rr:.6e}  (reference: {ref['iterations']}, "
               f"{ref['coarse_iterations']}, {ref['exact_relative_residual']:.6e})", flush=True)
         print("history", " ".join(f"{h:.6e}" for h in hist), flush=True)
-    assert abs(it - ref["iterations"]) <= 1, (it, ref["iterations"])
+    assert it == ref["iterations"] and abs(cit - ref["coarse_iterations"]) <= 3, (it, cit, ref["iterations"], ref["coarse_iterations"])
     assert rr < 1e-10
     n = min(len(hist), len(ref["history"]))
-    dev = float(np.max(np.abs(np.log10(np.asarray(hist[:n]) / np.asarray(ref["history"][:n])))))
-    assert dev < 0.1, dev     # same convergence curve (within 25 %) as the reference on the same process grid
+    dev = float(np.max(np.abs(np.asarray(hist[:n]) / np.asarray(ref["history"][:n]) - 1.0)))
+    assert dev < 2e-3, dev     # the reference's (scalar build) residual history on the same process grid, digit for digit at the start
     return dev * 1e-6
 
 

@@ -90,9 +90,9 @@ def test_decomposed_three_level_amg(nproc, grid, lattice):
 @pytest.mark.gpu
 @pytest.mark.parametrize("nproc,grid", [(2, "2,1,1,1"), (4, "2,2,1,1")])
 def test_sample_configuration_vs_reference_on_the_same_process_grid(nproc, grid):
-    """the reference itself, run on 2 and on 4 MPI ranks (oracle/run_reference_np2.sh -> tests/golden/ref_8x8_3lvl_np2.json,
-    ..._np4.json): 11 iterations (1.55e-11 / 1.46e-11); the decomposed GPU run must give the same count (+-1) and
-    convergence curve"""
+    """the reference itself (scalar build), run on 2 and on 4 MPI ranks (oracle/run_reference_np2.sh ->
+    tests/golden/ref_8x8_3lvl_np2.json, ..._np4.json): 11 iterations, 1.4156e-11 / 1.6707e-11; the decomposed GPU run must
+    give the same count and the same residual history to 2e-3 (measured: 7 digits at the first iteration)"""
     out = launch(nproc, "--mode", "sample_np2", "--grid", grid, "--tol", "1", timeout=600)
     assert f"sample.ini on {nproc} processes: 1" in out
 
