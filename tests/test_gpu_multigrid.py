@@ -205,7 +205,7 @@ def test_full_setup_and_solve_iteration_parity(gold4):
     assert rr < 1e-10
     hist = ctx.residual_history()
     # same convergence rate as the reference (history agrees within a factor 2 per step)
-    assert len(hist) == len(ref_hist) and np.all(np.abs(hist / ref_hist - 1.0) < 0.05)
+    assert len(hist) == len(ref_hist) and np.all(np.abs(hist / ref_hist - 1.0) < 5e-3)
     # true solution: D x = b
     from oracle import orc
     Dx = orc.dirac_apply(lattice(gold4), gold4["D"], gold4["clover"], x, 64)
@@ -271,7 +271,7 @@ def test_three_level_kcycle_solve(gold8, mp, fixture):
     # measured: identical to the reference -- 11 iterations, 192 coarse iterations, same history to 3 digits
     assert it == ref_it and rr < 1e-10
     hist = ctx.residual_history()
-    assert len(hist) == len(ref_hist) and np.all(np.abs(hist / ref_hist - 1.0) < 0.05)
+    assert len(hist) == len(ref_hist) and np.all(np.abs(hist / ref_hist - 1.0) < 5e-3)
     assert abs(cit - int(g3["ones_solve_iters"][1])) <= 10
     assert abs(rr / float(g3["ones_solve_norm_res"][0]) - 1.0) < 0.05
     from oracle import orc
@@ -294,7 +294,7 @@ def test_mixed_precision_2_amg(gold4):
     assert it == int(gm["ones_solve_iters"][0]) and abs(cit - int(gm["ones_solve_iters"][1])) <= 8
     assert rr < 1e-10 and abs(rr / float(gm["ones_solve_norm_res"][0]) - 1.0) < 0.2
     hist = ctx.residual_history(); ref = gm["ref_log_ones_history"]
-    assert len(hist) == len(ref) and np.all(np.abs(hist / ref - 1.0) < 0.05)
+    assert len(hist) == len(ref) and np.all(np.abs(hist / ref - 1.0) < 0.05)   # fp32 Krylov basis: the first iterations agree to 1e-7, the last ones to a few percent
     from oracle import orc
     assert relerr(orc.dirac_apply([4, 4, 4, 4], gold4["D"], gold4["clover"], x, 64), b) < 1e-9
     ctx.close()
@@ -383,5 +383,5 @@ def test_setup_and_solve_with_256_site_blocks_vs_reference(gold_b4, gold8):
     assert it == int(gold_b4["ones_solve_iters"][0]) == len(ref_hist)
     assert abs(cit - int(gold_b4["ones_solve_iters"][1])) <= 8 and rr < 1e-10
     hist = ctx.residual_history()
-    assert np.all(np.abs(hist / ref_hist - 1.0) < 0.05)
+    assert np.all(np.abs(hist / ref_hist - 1.0) < 5e-3)
     ctx.close()
