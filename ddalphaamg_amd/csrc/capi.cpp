@@ -189,6 +189,10 @@ static void install_comm(ddamg_hip_ctx* c, Comm* comm) {
   c->rw_outer.comm = comm; c->rw_blas.comm = comm; c->rw_mp.comm = comm;
   if (c->mg32) c->mg32->set_comm(comm);
   if (c->mg64) c->mg64->set_comm(comm);
+  // creating a communicator may draw from libc rand() inside the communication library (observed: the first RCCL
+  // communicator of a process does); the reference's test vectors come from the stream seeded at init and touched by
+  // nothing else (src/init.c:870-873), so restore that state
+  srand(1000u * (unsigned)c->levels[0]->geom.rank);
 }
 
 int ddamg_hip_comm_init_rccl(ddamg_hip_ctx* c, const void* id128) {

@@ -94,3 +94,35 @@ ctx.close()
 """
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "TORCH_RCCL_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_256_site_blocks_through_rccl_self_exchange(gold8):
+    """the production block shape (4^4 Schwarz blocks: resident-operator smoother kernel, arithmetic-neighbour stencil
+    kernel with process-boundary tiles, matrix-core Galerkin) through the transport, against the reference's run with
+    these blocks (tests/golden/ref_8x8_b4.npz: 15 iterations) -- same rand() stream, same hierarchy"""
+    from conftest import load_golden
+    gb = load_golden("ref_8x8_b4.npz")
+    p = api.default_params(); p.num_levels = 2
+    for mu in range(4):
+        p.local_lattice[0][mu] = 8; p.block_lattice[0][mu] = 4; p.local_lattice[1][mu] = 2
+        p.process_grid[mu] = -1
+    p.num_vect[0] = 20; p.post_smooth_iter[0] = 2; p.block_iter[0] = 4; p.setup_iter[0] = 3
+    p.restart, p.max_restart, p.tol = 50, 20, 1e-10
+    p.coarse_iter, p.coarse_restart, p.coarse_tol = 100, 5, 5e-2
+    p.mixed_precision, p.method, p.odd_even = 1, 2, 1
+    p.m0, p.csw = float(gb["meta_f64"][0]), float(gb["meta_f64"][1])
+    ctx = dd.Context(p)
+    ctx.comm_init_rccl(api.rccl_unique_id())
+    ctx.set_gauge(gold8["gauge"], anti_pbc=True)
+    eta = ctx.vector(0, 32).upload(gb["smoother_eta"]); phi = ctx.vector(0, 32)
+    ctx.setup(3)
+    # with the process as its own neighbour every block touches the process boundary on both sides, exactly as every
+    # block touches the lattice boundary in the undivided 2-blocks-per-direction run: the same block lists
+    ctx.smoother(phi, eta, 2, initial_guess_zero=True)
+    assert relerr(phi.download(), gb["smoother_nores_out_c2"]) < 5e-5
+    b = np.zeros((4096, 12, 2)); b[..., 0] = 1.0
+    x, it, cit, rr = ctx.solve(b, 1e-10)
+    ref_hist = gb["ref_log_ones_history"]
+    assert it == int(gb["ones_solve_iters"][0]) and rr < 1e-10
+    assert np.all(np.abs(ctx.residual_history() / ref_hist - 1.0) < 5e-3)
+    ctx.close()
