@@ -74,6 +74,11 @@ CASES = {
                    extra="d1 global lattice: 2 2 2 2\nd1 local lattice: 2 2 2 2", method=2, mp=1,
                    keep=["meta_int", "meta_f64", "smoother_eta", "smoother_phi0", "smoother_nores_out_c1", "smoother_nores_out_c2",
                          "smoother_nores_out_c3", "smoother_res_out_c2", "ones_solve_iters", "ones_solve_norm_res"]),
+    # production block shapes at a larger volume: 16^4, 4^4 blocks and aggregates on the fine level (-> 4^4), 2^4 on the
+    # coarse level (-> 2^4), K-cycle; seeded random links (the test regenerates them: conftest.random_su3(V*4, 1616))
+    "16x16_3lvl": dict(conf="", synthetic=1616, levels=3, L="16 16 16 16", B="4 4 4 4", nvec=24, setup=3, m0=0.3,
+                       extra="d1 global lattice: 4 4 4 4\nd1 local lattice: 4 4 4 4\nd1 block lattice: 2 2 2 2\nd1 post smooth iter: 2\nd1 block iter: 4\nd1 test vectors: 28\nd1 setup iter: 2",
+                       method=2, mp=1, keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),
     "8x8_gmres_mp2": dict(conf="conf/8x8x8x8b6.0000id3n1", levels=1, L="8 8 8 8", B="2 2 2 2", nvec=4, setup=0, extra="", method=0, mp=2,
                           keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),
 }

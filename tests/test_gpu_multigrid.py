@@ -385,3 +385,36 @@ def test_setup_and_solve_with_256_site_blocks_vs_reference(gold_b4, gold8):
     hist = ctx.residual_history()
     assert np.all(np.abs(hist / ref_hist - 1.0) < 5e-3)
     ctx.close()
+
+
+def test_three_level_production_block_shapes_16x16(tmp_path):
+    """16^4 with the block shapes of the production configurations -- 4^4 Schwarz blocks and aggregates on the fine level
+    (-> 4^4), 2^4 on the coarse level (-> 2^4), K-cycle, Nvec 24/28, setup 3 (+2) -- on seeded random links, against the
+    reference's run (tests/golden/ref_16x16_3lvl.npz): resident-operator smoother, matrix-core Galerkin construction on
+    both levels, arithmetic-neighbour stencil.  Same rand() stream, same iteration count and residual history."""
+    from conftest import load_golden, random_su3
+    g = load_golden("ref_16x16_3lvl.npz")
+    V = 16 ** 4
+    p = api.default_params(); p.num_levels = 3
+    for mu in range(4):
+        p.local_lattice[0][mu] = 16; p.block_lattice[0][mu] = 4
+        p.local_lattice[1][mu] = 4; p.block_lattice[1][mu] = 2
+        p.local_lattice[2][mu] = 2
+    p.num_vect[0] = 24; p.num_vect[1] = 28
+    p.post_smooth_iter[0] = p.post_smooth_iter[1] = 2; p.block_iter[0] = p.block_iter[1] = 4
+    p.setup_iter[0] = 3; p.setup_iter[1] = 2
+    p.restart, p.max_restart, p.tol = 50, 20, 1e-10
+    p.coarse_iter, p.coarse_restart, p.coarse_tol = 100, 5, 5e-2
+    p.mixed_precision, p.method, p.odd_even = 1, 2, 1
+    p.m0, p.csw = float(g["meta_f64"][0]), float(g["meta_f64"][1])
+    ctx = dd.Context(p)
+    plaq = ctx.set_gauge(random_su3(V * 4, 1616).reshape(V, 4, 9, 2), anti_pbc=True)
+    assert abs(plaq - float(g["meta_f64"][2])) < 1e-10
+    ctx.setup(3)
+    b = np.zeros((V, 12, 2)); b[..., 0] = 1.0
+    x, it, cit, rr = ctx.solve(b, 1e-10)
+    ref_hist = g["ref_log_ones_history"]
+    assert it == int(g["ones_solve_iters"][0]) == len(ref_hist) and rr < 1e-10
+    assert abs(cit - int(g["ones_solve_iters"][1])) <= max(3, int(g["ones_solve_iters"][1]) // 20)
+    assert np.all(np.abs(ctx.residual_history() / ref_hist - 1.0) < 5e-3)
+    ctx.close()
