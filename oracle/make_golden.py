@@ -79,6 +79,10 @@ CASES = {
     "16x16_3lvl": dict(conf="", synthetic=1616, levels=3, L="16 16 16 16", B="4 4 4 4", nvec=24, setup=3, m0=0.3,
                        extra="d1 global lattice: 4 4 4 4\nd1 local lattice: 4 4 4 4\nd1 block lattice: 2 2 2 2\nd1 post smooth iter: 2\nd1 block iter: 4\nd1 test vectors: 28\nd1 setup iter: 2",
                        method=2, mp=1, keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),
+    # the same hierarchy on smooth links (bench.near_unit_gauge(V, 0.35, 1617)), m0 = -0.3: a hard system
+    "16x16_3lvl_hard": dict(conf="", synthetic=1617, near_unit=True, levels=3, L="16 16 16 16", B="4 4 4 4", nvec=24, setup=3, m0=-0.3,
+                            extra="d1 global lattice: 4 4 4 4\nd1 local lattice: 4 4 4 4\nd1 block lattice: 2 2 2 2\nd1 post smooth iter: 2\nd1 block iter: 4\nd1 test vectors: 28\nd1 setup iter: 2",
+                            method=2, mp=1, keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),
     "8x8_gmres_mp2": dict(conf="conf/8x8x8x8b6.0000id3n1", levels=1, L="8 8 8 8", B="2 2 2 2", nvec=4, setup=0, extra="", method=0, mp=2,
                           keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),
 }
@@ -97,7 +101,12 @@ def run_case(name):
         sys.path.insert(0, os.path.join(REPO, "tests"))
         from conftest import random_su3
         Ls = [int(x) for x in cfg["L"].split()]
-        U = random_su3(int(np.prod(Ls)) * 4, synthetic)
+        if cfg.pop("near_unit", False):
+            sys.path.insert(0, REPO)
+            from bench import near_unit_gauge      # smooth links exp(i 0.35 H): a system on which multigrid has work to do
+            U = near_unit_gauge(int(np.prod(Ls)), 0.35, synthetic)
+        else:
+            U = random_su3(int(np.prod(Ls)) * 4, synthetic)
         cfg["conf"] = os.path.join(tmp, "synthetic.conf")
         with open(cfg["conf"], "wb") as f:
             f.write(np.asarray(Ls, dtype="<i4").tobytes()); f.write(np.asarray([0.0], dtype="<f8").tobytes())

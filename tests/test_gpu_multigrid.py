@@ -387,13 +387,15 @@ def test_setup_and_solve_with_256_site_blocks_vs_reference(gold_b4, gold8):
     ctx.close()
 
 
-def test_three_level_production_block_shapes_16x16(tmp_path):
+@pytest.mark.parametrize("fixture", ["ref_16x16_3lvl.npz", "ref_16x16_3lvl_hard.npz"], ids=["random-links", "smooth-links"])
+def test_three_level_production_block_shapes_16x16(fixture):
     """16^4 with the block shapes of the production configurations -- 4^4 Schwarz blocks and aggregates on the fine level
-    (-> 4^4), 2^4 on the coarse level (-> 2^4), K-cycle, Nvec 24/28, setup 3 (+2) -- on seeded random links, against the
-    reference's run (tests/golden/ref_16x16_3lvl.npz): resident-operator smoother, matrix-core Galerkin construction on
-    both levels, arithmetic-neighbour stencil.  Same rand() stream, same iteration count and residual history."""
+    (-> 4^4), 2^4 on the coarse level (-> 2^4), K-cycle, Nvec 24/28, setup 3 (+2) -- against the reference's runs on
+    seeded random links (m0 0.3, an easy system) and on smooth links exp(0.35 i H) (m0 -0.3, a hard one):
+    resident-operator smoother, matrix-core Galerkin construction on both levels, arithmetic-neighbour stencil.
+    Same rand() stream, same iteration count and residual history."""
     from conftest import load_golden, random_su3
-    g = load_golden("ref_16x16_3lvl.npz")
+    g = load_golden(fixture)
     V = 16 ** 4
     p = api.default_params(); p.num_levels = 3
     for mu in range(4):
@@ -408,7 +410,14 @@ def test_three_level_production_block_shapes_16x16(tmp_path):
     p.mixed_precision, p.method, p.odd_even = 1, 2, 1
     p.m0, p.csw = float(g["meta_f64"][0]), float(g["meta_f64"][1])
     ctx = dd.Context(p)
-    plaq = ctx.set_gauge(random_su3(V * 4, 1616).reshape(V, 4, 9, 2), anti_pbc=True)
+    if "hard" in fixture:
+        import os, sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from bench import near_unit_gauge
+        U = near_unit_gauge(V, 0.35, 1617)
+    else:
+        U = random_su3(V * 4, 1616).reshape(V, 4, 9, 2)
+    plaq = ctx.set_gauge(U, anti_pbc=True)
     assert abs(plaq - float(g["meta_f64"][2])) < 1e-10
     ctx.setup(3)
     b = np.zeros((V, 12, 2)); b[..., 0] = 1.0
