@@ -9,6 +9,7 @@
 #include "common.h"
 #include "geometry.h"
 #include "coarse_op.h"
+#include <vector>
 
 namespace ddamg {
 
@@ -32,16 +33,17 @@ template <typename T>
 class CoarseSap {
  public:
   ~CoarseSap();
-  void setup(const Geometry& g, const CoarseOp<T>* op, int block_iter, hipStream_t st);
+  void setup(const Geometry& g, const CoarseOp<T>* op, int block_iter, int method, hipStream_t st);
   void smooth(T* phi, T* Dphi, const T* eta, int cycles, int res, hipStream_t st);
   T *r = nullptr, *latest = nullptr, *x = nullptr, *tmp = nullptr;
 
  private:
   const CoarseOp<T>* op_ = nullptr;
   int V_ = 0, n_ = 0, BS_ = 0, block_iter_ = 4;
-  int nblk_[3] = {0, 0, 0};       // colour 0, colour 1, colour 1 without the reference's lists 4 and 5
-  int* d_blocks_[3] = {nullptr, nullptr, nullptr};
-  int* d_sites_[3] = {nullptr, nullptr, nullptr};
+  enum Schedule { ADDITIVE, RED_BLACK, SIXTEEN, TWO_COLOR } schedule_ = RED_BLACK;
+  int ncolors_ = 2;
+  std::vector<int> nblk_;         // per colour (+ for red-black: colour 1 without the reference's lists 4 and 5)
+  std::vector<int*> d_blocks_, d_sites_;
   unsigned char* d_blk_face_ = nullptr;
 };
 

@@ -218,23 +218,32 @@ __global__ void block_minres_kernel(T* __restrict__ lphi, T* __restrict__ r, con
 
 template <typename T> CoarseSap<T>::~CoarseSap() {
   for (T* p : {r, latest, x, tmp}) if (p) (void)hipFree(p);
-  for (int i = 0; i < 3; i++) { if (d_blocks_[i]) (void)hipFree(d_blocks_[i]); if (d_sites_[i]) (void)hipFree(d_sites_[i]); }
+  for (int* p : d_blocks_) if (p) (void)hipFree(p);
+  for (int* p : d_sites_) if (p) (void)hipFree(p);
   if (d_blk_face_) (void)hipFree(d_blk_face_);
 }
 
 template <typename T>
-void CoarseSap<T>::setup(const Geometry& g, const CoarseOp<T>* op, int block_iter, hipStream_t st) {
+void CoarseSap<T>::setup(const Geometry& g, const CoarseOp<T>* op, int block_iter, int method, hipStream_t st) {
   op_ = op; V_ = g.V; n_ = op->n(); BS_ = g.block_sites; block_iter_ = block_iter;
-  for (int mu = 0; mu < 4; mu++) DDAMG_REQUIRE((g.nblk[mu] * g.P[mu]) % 2 == 0, "red-black SAP needs an even number of blocks per direction of the global lattice");
+  DDAMG_REQUIRE(method >= 1 && method <= 3, "Schwarz smoother: method must be 1 (additive), 2 (red-black) or 3 (sixteen colours)");
+  // same colourings as on the fine level (schwarz_layout_PRECISION_define, src/schwarz_generic.c:318-333)
+  schedule_ = method == 1 ? ADDITIVE : method == 2 ? RED_BLACK : !g.block_color16.empty() ? SIXTEEN : TWO_COLOR;
+  ncolors_ = schedule_ == ADDITIVE ? 1 : schedule_ == SIXTEEN ? 16 : 2;
+  if (schedule_ != ADDITIVE)
+    for (int mu = 0; mu < 4; mu++) DDAMG_REQUIRE((g.nblk[mu] * g.P[mu]) % 2 == 0, "multiplicative SAP needs an even number of blocks per direction of the global lattice");
   const size_t nel = (size_t)V_ * n_ * 2;
   for (T** p : {&r, &latest, &x, &tmp}) { DDAMG_HIP_CHECK(device_alloc(p, sizeof(T) * nel)); DDAMG_HIP_CHECK(hipMemsetAsync(*p, 0, sizeof(T) * nel, st)); }
-  std::vector<int> bl[3], sl[3];
+  // one list per colour; red-black keeps a second list of colour 1 without the reference's lists 4 and 5
+  const int nlists = ncolors_ + (schedule_ == RED_BLACK ? 1 : 0);
+  std::vector<std::vector<int>> bl(nlists), sl(nlists);
   for (int b = 0; b < g.num_blocks; b++) {
-    const int c = g.block_color[b];
+    const int c = schedule_ == ADDITIVE ? 0 : schedule_ == SIXTEEN ? g.block_color16[b] : g.block_color[b];
     bl[c].push_back(b);
-    if (c == 1 && g.block_list[b] != 4 && g.block_list[b] != 5) bl[2].push_back(b);
+    if (schedule_ == RED_BLACK && c == 1 && g.block_list[b] != 4 && g.block_list[b] != 5) bl[2].push_back(b);
   }
-  for (int i = 0; i < 3; i++) {
+  nblk_.assign(nlists, 0); d_blocks_.assign(nlists, nullptr); d_sites_.assign(nlists, nullptr);
+  for (int i = 0; i < nlists; i++) {
     for (int b : bl[i]) for (int k = 0; k < BS_; k++) sl[i].push_back(b * BS_ + k);
     nblk_[i] = (int)bl[i].size();
     if (nblk_[i] == 0) continue;
@@ -243,7 +252,7 @@ void CoarseSap<T>::setup(const Geometry& g, const CoarseOp<T>* op, int block_ite
     DDAMG_HIP_CHECK(device_alloc(&d_sites_[i], sizeof(int) * sl[i].size()));
     DDAMG_HIP_CHECK(hipMemcpyAsync(d_sites_[i], sl[i].data(), sizeof(int) * sl[i].size(), hipMemcpyHostToDevice, st));
   }
-  DDAMG_REQUIRE(nblk_[0] > 0 && nblk_[1] > 0, "red-black SAP needs blocks of both colours");
+  for (int c = 0; c < ncolors_; c++) DDAMG_REQUIRE(nblk_[c] > 0, "SAP needs blocks of every colour");
   DDAMG_HIP_CHECK(device_alloc(&d_blk_face_, V_));
   DDAMG_HIP_CHECK(hipMemcpyAsync(d_blk_face_, g.blk_face.data(), V_, hipMemcpyHostToDevice, st));
   DDAMG_HIP_CHECK(hipStreamSynchronize(st));
@@ -259,30 +268,49 @@ void CoarseSap<T>::smooth(T* phi, T* Dphi, const T* eta, int cycles, int res, hi
   const double eps = sizeof(T) == 4 ? 1e-6 : 1e-14;
   const int init_res = res;
   if (res == NO_RES) { vec_copy<T>(r, eta, all, st); vec_zero<T>(x, all, st); }
-  else vec_copy<T>(x, phi, all, st);
+  else {
+    vec_copy<T>(x, phi, all, st);
+    if (schedule_ == ADDITIVE) vec_copy<T>(latest, phi, all, st);
+  }
   for (int k = 0; k < cycles; k++)
-    for (int color = 0; color < 2; color++) {
+    for (int color = 0; color < ncolors_; color++) {
       const int li = color;
-      if (k == 0 && init_res == RES) {
-        // r_b = eta_b - (D x)_b   (coarse_block_operator + coarse_block_boundary_op)
-        op_->apply_masked(tmp, x, d_sites_[li], nblk_[li] * BS_, nullptr, false, 1.0, -1.0, false, st);
+      // which residual update the blocks of this colour get: see SapSmoother<T>::smooth (sap.hip) for the four schedules
+      bool full, none = false;
+      int lj = li;
+      if (schedule_ == RED_BLACK) {
+        full = k == 0 && init_res == RES;
+        none = k == 0 && init_res == NO_RES && color == 0;
+        if (k == 0 && init_res == NO_RES) lj = 2;      // the first sweep from zero skips lists 4,5
+      } else if (schedule_ == TWO_COLOR) {
+        full = k == 0 && init_res == RES; none = res == NO_RES;
+      } else {
+        full = k == 0; none = res == NO_RES;
+      }
+      if (none) {
+      } else if (full) {
+        // r_b = eta_b - (D x)_b   (coarse_block_operator + coarse_block_boundary_op); the additive method takes the
+        // start vector (kept in latest), the blocks being solved side by side
+        op_->apply_masked(tmp, schedule_ == ADDITIVE ? latest : x, d_sites_[li], nblk_[li] * BS_, nullptr, false, 1.0, -1.0, false, st);
         hipLaunchKernelGGL((block_ew_kernel<T, BOP_ETA_MINUS>), dim3(nblk_[li]), dim3(256), 0, st, r, eta, tmp, d_blocks_[li], blen);
-      } else if (!(k == 0 && init_res == NO_RES && color == 0)) {
-        // r_b -= D_{b,ext} latest  (n_coarse_block_boundary_op); the first sweep from zero skips lists 4,5
-        const int lj = (k == 0 && init_res == NO_RES) ? 2 : li;
+      } else {
+        // r_b -= D_{b,ext} latest  (n_coarse_block_boundary_op)
         if (nblk_[lj] > 0) op_->apply_masked(r, latest, d_sites_[lj], nblk_[lj] * BS_, d_blk_face_, false, 0.0, +1.0, true, st);
       }
-      // local_minres on every block of this colour
+      // local_minres on every block of this colour (with one colour all reads of the previous generation of updates are
+      // done by now, so the same buffer takes the new one)
       hipLaunchKernelGGL((block_ew_kernel<T, BOP_ZERO>), dim3(nblk_[li]), dim3(256), 0, st, latest, (const T*)nullptr, (const T*)nullptr, d_blocks_[li], blen);
       for (int it = 0; it < block_iter_; it++) {
         op_->apply_masked(tmp, r, d_sites_[li], nblk_[li] * BS_, d_blk_face_, true, 1.0, -1.0, false, st);   // Dr = D_block r
         hipLaunchKernelGGL(block_minres_kernel<T>, dim3(nblk_[li]), dim3(256), 0, st, latest, r, tmp, d_blocks_[li], blen / 2, eps);
       }
       hipLaunchKernelGGL((block_ew_kernel<T, BOP_ADD>), dim3(nblk_[li]), dim3(256), 0, st, x, latest, (const T*)nullptr, d_blocks_[li], blen);
+      res = RES;
     }
   DDAMG_HIP_CHECK(hipGetLastError());
   vec_copy<T>(phi, x, all, st);
   if (Dphi != nullptr) {
+    DDAMG_REQUIRE(schedule_ != SIXTEEN, "the sixteen-colour smoother does not return D*phi");
     op_->apply_masked(r, latest, d_sites_[0], nblk_[0] * BS_, d_blk_face_, false, 0.0, +1.0, true, st);
     vec_minus<T>(Dphi, eta, r, all, st);
   }

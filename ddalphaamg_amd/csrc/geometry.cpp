@@ -35,6 +35,9 @@ void Geometry::build(const int L_[4], const int B_[4], const int A_[4], const in
   parity.assign(V, 0);
   block_color.assign(num_blocks, 0);
   block_list.assign(num_blocks, 0);
+  bool sixteen = true;
+  for (int mu = 0; mu < 4; mu++) if (nblk[mu] % 2) sixteen = false;
+  block_color16.assign(sixteen ? num_blocks : 0, 0);
 
   // enumerate: aggregates -> blocks in aggregate -> parity -> lexicographic in block
   int bpa[4];  // blocks per aggregate per direction
@@ -66,6 +69,12 @@ void Geometry::build(const int L_[4], const int B_[4], const int A_[4], const in
       else if (plus == 0) list = col == 0 ? 3 : 5;
       else list = 2 + 4 * col;
       block_list[blk] = list;
+      if (sixteen) {
+        // position k of the corner 8(t%2)+4(z%2)+2(y%2)+(x%2) of the 2^4 cell in the reference's walk through it
+        static const int sigma[16] = {0, 1, 3, 2, 6, 4, 5, 7, 15, 14, 12, 13, 9, 11, 10, 8};
+        const int corner = 8 * (gb[0] % 2) + 4 * (gb[1] % 2) + 2 * (gb[2] % 2) + (gb[3] % 2);
+        for (int k = 0; k < 16; k++) if (sigma[k] == corner) block_color16[blk] = k;
+      }
       for (int par = 0; par < 2; par++)
         for (r[0] = 0; r[0] < B[0]; r[0]++) for (r[1] = 0; r[1] < B[1]; r[1]++)
         for (r[2] = 0; r[2] < B[2]; r[2]++) for (r[3] = 0; r[3] < B[3]; r[3]++) {

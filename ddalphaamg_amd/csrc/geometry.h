@@ -44,6 +44,8 @@ struct Geometry {
   std::vector<int> blk_nb;       // [8*block_sites] in-block neighbour (block-local index) or -1
   std::vector<int> block_color;  // [num_blocks] red-black colour (src/schwarz_generic.c:383-395)
   std::vector<int> block_list;   // [num_blocks] 0..7: red-black list of the reference (:415-428)
+  std::vector<int> block_color16;  // [num_blocks] colour 0..15 of the 16-colour smoother (:325-333,387-394); empty when a
+                                   // direction has an odd number of local blocks (the reference then falls back to 2 colours)
   int block_even_sites = 0;      // number of block-local even sites (first in the block)
   std::vector<unsigned char> blk_face;  // [V] bit d set: the neighbour in direction d lies outside the site's Schwarz block
   std::vector<unsigned char> agg_face;  // [V] bit d set: the neighbour in direction d lies outside the site's aggregate

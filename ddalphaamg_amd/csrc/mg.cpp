@@ -33,8 +33,8 @@ Multigrid<T>::Multigrid(const ddamg_hip_params& par, const std::vector<const Geo
     if (d == 0) lv.fop = fop;
     else lv.cop.alloc(g, lv.n);
     if (!lv.coarsest) {
-      if (d == 0) { lv.fsap.setup(g, fop, par.block_iter[0], st_); lv.fip.alloc(g, *geoms[1], lv.nvec); }
-      else { lv.csap.setup(g, &lv.cop, par.block_iter[d], st_); lv.cip.alloc(g, *geoms[d + 1], lv.n, lv.nvec); }
+      if (d == 0) { lv.fsap.setup(g, fop, par.block_iter[0], par.method, st_); lv.fip.alloc(g, *geoms[1], lv.nvec); }
+      else { lv.csap.setup(g, &lv.cop, par.block_iter[d], par.method, st_); lv.cip.alloc(g, *geoms[d + 1], lv.n, lv.nvec); }
       DDAMG_HIP_CHECK(device_alloc(&lv.d_agg_face, g.V));
       DDAMG_HIP_CHECK(hipMemcpy(lv.d_agg_face, g.agg_face.data(), g.V, hipMemcpyHostToDevice));
       for (int mu = 0; mu < 4; mu++) {
@@ -53,8 +53,8 @@ Multigrid<T>::Multigrid(const ddamg_hip_params& par, const std::vector<const Geo
       lv.gm.view = whole(lv.nel);
       lv.gm.st = st_; lv.gm.rw = &lv.rw;
       lv.gm.op = [this, d](T* out, const T* in) { this->apply_op(d, out, in); };
-      lv.gm.prec = [this, d](T* phi, T* Dphi, const T* eta, int res) { this->vcycle(d, phi, Dphi, eta, res); };
-      lv.gm.prec_gives_Dphi = par.mixed_precision == 2;   // src/linsolve_generic.c:832-835
+      lv.gm.prec = [this, d](T* phi, T* Dphi, const T* eta, int res) { this->vcycle(d, phi, par_.method <= 2 ? Dphi : nullptr, eta, res); };
+      lv.gm.prec_gives_Dphi = par.mixed_precision == 2 && par.method <= 2;   // src/linsolve_generic.c:757,828-835
       // the reference's vector loops visit this level aggregate -> block -> lexicographic inside the block
       // (src/gathering_generic.c:126-157); ours orders block sites by parity first
       lv.ref_order.reserve(g.V);

@@ -16,6 +16,7 @@
 #include "common.h"
 #include "geometry.h"
 #include "fine_op.h"
+#include <vector>
 
 namespace ddamg {
 
@@ -32,7 +33,8 @@ template <typename T>
 class SapSmoother {
  public:
   ~SapSmoother();
-  void setup(const Geometry& g, const FineOp<T>* op, int block_iter, hipStream_t st);
+  // method: 1 additive, 2 red-black, 3 sixteen colours (g.method of the reference, src/vcycle_generic.c:33-39)
+  void setup(const Geometry& g, const FineOp<T>* op, int block_iter, int method, hipStream_t st);
   // phi = smoothed iterate after `cycles` red-black sweeps.  res==NO_RES: start from phi=0, r=eta;
   // res==RES: start from the given phi.  (Dphi output of the reference's mixed_precision==2 path is
   // produced when Dphi != nullptr.)
@@ -44,11 +46,12 @@ class SapSmoother {
  private:
   const FineOp<T>* op_ = nullptr;
   int V_ = 0, BS_ = 0, HS_ = 0, nblocks_ = 0, block_iter_ = 4;
-  int ncol_[2] = {0, 0};
-  int ncol_interior_[2] = {0, 0};                  // the first ncol_interior_[c] blocks of a colour list have no site next to another process
+  enum Schedule { ADDITIVE, RED_BLACK, SIXTEEN, TWO_COLOR } schedule_ = RED_BLACK;
+  std::vector<int> ncol_, ncol_interior_;          // blocks per colour; the first ncol_interior_[c] of them have no site next to another process
   int* d_blk_nb_ = nullptr;
   int* d_block_list_ = nullptr;
-  int* d_color_blocks_[2] = {nullptr, nullptr};  // block indices per colour
+  std::vector<int*> d_color_blocks_;               // block indices per colour
+  T* latest2_ = nullptr;                           // additive method: the other generation of block updates
   void launch(int color, int mode_default, unsigned skip_mask, const T* eta, hipStream_t st);
 };
 

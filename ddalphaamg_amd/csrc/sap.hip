@@ -15,7 +15,10 @@ enum { MODE_NONE = 0, MODE_NBOUNDARY = 1, MODE_FULLRES = 2 };
 template <typename T>
 struct SapArgs {
   SapDev<T> s;
-  T* x; T* r; T* latest;
+  T* x; T* r;
+  const T* latest;       // block updates the residual is brought up to date with (MODE_NBOUNDARY)
+  T* latest_out;         // this solve's update (== latest except in the additive method, which keeps two generations)
+  const T* res_src;      // iterate the full residual is computed from (MODE_FULLRES): x, or the additive method's copy of phi
   const T* eta;          // only read in MODE_FULLRES
   const int* blocks;     // block indices to process
   int nblocks;           // number of entries in `blocks`
@@ -173,15 +176,15 @@ __global__ __launch_bounds__((HS < 64 ? 64 : HS)) void sap_block_kernel(SapArgs<
   if (mode == MODE_FULLRES) {
     // r_b = eta_b - (D x)_b with the full operator, x from global memory (block_op + boundary_op)
     T xs[24], e[24], et[24];
-    load_site<T, 24>(a.x, V, se, xs);
+    load_site<T, 24>(a.res_src, V, se, xs);
     clover_apply<T>(op.clover, V, se, xs, e);
-    ext_hops<T, DIST>(a.x, op, se, 0xffu, e);
+    ext_hops<T, DIST>(a.res_src, op, se, 0xffu, e);
     load_site<T, 24>(a.eta, V, se, et);
 #pragma unroll
     for (int k = 0; k < 24; k++) re[k] = et[k] - e[k];
-    load_site<T, 24>(a.x, V, so, xs);
+    load_site<T, 24>(a.res_src, V, so, xs);
     clover_apply<T>(op.clover, V, so, xs, e);
-    ext_hops<T, DIST>(a.x, op, so, 0xffu, e);
+    ext_hops<T, DIST>(a.res_src, op, so, 0xffu, e);
     load_site<T, 24>(a.eta, V, so, et);
 #pragma unroll
     for (int k = 0; k < 24; k++) ro[k] = et[k] - e[k];
@@ -291,13 +294,13 @@ __global__ __launch_bounds__((HS < 64 ? 64 : HS)) void sap_block_kernel(SapArgs<
 #pragma unroll
     for (int k = 0; k < 24; k++) xs[k] += lphi[k];
     store_site<T, 24>(a.x, V, se, xs);
-    store_site<T, 24>(a.latest, V, se, lphi);
+    store_site<T, 24>(a.latest_out, V, se, lphi);
     store_site<T, 24>(a.r, V, se, rm);
     load_site<T, 24>(a.x, V, so, xs);
 #pragma unroll
     for (int k = 0; k < 24; k++) { xs[k] += to[k]; rm[k] = 0; }
     store_site<T, 24>(a.x, V, so, xs);
-    store_site<T, 24>(a.latest, V, so, to);
+    store_site<T, 24>(a.latest_out, V, so, to);
     store_site<T, 24>(a.r, V, so, rm);
   }
 }
@@ -436,9 +439,9 @@ __global__ __launch_bounds__((BS < 64 ? 64 : BS), (sizeof(T) == 4 ? 2 : 1)) void
   T v0[24];   // r, then (even) the MinRes residual rm
   if (mode == MODE_FULLRES) {
     T xs[24], e[24], et[24];
-    load_site<T, 24>(a.x, V, s, xs);
+    load_site<T, 24>(a.res_src, V, s, xs);
     clover_apply<T>(op.clover, V, s, xs, e);
-    ext_hops<T, DIST>(a.x, op, s, 0xffu, e);
+    ext_hops<T, DIST>(a.res_src, op, s, 0xffu, e);
     load_site<T, 24>(a.eta, V, s, et);
 #pragma unroll
     for (int k = 0; k < 24; k++) v0[k] = et[k] - e[k];
@@ -553,7 +556,7 @@ __global__ __launch_bounds__((BS < 64 ? 64 : BS), (sizeof(T) == 4 ? 2 : 1)) void
 #pragma unroll
     for (int k = 0; k < 24; k++) xs[k] += v1[k];
     store_site<T, 24>(a.x, V, s, xs);
-    store_site<T, 24>(a.latest, V, s, v1);
+    store_site<T, 24>(a.latest_out, V, s, v1);
     store_site<T, 24>(a.r, V, s, v0);
   }
 }
@@ -564,20 +567,28 @@ template <typename T>
 SapSmoother<T>::~SapSmoother() {
   if (r) (void)hipFree(r);
   if (latest) (void)hipFree(latest);
+  if (latest2_) (void)hipFree(latest2_);
   if (x) (void)hipFree(x);
   if (d_blk_nb_) (void)hipFree(d_blk_nb_);
   if (d_block_list_) (void)hipFree(d_block_list_);
-  for (int c = 0; c < 2; c++) if (d_color_blocks_[c]) (void)hipFree(d_color_blocks_[c]);
+  for (int* p : d_color_blocks_) if (p) (void)hipFree(p);
 }
 
 template <typename T>
-void SapSmoother<T>::setup(const Geometry& g, const FineOp<T>* op, int block_iter, hipStream_t st) {
+void SapSmoother<T>::setup(const Geometry& g, const FineOp<T>* op, int block_iter, int method, hipStream_t st) {
   op_ = op; V_ = g.V; BS_ = g.block_sites; HS_ = g.block_sites / 2; nblocks_ = g.num_blocks; block_iter_ = block_iter;
+  DDAMG_REQUIRE(method >= 1 && method <= 3, "Schwarz smoother: method must be 1 (additive), 2 (red-black) or 3 (sixteen colours)");
   DDAMG_REQUIRE(g.block_even_sites * 2 == g.block_sites, "Schwarz blocks need as many even as odd sites (even block extents)");
   DDAMG_REQUIRE(HS_ == 8 || HS_ == 16 || HS_ == 32 || HS_ == 64 || HS_ == 128 || HS_ == 256,
                 "Schwarz block volume must be 16..512 sites and a power of two on the GPU smoother");
-  for (int mu = 0; mu < 4; mu++)
-    DDAMG_REQUIRE((g.nblk[mu] * g.P[mu]) % 2 == 0, "red-black SAP needs an even number of blocks per direction of the global lattice");
+  // colouring (schwarz_layout_PRECISION_define, src/schwarz_generic.c:318-333): 1 colour for the additive method, 2 for
+  // red-black, 16 for the sixteen-colour method -- which, like the reference, drops to the plain two-colour sweep
+  // (schwarz_PRECISION, :1433-1650) when a direction holds an odd number of local blocks
+  schedule_ = method == 1 ? ADDITIVE : method == 2 ? RED_BLACK : !g.block_color16.empty() ? SIXTEEN : TWO_COLOR;
+  const int ncolors = schedule_ == ADDITIVE ? 1 : schedule_ == SIXTEEN ? 16 : 2;
+  if (schedule_ != ADDITIVE)
+    for (int mu = 0; mu < 4; mu++)
+      DDAMG_REQUIRE((g.nblk[mu] * g.P[mu]) % 2 == 0, "multiplicative SAP needs an even number of blocks per direction of the global lattice");
   const size_t n = (size_t)24 * V_;
   DDAMG_HIP_CHECK(device_alloc(&r, sizeof(T) * n));
   DDAMG_HIP_CHECK(device_alloc(&latest, sizeof(T) * n));
@@ -585,23 +596,29 @@ void SapSmoother<T>::setup(const Geometry& g, const FineOp<T>* op, int block_ite
   DDAMG_HIP_CHECK(hipMemsetAsync(r, 0, sizeof(T) * n, st));
   DDAMG_HIP_CHECK(hipMemsetAsync(latest, 0, sizeof(T) * n, st));
   DDAMG_HIP_CHECK(hipMemsetAsync(x, 0, sizeof(T) * n, st));
+  if (schedule_ == ADDITIVE) {
+    DDAMG_HIP_CHECK(device_alloc(&latest2_, sizeof(T) * n));
+    DDAMG_HIP_CHECK(hipMemsetAsync(latest2_, 0, sizeof(T) * n, st));
+  }
   DDAMG_HIP_CHECK(device_alloc(&d_blk_nb_, sizeof(int) * 8 * BS_));
   DDAMG_HIP_CHECK(hipMemcpyAsync(d_blk_nb_, g.blk_nb.data(), sizeof(int) * 8 * BS_, hipMemcpyHostToDevice, st));
   DDAMG_HIP_CHECK(device_alloc(&d_block_list_, sizeof(int) * nblocks_));
   DDAMG_HIP_CHECK(hipMemcpyAsync(d_block_list_, g.block_list.data(), sizeof(int) * nblocks_, hipMemcpyHostToDevice, st));
   // per colour: blocks without a neighbour on another process first (their solves overlap with the halo exchange)
-  std::vector<int> cb[2], cbb[2];
+  std::vector<std::vector<int>> cb(ncolors), cbb(ncolors);
   for (int b = 0; b < nblocks_; b++) {
     bool boundary = false;
     for (int i = 0; i < BS_ && !boundary; i++)
       for (int d = 0; d < 8; d++) if (g.nb[(size_t)d * V_ + (size_t)b * BS_ + i] < 0) { boundary = true; break; }
-    (boundary ? cbb : cb)[g.block_color[b]].push_back(b);
+    const int c = schedule_ == ADDITIVE ? 0 : schedule_ == SIXTEEN ? g.block_color16[b] : g.block_color[b];
+    (boundary ? cbb : cb)[c].push_back(b);
   }
-  for (int c = 0; c < 2; c++) {
+  ncol_.assign(ncolors, 0); ncol_interior_.assign(ncolors, 0); d_color_blocks_.assign(ncolors, nullptr);
+  for (int c = 0; c < ncolors; c++) {
     ncol_interior_[c] = (int)cb[c].size();
     cb[c].insert(cb[c].end(), cbb[c].begin(), cbb[c].end());
     ncol_[c] = (int)cb[c].size();
-    DDAMG_REQUIRE(ncol_[c] > 0, "red-black SAP needs blocks of both colours");
+    DDAMG_REQUIRE(ncol_[c] > 0, "SAP needs blocks of every colour");
     DDAMG_HIP_CHECK(device_alloc(&d_color_blocks_[c], sizeof(int) * ncol_[c]));
     DDAMG_HIP_CHECK(hipMemcpyAsync(d_color_blocks_[c], cb[c].data(), sizeof(int) * ncol_[c], hipMemcpyHostToDevice, st));
   }
@@ -639,7 +656,8 @@ void SapSmoother<T>::launch(int color, int mode, unsigned skip_mask, const T* et
   SapArgs<T> a;
   a.s.op = op_->dev(); a.s.blk_nb = d_blk_nb_; a.s.block_list = d_block_list_;
   a.s.block_sites = BS_; a.s.half_sites = HS_; a.s.block_iter = block_iter_;
-  a.x = x; a.r = r; a.latest = latest; a.eta = eta;
+  a.x = x; a.r = r; a.latest = latest; a.latest_out = latest; a.res_src = x; a.eta = eta;
+  if (schedule_ == ADDITIVE) { a.latest_out = latest2_; a.res_src = latest; }   // two generations of updates; x is being written
   a.blocks = d_color_blocks_[color]; a.nblocks = ncol_[color];
   a.mode = mode < 0 ? MODE_NBOUNDARY : mode; a.skip_mask = skip_mask; a.solve = mode < 0 ? 0 : 1;
   // couplings to blocks on neighbouring processes: the reference exchanges the ghost shell of latest_iter
@@ -663,7 +681,7 @@ void SapSmoother<T>::launch(int color, int mode, unsigned skip_mask, const T* et
   if (op_->distributed() && a.mode != MODE_NONE) {
     // exchange in flight while the blocks away from the process boundary are solved; blocks of one colour are
     // independent of each other, so the split changes nothing in the result
-    op_->halo_begin(a.mode == MODE_FULLRES ? x : latest, st);
+    op_->halo_begin(a.mode == MODE_FULLRES ? a.res_src : a.latest, st);
     run(d_color_blocks_[color], ncol_interior_[color]);
     op_->halo_finish(st);
     run(d_color_blocks_[color] + ncol_interior_[color], ncol_[color] - ncol_interior_[color]);
@@ -678,29 +696,47 @@ void SapSmoother<T>::smooth(T* phi, T* Dphi, const T* eta, int cycles, int res, 
   DDAMG_REQUIRE(phi != eta, "smoother: phi and eta must differ");  // ASSERT( phi != eta ), src/vcycle_generic.c:28
   const View all = whole((size_t)24 * V_);
   const int init_res = res;
+  const int ncolors = (int)ncol_.size();
   if (res == NO_RES) {
     vec_copy<T>(r, eta, all, st);
     vec_zero<T>(x, all, st);
   } else {
     vec_copy<T>(x, phi, all, st);
+    if (schedule_ == ADDITIVE) vec_copy<T>(latest, phi, all, st);   // src/schwarz_generic.c:1099-1100
   }
-  // the reference walks 8 block lists per cycle (colour 0: lists 0-3, colour 1: lists 4-7) and, when
-  // started without a residual, only switches the residual update on after list 5 of the first
-  // cycle (src/schwarz_generic.c:1344): lists 4 and 5 of cycle 0 are solved against the stale r.
   for (int k = 0; k < cycles; k++) {
-    for (int color = 0; color < 2; color++) {
+    for (int color = 0; color < ncolors; color++) {
       int mode; unsigned skip = 0;
-      if (k == 0 && init_res == RES) mode = MODE_FULLRES;
-      else if (k == 0 && init_res == NO_RES) {
-        if (color == 0) mode = MODE_NONE;
-        else { mode = MODE_NBOUNDARY; skip = (1u << 4) | (1u << 5); }
-      } else mode = MODE_NBOUNDARY;
+      if (schedule_ == RED_BLACK) {
+        // the reference walks 8 block lists per cycle (colour 0: lists 0-3, colour 1: lists 4-7) and, when
+        // started without a residual, only switches the residual update on after list 5 of the first
+        // cycle (src/schwarz_generic.c:1344): lists 4 and 5 of cycle 0 are solved against the stale r.
+        if (k == 0 && init_res == RES) mode = MODE_FULLRES;
+        else if (k == 0 && init_res == NO_RES) {
+          if (color == 0) mode = MODE_NONE;
+          else { mode = MODE_NBOUNDARY; skip = (1u << 4) | (1u << 5); }
+        } else mode = MODE_NBOUNDARY;
+      } else if (schedule_ == TWO_COLOR) {
+        // schwarz_PRECISION :1470-1555: full residual only in the first cycle of a start with an initial guess
+        if (res == NO_RES) mode = MODE_NONE;
+        else mode = (k == 0 && init_res == RES) ? MODE_FULLRES : MODE_NBOUNDARY;
+      } else {
+        // additive_schwarz_PRECISION :1111-1171 and sixteen_color_schwarz_PRECISION :1691-1765: the first cycle takes
+        // the full residual wherever there is an iterate to take it from
+        if (res == NO_RES) mode = MODE_NONE;
+        else mode = k == 0 ? MODE_FULLRES : MODE_NBOUNDARY;
+      }
       launch(color, mode, skip, eta, st);
+      res = RES;
     }
+    if (schedule_ == ADDITIVE) std::swap(latest, latest2_);
   }
   vec_copy<T>(phi, x, all, st);  // relax_fac == 1 (the reference's default, src/init.c)
   if (Dphi != nullptr) {
-    // D phi = eta - r, after bringing the colour-0 residuals up to date (src/schwarz_generic.c:1355-1396)
+    // D phi = eta - r, after bringing the residuals of the blocks that were solved before their neighbours up to date
+    // (red-black: colour 0, src/schwarz_generic.c:1355-1396; additive: every block, :1180-1222); the reference does not
+    // offer this by-product with sixteen colours (ASSERT( D_phi == NULL ), :1656)
+    DDAMG_REQUIRE(schedule_ != SIXTEEN, "the sixteen-colour smoother does not return D*phi");
     launch(0, -1, 0, eta, st);
     vec_minus<T>(Dphi, eta, r, all, st);
   }

@@ -29,7 +29,7 @@ static void ensure_mg(ddamg_hip_ctx* c) {
   }
   DDAMG_REQUIRE(c->have_operator, "no operator set (call ddamg_hip_set_gauge / ddamg_hip_set_operator first)");
   DDAMG_REQUIRE(c->par.num_levels >= 2, "multigrid needs at least two levels");
-  DDAMG_REQUIRE(c->par.method == 2, "multigrid preconditioner needs method == 2 (red-black SAP)");
+  DDAMG_REQUIRE(c->par.method >= 1 && c->par.method <= 3, "multigrid preconditioner needs method 1 (additive), 2 (red-black) or 3 (sixteen-colour SAP)");
   std::vector<const Geometry*> geoms;
   for (auto& lv : c->levels) geoms.push_back(&lv->geom);
   if (c->par.mixed_precision == 0) {
@@ -85,8 +85,8 @@ static void ensure_mp(ddamg_hip_ctx* c) {
   c->mp_inner.op = [c](float* out, const float* in) { c->fop32.apply(out, in, c->stream); };
   if (c->par.method > 0) {
     // arnoldi_step_MP: prec( Z[j], w, V[j], _NO_RES ) -- the smoother hands back w = D Z[j] (src/linsolve.c:338-343)
-    c->mp_inner.prec = [c](float* phi, float* Dphi, const float* eta, int res) { c->mg32->vcycle(0, phi, Dphi, eta, res); };
-    c->mp_inner.prec_gives_Dphi = true;
+    c->mp_inner.prec = [c](float* phi, float* Dphi, const float* eta, int res) { c->mg32->vcycle(0, phi, c->par.method <= 2 ? Dphi : nullptr, eta, res); };
+    c->mp_inner.prec_gives_Dphi = c->par.method <= 2;   // g.method >= 1 && g.method <= 2, src/linsolve.c:338
   }
   for (double** p : {&c->mp_x, &c->mp_b, &c->mp_r}) DDAMG_HIP_CHECK(device_alloc(p, sizeof(double) * n));
   if (!c->rw_blas_ready) { c->rw_blas.init(8); c->rw_blas_ready = true; }

@@ -36,7 +36,7 @@ def setup_iterations(g):
     return 4 if volume(g) == 256 else 2     # "d0 setup iter" of the two golden runs (oracle/make_golden.py)
 
 
-def make_ctx(g, mixed_precision=1):
+def make_ctx(g, mixed_precision=1, method=2):
     L = lattice(g)
     p = api.default_params()
     p.num_levels = 2
@@ -48,7 +48,7 @@ def make_ctx(g, mixed_precision=1):
     p.post_smooth_iter[0] = 2; p.block_iter[0] = 4; p.setup_iter[0] = setup_iterations(g)
     p.restart, p.max_restart, p.tol = 50, 20, 1e-10
     p.coarse_iter, p.coarse_restart, p.coarse_tol = 100, 5, 5e-2
-    p.mixed_precision, p.method, p.odd_even = mixed_precision, 2, 1
+    p.mixed_precision, p.method, p.odd_even = mixed_precision, method, 1
     p.m0, p.csw = float(g["meta_f64"][0]), float(g["meta_f64"][1])
     ctx = dd.Context(p)
     ctx.set_operator(g["D"], g["clover"])
