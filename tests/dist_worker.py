@@ -165,7 +165,7 @@ def run_gmres(rank, world, P, mp):
     return err
 
 
-def run_amg(rank, world, P, mp, levels=2, G=None):
+def run_amg(rank, world, P, mp, levels=2, G=None, method=2):
     """two-level FGMRES+AMG on the decomposed 8^4 sample configuration (2^4 blocks and aggregates, Nvec 20):
     (1) the hierarchy of the undivided run is handed over (interpolation vectors) and the Galerkin operator,
     smoother, coarse operator and solve of the decomposed run are compared with it; (2) the decomposed run
@@ -194,7 +194,7 @@ def run_amg(rank, world, P, mp, levels=2, G=None):
         p.num_vect[1] = 24; p.post_smooth_iter[1] = 2; p.block_iter[1] = 4; p.setup_iter[1] = 2
         p.restart, p.max_restart, p.tol = 30, 20, 1e-10
         p.coarse_iter, p.coarse_restart, p.coarse_tol = 30, 10, 5e-2
-        p.mixed_precision, p.method, p.odd_even = mp, 2, 1
+        p.mixed_precision, p.method, p.odd_even = mp, method, 1
         p.m0, p.csw = m0, 1.0
         return p
 
@@ -250,7 +250,7 @@ def run_amg(rank, world, P, mp, levels=2, G=None):
     dist.barrier()
     ctx.close()
     if rank == 0:
-        print(f"amg mp{mp} levels {levels}: undivided {it1} its ({cit1} coarse) relres {rr1:.2e} | same hierarchy {it} ({cit}) {rr:.2e} | own setup {it2} ({cit2}) {rr2:.2e}", flush=True)
+        print(f"amg mp{mp} method {method} levels {levels}: undivided {it1} its ({cit1} coarse) relres {rr1:.2e} | same hierarchy {it} ({cit}) {rr:.2e} | own setup {it2} ({cit2}) {rr2:.2e}", flush=True)
         print("errs", {k: f"{v:.2e}" for k, v in errs.items()}, flush=True)
     tol32 = {"galerkin_D": 2e-5, "galerkin_self": 2e-5, "smoother": 5e-5, "coarse_apply": 2e-5, "solution": 1e-7, "solution_own_setup": 1e-7}
     for k, v in errs.items():
@@ -323,6 +323,7 @@ def main():
     ap.add_argument("--prec", type=int, default=64)
     ap.add_argument("--transport", default="host")
     ap.add_argument("--tol", type=float, default=1e-13)
+    ap.add_argument("--method", type=int, default=2, help="Schwarz schedule of the amg modes: 1 additive, 2 red-black, 3 sixteen colours")
     a = ap.parse_args()
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -333,11 +334,11 @@ def main():
     elif a.mode == "gauge":
         err = run_gauge(rank, world, P)
     elif a.mode == "amg":
-        err = run_amg(rank, world, P, a.prec)
+        err = run_amg(rank, world, P, a.prec, method=a.method)
     elif a.mode == "sample_np2":
         err = run_sample_np2(rank, world, P)
     elif a.mode == "amg3":
-        err = run_amg(rank, world, P, a.prec, levels=3, G=[int(x) for x in a.lattice.split(",")])
+        err = run_amg(rank, world, P, a.prec, levels=3, G=[int(x) for x in a.lattice.split(",")], method=a.method)
     elif a.mode == "gmres":
         err = run_gmres(rank, world, P, a.prec)
     else:

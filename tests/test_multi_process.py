@@ -80,6 +80,22 @@ def test_decomposed_two_level_amg(nproc, grid, mp):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nproc,grid,method,mp", [(2, "2,1,1,1", 1, 1), (2, "1,1,1,2", 1, 2), (2, "1,2,1,1", 3, 1), (4, "2,1,2,1", 3, 1)])
+def test_decomposed_two_level_amg_other_schedules(nproc, grid, method, mp):
+    """additive and sixteen-colour Schwarz on a process grid: the halo of the previous generation of block updates
+    (additive) and of the iterate (first cycle) travel between the colour stages"""
+    launch(nproc, "--mode", "amg", "--grid", grid, "--prec", str(mp), "--method", str(method), "--tol", "1e-6", timeout=600)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc,grid,lattice,method", [(2, "2,1,1,1", "8,8,8,8", 3), (2, "1,1,2,1", "8,8,8,8", 1)])
+def test_decomposed_three_level_amg_other_schedules(nproc, grid, lattice, method):
+    """the same on three levels; with sixteen colours the decomposed coarse level has an odd number of blocks in the
+    split direction and runs the reference's two-colour fall-back there (src/schwarz_generic.c:323-333)"""
+    launch(nproc, "--mode", "amg3", "--grid", grid, "--lattice", lattice, "--prec", "1", "--method", str(method), "--tol", "1e-6", timeout=900)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nproc,grid,lattice", [(2, "2,1,1,1", "16,8,8,8"), (2, "2,1,1,1", "8,8,8,8"), (4, "1,2,2,1", "8,16,16,8")])
 def test_decomposed_three_level_amg(nproc, grid, lattice):
     """K-cycle, coarse-level Schwarz smoother and coarse Galerkin construction on a process grid (random links; the
