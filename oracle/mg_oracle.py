@@ -230,10 +230,14 @@ def coarse_solve(Mc, Lc, n, b, tol, restart, max_restart):
 
 # ---- red-black Schwarz ------------------------------------------------------------------------------
 class Schwarz:
-    def __init__(self, L, B, A, block_iter):
+    SIGMA = [0, 1, 3, 2, 6, 4, 5, 7, 15, 14, 12, 13, 9, 11, 10, 8]   # src/schwarz_generic.c:335
+
+    def __init__(self, L, B, A, block_iter, method=2):
         """A: fine matrix; blocks of extent B; the 8 block lists of the reference (colour x {inner, -boundary only,
-        both boundaries, +boundary only}, src/schwarz_generic.c:383-428)"""
-        self.A = A.tocsr(); self.block_iter = block_iter
+        both boundaries, +boundary only}, src/schwarz_generic.c:383-428).  method: 1 additive, 2 red-black, 3 sixteen
+        colours (src/schwarz_generic.c:318-333; an odd number of blocks in a direction falls back to two colours)"""
+        self.A = A.tocsr(); self.block_iter = block_iter; self.method = method
+        self.sixteen = method == 3 and all((L[mu] // B[mu]) % 2 == 0 for mu in range(4))
         c = coords(L)
         nblk = [L[mu] // B[mu] for mu in range(4)]
         bc = c // np.array(B)
@@ -257,6 +261,11 @@ class Schwarz:
             dofs = lambda s: (12 * s[:, None] + np.arange(12)[None, :]).ravel()
             I = dofs(sites); Ie = dofs(ev); Io = dofs(od)
             Abb_e_e = self.A[Ie][:, Ie]; Aeo = self.A[Ie][:, Io]; Aoe = self.A[Io][:, Ie]; Aoo = self.A[Io][:, Io]
+            corner = 8 * (gb[0] % 2) + 4 * (gb[1] % 2) + 2 * (gb[2] % 2) + (gb[3] % 2)
+            if method == 1:
+                col = 0
+            elif self.sixteen:
+                col = self.SIGMA.index(int(corner))
             self.blocks.append(dict(colour=col, list=lst, I=I, Ie=Ie, Io=Io, Dee=Abb_e_e, Deo=Aeo, Doe=Aoe,
                                     Doo_inv=spla.splu(Aoo.tocsc()), rows=self.A[I]))
 
@@ -284,6 +293,8 @@ class Schwarz:
         r[Ie] = re; r[Io] = 0
 
     def smooth(self, eta, cycles, phi0=None):
+        if self.method != 2:
+            return self._smooth_generic(eta, cycles, phi0)
         x = np.zeros_like(eta) if phi0 is None else phi0.copy()
         r = eta.copy()
         latest = np.zeros_like(eta)
@@ -308,16 +319,43 @@ class Schwarz:
         return x
 
 
+    def _smooth_generic(self, eta, cycles, phi0):
+        """additive_schwarz_PRECISION (src/schwarz_generic.c:1077-1257), sixteen_color_schwarz_PRECISION (:1652-1804)
+        and the two-colour schwarz_PRECISION (:1433-1650) it falls back to"""
+        x = np.zeros_like(eta) if phi0 is None else phi0.copy()
+        r = eta.copy()
+        latest = np.zeros_like(eta) if (phi0 is None or self.method != 1) else phi0.copy()
+        have_res = phi0 is not None
+        ncol = 1 if self.method == 1 else 16 if self.sixteen else 2
+        for k in range(cycles):
+            new = np.zeros_like(eta) if self.method == 1 else latest    # additive: two generations of updates
+            for colour in range(ncol):
+                mine = [blk for blk in self.blocks if blk["colour"] == colour]
+                for blk in mine:
+                    if not have_res:
+                        continue
+                    full = k == 0 if (self.method == 1 or self.sixteen) else (k == 0 and phi0 is not None)
+                    if full:
+                        r[blk["I"]] = eta[blk["I"]] - blk["rows"] @ (latest if self.method == 1 else x)
+                    else:
+                        r[blk["I"]] -= self._outside(blk, latest)
+                for blk in mine:
+                    self._block_solve(blk, x, r, new)
+                have_res = True
+            latest = new
+        return x
+
+
 # ---- V-cycle and solve ------------------------------------------------------------------------------
 class TwoLevel:
     def __init__(self, L, Lc, B, D, clover, interp_vectors, coarse_D, coarse_clover, post_smooth_iter=2, block_iter=4,
-                 coarse_tol=5e-2, coarse_restart=5, coarse_iter=100):
+                 coarse_tol=5e-2, coarse_restart=5, coarse_iter=100, method=2):
         self.L, self.Lc = L, Lc
         self.A = fine_matrix(L, D, clover)
         self.P = interpolation_matrix(L, Lc, interp_vectors)
         self.n = 2 * np.asarray(interp_vectors).shape[0]
         self.Mc = coarse_matrix(Lc, coarse_D, coarse_clover, self.n)
-        self.sap = Schwarz(L, B, self.A, block_iter)
+        self.sap = Schwarz(L, B, self.A, block_iter, method)
         self.post = post_smooth_iter
         # "coarse grid iterations" is the restart length, "coarse grid restarts" the number of cycles (src/init.c:927-931)
         self.ctol, self.crestart, self.cmax = coarse_tol, coarse_iter, coarse_restart

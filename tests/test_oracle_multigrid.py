@@ -77,3 +77,26 @@ def test_solve_iteration_count(hier):
     assert it == int(g["solve_iters"][0])
     assert abs(tl.coarse_its - int(g["solve_iters"][1])) <= 3
     assert relerr(mo.reim(x), np.asarray(g["solve_x"]).reshape(-1, 2)) < 1e-8
+
+
+# ---- the other Schwarz schedules: additive (method 1) and sixteen colours (method 3) ---------------------------
+@pytest.fixture(scope="module", params=[("4x4", 1), ("4x4", 3), ("ragged", 1), ("ragged", 3)], ids=lambda p: f"{p[0]}-method{p[1]}")
+def schedule(request):
+    name, method = request.param
+    g = load_golden(f"ref_{name}.npz"); gm = load_golden(f"ref_{name}_m{method}.npz")
+    L = [int(x) for x in g["meta_int"][:4]]
+    B = [int(x) for x in g["meta_int"][4:8]]
+    return g, gm, mo.Schwarz(L, B, mo.fine_matrix(L, g["D"], g["clover"]), 4, method)
+
+
+@pytest.mark.parametrize("cycles", [1, 2, 3])
+def test_schwarz_schedules_from_zero(schedule, cycles):
+    g, gm, sap = schedule
+    out = sap.smooth(vec(g["smoother_eta"]), cycles)
+    assert relerr(mo.reim(out), np.asarray(gm[f"smoother_nores_out_c{cycles}"]).reshape(-1, 2)) < 5e-5
+
+
+def test_schwarz_schedules_with_initial_guess(schedule):
+    g, gm, sap = schedule
+    out = sap.smooth(vec(g["smoother_eta"]), 2, phi0=vec(g["smoother_phi0"]))
+    assert relerr(mo.reim(out), np.asarray(gm["smoother_res_out_c2"]).reshape(-1, 2)) < 5e-5
