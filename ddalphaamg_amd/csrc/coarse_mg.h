@@ -47,6 +47,8 @@ class CoarseSap {
   unsigned char* d_blk_face_ = nullptr;
 };
 
+// y(x) = x(x) or y(x) += x(x) on the listed sites (AoS, n dof per site)
+template <typename T> void aos_list_copy(T* y, const T* x, const int* site_list, int nsites, int n, bool add, hipStream_t st);
 // chirality mask copy: out = in with the dofs of the other chirality zeroed (AoS, n dof per site)
 template <typename T> void aos_chirality_copy(T* out, const T* in, int V, int n, int chir, hipStream_t st);
 // column `col` of matrix `part` of every coarse site <- the coarse AoS vector `colvec` ([Vc][nc])

@@ -170,6 +170,20 @@ template <typename T> void aos_chirality_copy(T* out, const T* in, int V, int n,
 }
 
 template <typename T>
+__global__ void list_copy_kernel(T* __restrict__ y, const T* __restrict__ x, const int* __restrict__ site_list, size_t total, int nreal, int add) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const size_t o = (size_t)site_list[i / nreal] * nreal + i % nreal;
+  y[o] = add ? y[o] + x[o] : x[o];
+}
+template <typename T> void aos_list_copy(T* y, const T* x, const int* site_list, int nsites, int n, bool add, hipStream_t st) {
+  const size_t total = (size_t)nsites * n * 2;
+  if (total == 0) return;
+  hipLaunchKernelGGL(list_copy_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, y, x, site_list, total, 2 * n, add ? 1 : 0);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
 __global__ void store_col_kernel(T* __restrict__ M, const T* __restrict__ colvec, int Vc, int n, int nt, size_t msize, int part, int col) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= Vc * n) return;
@@ -320,6 +334,8 @@ template struct CoarseTransfer<float>;
 template struct CoarseTransfer<double>;
 template class CoarseSap<float>;
 template class CoarseSap<double>;
+template void aos_list_copy<float>(float*, const float*, const int*, int, int, bool, hipStream_t);
+template void aos_list_copy<double>(double*, const double*, const int*, int, int, bool, hipStream_t);
 template void aos_chirality_copy<float>(float*, const float*, int, int, int, hipStream_t);
 template void aos_chirality_copy<double>(double*, const double*, int, int, int, hipStream_t);
 template void store_matrix_column<float>(CoarseOp<float>&, const float*, int, int, hipStream_t);

@@ -73,6 +73,8 @@ class CoarseOp {
                     double sign_self, double sign_hop, bool accumulate, hipStream_t st) const;
   // out[s0,s1) = M0 in   or   M0^-1 in
   void self_mul(T* out, const T* in, int s0, int s1, bool inverse, hipStream_t st) const;
+  // the same on listed sites (global odd-even on a level whose sites are ordered by Schwarz block)
+  void self_mul_list(T* out, const T* in, const int* site_list, int nsites, bool inverse, hipStream_t st) const;
 
  private:
   T* M_ = nullptr;

@@ -195,6 +195,11 @@ template <typename T> void CoarseOp<T>::self_mul(T* out, const T* in, int s0, in
   launch_site<T>(dev(), out, in, s0, s1, inverse ? MODE_SELFINV : MODE_SELF, 1.0, 0.0, false, st);
 }
 
+template <typename T> void CoarseOp<T>::self_mul_list(T* out, const T* in, const int* site_list, int nsites, bool inverse, hipStream_t st) const {
+  DDAMG_REQUIRE(out != in, "coarse self coupling cannot run in place");
+  launch_site<T>(dev(), out, in, 0, nsites, inverse ? MODE_SELFINV : MODE_SELF, 1.0, 0.0, false, st, site_list);
+}
+
 // masked / listed variants (Schwarz blocks and aggregates on coarse levels):
 //   out(x) = [accumulate ? out(x) : 0] + sign_self * M0 in(x) + sign_hop * sum_{d in mask(x)} hop_d(in)   for x in list
 template <typename T> void CoarseOp<T>::apply_masked(T* out, const T* in, const int* site_list, int nsites, const unsigned char* dir_mask,

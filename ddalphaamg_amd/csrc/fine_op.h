@@ -53,6 +53,13 @@ class FineOp {
   void halo_begin(const T* v, hipStream_t st) const;
   void halo_finish(hipStream_t st) const;
   bool distributed() const { return halo_.active(); }
+  // global odd-even pieces (GMRES smoother, src/oddeven_generic.c:584-760).  Vectors keep their full length; the sites
+  // of the other parity hold zeros, so that eta = D phi gives  D_ee phi_e  on the even and the hopping term H_oe phi_e on
+  // the odd sites of an even-only phi (and the other way round).
+  //   oo_inv: out = D_oo^-1 in on the odd sites, 0 on the even ones (diag_oo_inv_PRECISION :547-582)
+  //   parity_select: out = a - b (b may be null) on the sites of parity `keep` (0 even, 1 odd), 0 elsewhere
+  void oo_inv(T* out, const T* in, hipStream_t st) const;
+  void parity_select(T* out, const T* a, const T* b, int keep, hipStream_t st) const;
 
  private:
   T* D_ = nullptr;
@@ -60,6 +67,7 @@ class FineOp {
   T* clover_inv_ = nullptr;
   int* nb_ = nullptr;
   int* lex_ = nullptr;      // lexicographic index of every device site (for the layout kernel)
+  unsigned char* parity_ = nullptr;   // [V] global parity of every site
   int* tile_nb_ = nullptr;
   unsigned short* tnb_ = nullptr;
   int V_ = 0;

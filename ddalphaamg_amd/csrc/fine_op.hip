@@ -282,6 +282,7 @@ FineOp<T>::~FineOp() {
   if (tile_nb_) (void)hipFree(tile_nb_);
   if (tnb_) (void)hipFree(tnb_);
   if (lex_) (void)hipFree(lex_);
+  if (parity_) (void)hipFree(parity_);
 }
 
 // ---- operator data: reference storage (lexicographic fp64) -> device layouts, on the device -----------------------
@@ -379,6 +380,10 @@ void FineOp<T>::upload(const Geometry& g, const double* D_ref, const double* clo
     DDAMG_HIP_CHECK(device_alloc(&nb_, sizeof(int) * 8 * V));
     DDAMG_HIP_CHECK(device_alloc(&lex_, sizeof(int) * V));
     DDAMG_HIP_CHECK(hipMemcpyAsync(lex_, g.lex_of_site.data(), sizeof(int) * V, hipMemcpyHostToDevice, st));
+    std::vector<unsigned char> par(V);
+    for (size_t i = 0; i < V; i++) par[i] = (unsigned char)g.parity[i];
+    DDAMG_HIP_CHECK(device_alloc(&parity_, V));
+    DDAMG_HIP_CHECK(hipMemcpy(parity_, par.data(), V, hipMemcpyHostToDevice));
   }
   double *dD = nullptr, *dC = nullptr;   // staging of the lexicographic fp64 arrays
   DDAMG_HIP_CHECK(device_alloc(&dD, sizeof(double) * 72 * V));
@@ -398,6 +403,57 @@ void FineOp<T>::upload(const Geometry& g, const double* D_ref, const double* clo
   DDAMG_HIP_CHECK(hipFree(dD));
   DDAMG_HIP_CHECK(hipFree(dC));
   if (g.distributed() && !halo_.active()) halo_.init(g);
+}
+
+// ---- global odd-even pieces ------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void oo_inv_kernel(T* __restrict__ out, const T* __restrict__ in, const T* __restrict__ clover_inv,
+                                                     const unsigned char* __restrict__ parity, int V) {
+  const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= (size_t)V) return;
+  T e[24];
+  if (parity[s]) {
+    T p[24], cl[36];
+    load_site<T, 24>(in, V, s, p);
+    load_site<T, 36>(clover_inv, V, s, cl);
+    herm6_mul<T>(cl, p, e);
+    load_site<T, 36>(clover_inv + (size_t)36 * V, V, s, cl);
+    herm6_mul<T>(cl, p + 12, e + 12);
+  } else {
+#pragma unroll
+    for (int k = 0; k < 24; k++) e[k] = 0;
+  }
+  store_site<T, 24>(out, V, s, e);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void parity_select_kernel(T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b,
+                                                            const unsigned char* __restrict__ parity, int keep, int V) {
+  const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= (size_t)V) return;
+  T e[24];
+  if (parity[s] == keep) {
+    load_site<T, 24>(a, V, s, e);
+    if (b) {
+      T f[24];
+      load_site<T, 24>(b, V, s, f);
+#pragma unroll
+      for (int k = 0; k < 24; k++) e[k] -= f[k];
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < 24; k++) e[k] = 0;
+  }
+  store_site<T, 24>(out, V, s, e);
+}
+template <typename T>
+void FineOp<T>::oo_inv(T* out, const T* in, hipStream_t st) const {
+  hipLaunchKernelGGL(oo_inv_kernel<T>, dim3((unsigned)((V_ + 255) / 256)), dim3(256), 0, st, out, in, clover_inv_, parity_, (int)V_);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+template <typename T>
+void FineOp<T>::parity_select(T* out, const T* a, const T* b, int keep, hipStream_t st) const {
+  hipLaunchKernelGGL(parity_select_kernel<T>, dim3((unsigned)((V_ + 255) / 256)), dim3(256), 0, st, out, a, b, parity_, keep, (int)V_);
+  DDAMG_HIP_CHECK(hipGetLastError());
 }
 
 // ---- layout converters ---------------------------------------------------------------------

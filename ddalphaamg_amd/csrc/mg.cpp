@@ -33,8 +33,29 @@ Multigrid<T>::Multigrid(const ddamg_hip_params& par, const std::vector<const Geo
     if (d == 0) lv.fop = fop;
     else lv.cop.alloc(g, lv.n);
     if (!lv.coarsest) {
-      if (d == 0) { lv.fsap.setup(g, fop, par.block_iter[0], par.method, st_); lv.fip.alloc(g, *geoms[1], lv.nvec); }
-      else { lv.csap.setup(g, &lv.cop, par.block_iter[d], par.method, st_); lv.cip.alloc(g, *geoms[d + 1], lv.n, lv.nvec); }
+      if (par.method == 4) {
+        // smoother = GMRES on the odd-even Schur complement of this level (schwarz_PRECISION_alloc, src/schwarz_generic.c:78-83:
+        // restart length block_iter, tolerance EPS_PRECISION, no preconditioner; the V-cycle sets the number of restarts)
+        DDAMG_REQUIRE(par.odd_even == 1, "the GMRES smoother is implemented on the odd-even preconditioned operator (odd_even = 1)");
+        for (int i = 0; i < 4; i++) { DDAMG_HIP_CHECK(device_alloc(&lv.sbuf[i], sizeof(T) * lv.nel)); DDAMG_HIP_CHECK(device_zero(lv.sbuf[i], sizeof(T) * lv.nel)); }
+        lv.srw.init(par.block_iter[d] + 8);
+        lv.sgm.alloc(lv.nel, par.block_iter[d], false);
+        lv.sgm.tol = sizeof(T) == 4 ? 1e-6 : 1e-14;
+        lv.sgm.view = whole(lv.nel);
+        lv.sgm.st = st_; lv.sgm.rw = &lv.srw;
+        lv.sgm.op = [this, d](T* out, const T* in) { this->smoother_schur(d, out, in); };
+        if (d > 0) {
+          std::vector<int> ps[2];
+          for (int s = 0; s < g.V; s++) ps[g.parity[s]].push_back(s);
+          for (int q = 0; q < 2; q++) {
+            lv.n_parity_sites[q] = (int)ps[q].size();
+            DDAMG_HIP_CHECK(device_alloc(&lv.d_parity_sites[q], sizeof(int) * ps[q].size()));
+            DDAMG_HIP_CHECK(hipMemcpy(lv.d_parity_sites[q], ps[q].data(), sizeof(int) * ps[q].size(), hipMemcpyHostToDevice));
+          }
+        }
+      }
+      if (d == 0) { if (par.method != 4) lv.fsap.setup(g, fop, par.block_iter[0], par.method, st_); lv.fip.alloc(g, *geoms[1], lv.nvec); }
+      else { if (par.method != 4) lv.csap.setup(g, &lv.cop, par.block_iter[d], par.method, st_); lv.cip.alloc(g, *geoms[d + 1], lv.n, lv.nvec); }
       DDAMG_HIP_CHECK(device_alloc(&lv.d_agg_face, g.V));
       DDAMG_HIP_CHECK(hipMemcpy(lv.d_agg_face, g.agg_face.data(), g.V, hipMemcpyHostToDevice));
       for (int mu = 0; mu < 4; mu++) {
@@ -130,6 +151,11 @@ template <typename T> void Multigrid<T>::apply_op(int l, T* out, const T* in) {
   else lv_[l]->cop.apply(out, in, st_);
 }
 template <typename T> void Multigrid<T>::smoother(int l, T* phi, T* Dphi, const T* eta, int cycles, int res) {
+  if (par_.method == 4) {
+    DDAMG_REQUIRE(Dphi == nullptr, "the GMRES smoother does not return D*phi");   // ASSERT( Dphi == NULL ), src/vcycle_generic.c:82
+    gmres_smoother(l, phi, eta, cycles, res);
+    return;
+  }
   if (l == 0) lv_[0]->fsap.smooth(phi, Dphi, eta, cycles, res, st_);
   else lv_[l]->csap.smooth(phi, Dphi, eta, cycles, res, st_);
 }
@@ -143,6 +169,77 @@ template <typename T> void Multigrid<T>::interpolate(int l, T* phi, const T* phi
 }
 template <typename T> void Multigrid<T>::set_kcycle_tol(double tol) {
   for (auto& p : lv_) if (p->depth > 0 && !p->coarsest) p->gm.tol = tol;
+}
+
+// ---- GMRES smoother on the odd-even Schur complement of a smoothing level (method 4) ----------------------------
+// S = D_ee - D_eo D_oo^-1 D_oe on the even sites (apply_schur_complement_PRECISION src/oddeven_generic.c:704-740,
+// coarse_apply_schur_complement_PRECISION src/coarse_oddeven_generic.c).  Vectors keep the level's full length and
+// site order; the Krylov vectors are zero on the odd sites.
+template <typename T>
+void Multigrid<T>::smoother_schur(int l, T* out, const T* in) {
+  MGLevel<T>& lv = *lv_[l];
+  T *t = lv.sbuf[0], *u = lv.sbuf[1];
+  if (l == 0) {
+    const FineOp<T>& D = *lv.fop;
+    D.apply(t, in, st_);                    // even: D_ee in_e        odd: H_oe in_e
+    D.oo_inv(u, t, st_);                    // odd: D_oo^-1 H_oe in_e  even: 0
+    D.apply(lv.sbuf[3], u, st_);            // even: H_eo D_oo^-1 H_oe in_e
+    D.parity_select(out, t, lv.sbuf[3], 0, st_);
+  } else {
+    const int *Le = lv.d_parity_sites[0], *Lo = lv.d_parity_sites[1];
+    const int ne = lv.n_parity_sites[0], no = lv.n_parity_sites[1];
+    lv.cop.self_mul_list(out, in, Le, ne, false, st_);                               // out_e = D_ee in_e
+    lv.cop.apply_masked(t, in, Lo, no, nullptr, false, 0.0, -1.0, false, st_);       // t_o = D_oe in_e
+    lv.cop.self_mul_list(u, t, Lo, no, true, st_);                                   // u_o = D_oo^-1 t_o
+    lv.cop.apply_masked(out, u, Le, ne, nullptr, false, 0.0, +1.0, true, st_);       // out_e -= D_eo u_o
+  }
+}
+
+// smoother_PRECISION, g.method == 4 with odd-even (src/vcycle_generic.c:48-71) around solve_oddeven_PRECISION
+// (src/oddeven_generic.c:740-777) / coarse_solve_odd_even_PRECISION: the system for the correction is reduced to the even
+// sites, GMRES(block_iter) runs `cycles` restarts on it from a zero start, the odd sites follow by back substitution.
+template <typename T>
+void Multigrid<T>::gmres_smoother(int l, T* phi, const T* eta, int cycles, int res) {
+  MGLevel<T>& lv = *lv_[l];
+  const View all = whole(lv.nel);
+  Gmres<T>& gm = lv.sgm;
+  T *t = lv.sbuf[0], *u = lv.sbuf[1], *rhs = lv.sbuf[2];
+  // right-hand side: eta, or the residual eta - D phi when phi carries an iterate
+  const T* b = eta;
+  if (res == RES) {
+    apply_op(l, t, phi);
+    vec_minus<T>(rhs, eta, t, all, st_);
+    b = rhs;
+  }
+  if (l == 0) {
+    const FineOp<T>& D = *lv.fop;
+    D.oo_inv(u, b, st_);                          // u_o = D_oo^-1 b_o
+    D.apply(t, u, st_);                           // t_e = H_eo D_oo^-1 b_o
+    D.parity_select(gm.b, b, t, 0, st_);          // b_e - D_eo D_oo^-1 b_o
+    gm.num_restart = cycles; gm.initial_guess_zero = true;
+    gm.solve();                                   // S x_e = b_e
+    D.apply(t, gm.x, st_);                        // t_o = H_oe x_e
+    D.parity_select(u, b, t, 1, st_);             // b_o - D_oe x_e on the odd sites
+    D.oo_inv(t, u, st_);                          // x_o
+    if (res == NO_RES) vec_plus<T>(phi, gm.x, t, all, st_);
+    else { vec_plus<T>(u, gm.x, t, all, st_); vec_plus<T>(phi, phi, u, all, st_); }
+  } else {
+    const int *Le = lv.d_parity_sites[0], *Lo = lv.d_parity_sites[1];
+    const int ne = lv.n_parity_sites[0], no = lv.n_parity_sites[1];
+    T* x = u;                                                                        // assembled correction
+    lv.cop.self_mul_list(x, b, Lo, no, true, st_);                                   // x_o = D_oo^-1 b_o
+    vec_zero<T>(gm.b, all, st_);
+    lv.cop.apply_masked(gm.b, x, Le, ne, nullptr, false, 0.0, +1.0, false, st_);     // -D_eo x_o on the even sites
+    aos_list_copy<T>(gm.b, b, Le, ne, lv.n, true, st_);                                     // + b_e
+    gm.num_restart = cycles; gm.initial_guess_zero = true;
+    gm.solve();
+    vec_copy<T>(t, b, all, st_);
+    lv.cop.apply_masked(t, gm.x, Lo, no, nullptr, false, 0.0, +1.0, true, st_);      // t_o = b_o - D_oe x_e
+    lv.cop.self_mul_list(x, t, Lo, no, true, st_);                                   // x_o = D_oo^-1 t_o
+    aos_list_copy<T>(x, gm.x, Le, ne, lv.n, false, st_);                                    // x_e
+    if (res == NO_RES) vec_copy<T>(phi, x, all, st_);
+    else vec_plus<T>(phi, phi, x, all, st_);
+  }
 }
 
 // ---- coarsest level: odd-even Schur complement solve ----------------------------------------------
@@ -256,9 +353,9 @@ void Multigrid<T>::define_interpolation(int l) {
     double t0 = tick(nullptr, 0);
     random_vector(l, tv);
     t0 = tick("random test vectors", t0);
-    // three smoother passes with 1, 2, 3 cycles (src/setup_generic.c:215-231)
+    // three smoother passes with 1, 2, 3 cycles -- one cycle each with the GMRES smoother (src/setup_generic.c:215-231)
     for (int c = 1; c <= 3; c++) {
-      smoother(l, lv.buf[2], nullptr, tv, c, NO_RES);
+      smoother(l, lv.buf[2], nullptr, tv, par_.method >= 4 ? 1 : c, NO_RES);
       vec_copy<T>(tv, lv.buf[2], all, st_);
     }
     tick("initial smoothing", t0);
@@ -317,7 +414,7 @@ void Multigrid<T>::build_coarse_operator(int l) {
       // all 2*Nvec columns at once on the matrix cores (coarse_batch.hip)
       if (!gal_cwork_) DDAMG_HIP_CHECK(device_alloc(&gal_cwork_, sizeof(T) * coarse_galerkin_batch_work(lv_[1]->g->V, lv_[1]->n)));
       coarse_galerkin_batched(nx.cop, lv.cop, lv.cip, lv.d_agg_face, gal_cwork_, st_);
-      if (nx.coarsest) nx.cop.compute_self_inverse(st_);
+      if (nx.coarsest || par_.method == 4) nx.cop.compute_self_inverse(st_);   // D_oo^-1 of the Schur complements
       DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
       tick("Galerkin coarse operator", t_start);
       return;
@@ -340,7 +437,7 @@ void Multigrid<T>::build_coarse_operator(int l) {
         }
       }
   }
-  if (nx.coarsest) nx.cop.compute_self_inverse(st_);
+  if (nx.coarsest || par_.method == 4) nx.cop.compute_self_inverse(st_);
   DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
   tick("Galerkin coarse operator", t_start);
 }

@@ -41,6 +41,12 @@ struct MGLevel {
   Gmres<T> gm;
   ReduceWork rw;
   T* buf[4] = {nullptr, nullptr, nullptr, nullptr};
+  // GMRES smoother (method 4): GMRES(block_iter) restarted post_smooth_iter times on the global odd-even Schur complement
+  Gmres<T> sgm;
+  ReduceWork srw;
+  T* sbuf[4] = {nullptr, nullptr, nullptr, nullptr};
+  int* d_parity_sites[2] = {nullptr, nullptr};   // depth > 0: even / odd sites of this level
+  int n_parity_sites[2] = {0, 0};
   // setup helpers
   unsigned char* d_agg_face = nullptr;
   unsigned char* d_dir_mask[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -62,7 +68,7 @@ class Multigrid {
   void operator_changed();              // fine operator re-uploaded: rebuild the coarse operators
   void set_kcycle_tol(double tol);
   void release_setup_workspace();       // large temporaries of the Galerkin construction (kept across the builds of one setup)
-  void set_comm(Comm* c) { comm_ = c; for (auto& lv : lv_) { lv->rw.comm = c; lv->cop.set_comm(c); } }
+  void set_comm(Comm* c) { comm_ = c; for (auto& lv : lv_) { lv->rw.comm = c; lv->srw.comm = c; lv->cop.set_comm(c); } }
 
   // ---- hot path -----------------------------------------------------------------------------
   void apply_op(int l, T* out, const T* in);
@@ -99,6 +105,8 @@ class Multigrid {
   T* cwork_ = nullptr;    // coarse work space (5 vectors of the largest coarse level)
 
   void schur(T* out, const T* in);
+  void smoother_schur(int l, T* out, const T* in);            // (apply_schur_complement / coarse_apply_schur_complement on level l)
+  void gmres_smoother(int l, T* phi, const T* eta, int cycles, int res);
   double norm_of(int l, const T* v);
   void random_vector(int l, T* dst);
   void define_interpolation(int l);     // interpolation_PRECISION_define(NULL, level l)

@@ -29,7 +29,7 @@ static void ensure_mg(ddamg_hip_ctx* c) {
   }
   DDAMG_REQUIRE(c->have_operator, "no operator set (call ddamg_hip_set_gauge / ddamg_hip_set_operator first)");
   DDAMG_REQUIRE(c->par.num_levels >= 2, "multigrid needs at least two levels");
-  DDAMG_REQUIRE(c->par.method >= 1 && c->par.method <= 3, "multigrid preconditioner needs method 1 (additive), 2 (red-black) or 3 (sixteen-colour SAP)");
+  DDAMG_REQUIRE(c->par.method >= 1 && c->par.method <= 4, "multigrid preconditioner needs method 1 (additive), 2 (red-black), 3 (sixteen-colour SAP) or 4 (GMRES smoother)");
   std::vector<const Geometry*> geoms;
   for (auto& lv : c->levels) geoms.push_back(&lv->geom);
   if (c->par.mixed_precision == 0) {

@@ -86,7 +86,7 @@ CASES = {
                             extra="d1 global lattice: 4 4 4 4\nd1 local lattice: 4 4 4 4\nd1 block lattice: 2 2 2 2\nd1 post smooth iter: 2\nd1 block iter: 4\nd1 test vectors: 28\nd1 setup iter: 2",
                             method=2, mp=1, keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),
     # the other Schwarz schedules behind the same smoother seam: additive (method 1) and sixteen colours
-    # (method 3); 4^4 with 2^4 blocks has one block per colour, the ragged lattice two, the 8^4 three-level runs use the
+    # (method 3), and the GMRES smoother on the global odd-even Schur complement (method 4); 4^4 with 2^4 blocks has one block per colour, the ragged lattice two, the 8^4 three-level runs use the
     # schedules on the coarse level as well (4^4 coarse lattice, 2^4 blocks)
     "4x4_m1": dict(conf="conf/4x4x4x4b6.0000id3n1", levels=2, L="4 4 4 4", B="2 2 2 2", nvec=20, setup=4, extra="", method=1, mp=1,
                    keep=["meta_int", "meta_f64", "smoother_nores_out_c1", "smoother_nores_out_c2", "smoother_nores_out_c3", "smoother_res_out_c2", "solve_iters", "solve_norm_res", "ones_solve_iters", "ones_solve_norm_res"]),
@@ -100,6 +100,12 @@ CASES = {
                       extra="d1 global lattice: 2 2 2 2\nd1 local lattice: 2 2 2 2", method=3, mp=1, keep=["meta_int", "meta_f64", "smoother_nores_out_c1", "smoother_nores_out_c2", "smoother_nores_out_c3", "smoother_res_out_c2", "solve_iters", "solve_norm_res", "ones_solve_iters", "ones_solve_norm_res"]),
     "8x8_3lvl_m3": dict(conf="conf/8x8x8x8b6.0000id3n1", levels=3, L="8 8 8 8", B="2 2 2 2", nvec=28, setup=4,
                         extra=CASE_3LVL_EXTRA, method=3, mp=1, keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),
+    "4x4_m4": dict(conf="conf/4x4x4x4b6.0000id3n1", levels=2, L="4 4 4 4", B="2 2 2 2", nvec=20, setup=4, extra="", method=4, mp=1,
+                   keep=["meta_int", "meta_f64", "smoother_nores_out_c1", "smoother_nores_out_c2", "smoother_nores_out_c3", "smoother_res_out_c2", "solve_iters", "solve_norm_res", "ones_solve_iters", "ones_solve_norm_res"]),
+    "ragged_m4": dict(conf="", synthetic=4711, levels=2, L="8 4 4 8", B="4 2 2 2", nvec=12, setup=2, m0=0.3,
+                      extra="d1 global lattice: 2 2 2 2\nd1 local lattice: 2 2 2 2", method=4, mp=1, keep=["meta_int", "meta_f64", "smoother_nores_out_c1", "smoother_nores_out_c2", "smoother_nores_out_c3", "smoother_res_out_c2", "solve_iters", "solve_norm_res", "ones_solve_iters", "ones_solve_norm_res"]),
+    "8x8_3lvl_m4": dict(conf="conf/8x8x8x8b6.0000id3n1", levels=3, L="8 8 8 8", B="2 2 2 2", nvec=28, setup=4,
+                        extra=CASE_3LVL_EXTRA, method=4, mp=1, keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),
     "8x8_gmres_mp2": dict(conf="conf/8x8x8x8b6.0000id3n1", levels=1, L="8 8 8 8", B="2 2 2 2", nvec=4, setup=0, extra="", method=0, mp=2,
                           keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),
 }

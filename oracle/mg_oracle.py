@@ -346,6 +346,31 @@ class Schwarz:
         return x
 
 
+class GmresSmoother:
+    """smoother_PRECISION with g.method == 4 and odd-even (src/vcycle_generic.c:48-71): solve_oddeven_PRECISION
+    (src/oddeven_generic.c:740-777) -- GMRES(block_iter), `cycles` restarts, tolerance EPS_float, on the Schur complement
+    D_ee - D_eo D_oo^-1 D_oe of the global odd-even splitting, from a zero start on the residual."""
+
+    def __init__(self, L, A, block_iter):
+        self.A = A.tocsr(); self.block_iter = block_iter
+        par = coords(L).sum(axis=1) % 2
+        dofs = lambda s: (12 * s[:, None] + np.arange(12)[None, :]).ravel()
+        self.Ie = dofs(np.nonzero(par == 0)[0]); self.Io = dofs(np.nonzero(par == 1)[0])
+        self.Dee = self.A[self.Ie][:, self.Ie]; self.Deo = self.A[self.Ie][:, self.Io]; self.Doe = self.A[self.Io][:, self.Ie]
+        self.Doo_inv = spla.splu(self.A[self.Io][:, self.Io].tocsc())
+
+    def smooth(self, eta, cycles, phi0=None):
+        b = eta if phi0 is None else eta - self.A @ phi0
+        bo = b[self.Io]
+        be = b[self.Ie] - self.Deo @ self.Doo_inv.solve(bo)
+        S = lambda v: self.Dee @ v - self.Deo @ self.Doo_inv.solve(self.Doe @ v)
+        xe, _, _ = fgmres(S, be, 1e-6, self.block_iter, cycles)
+        x = np.zeros_like(eta)
+        x[self.Ie] = xe
+        x[self.Io] = self.Doo_inv.solve(bo - self.Doe @ xe)
+        return x if phi0 is None else phi0 + x
+
+
 # ---- V-cycle and solve ------------------------------------------------------------------------------
 class TwoLevel:
     def __init__(self, L, Lc, B, D, clover, interp_vectors, coarse_D, coarse_clover, post_smooth_iter=2, block_iter=4,
@@ -355,7 +380,7 @@ class TwoLevel:
         self.P = interpolation_matrix(L, Lc, interp_vectors)
         self.n = 2 * np.asarray(interp_vectors).shape[0]
         self.Mc = coarse_matrix(Lc, coarse_D, coarse_clover, self.n)
-        self.sap = Schwarz(L, B, self.A, block_iter, method)
+        self.sap = Schwarz(L, B, self.A, block_iter, method) if method != 4 else GmresSmoother(L, self.A, block_iter)
         self.post = post_smooth_iter
         # "coarse grid iterations" is the restart length, "coarse grid restarts" the number of cycles (src/init.c:927-931)
         self.ctol, self.crestart, self.cmax = coarse_tol, coarse_iter, coarse_restart

@@ -93,7 +93,7 @@ static void from_lex_f(vector_float v, uint64_t seed, int *ord, int nsites, int 
 /* ---- stage 2: two-level hierarchy and every hot-path function on it ---------------------- */
 static void dump_two_level(level_struct *l, struct Thread *threading)
 {
-  if (!(g.method >= 1 && g.method <= 3 && g.mixed_precision == 1 && g.num_levels == 2 && l->next_level)) return;
+  if (!(g.method >= 1 && g.method <= 4 && g.mixed_precision == 1 && g.num_levels == 2 && l->next_level)) return;
   char sh[100];
   level_struct *lc = l->next_level;
   const int n0 = l->num_inner_lattice_sites, nc = lc->num_inner_lattice_sites;

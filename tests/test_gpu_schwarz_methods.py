@@ -1,8 +1,9 @@
-"""GPU parity tests (-m gpu) of the other Schwarz schedules behind the smoother seam of the reference
-(smoother_PRECISION, src/vcycle_generic.c:25-39): additive (method 1, additive_schwarz_PRECISION
-src/schwarz_generic.c:1077-1257) and sixteen colours (method 3, sixteen_color_schwarz_PRECISION :1652-1804), on the
-fine level (odd-even block solves) and on an intermediate level (MinRes block solves), against dumps and runs of the
-reference with the same `method:` line (oracle/make_golden.py: 4x4_m*, ragged_m*, 8x8_3lvl_m*)."""
+"""GPU parity tests (-m gpu) of the other smoothers behind the smoother seam of the reference
+(smoother_PRECISION, src/vcycle_generic.c:25-84): additive Schwarz (method 1, additive_schwarz_PRECISION
+src/schwarz_generic.c:1077-1257), sixteen colours (method 3, sixteen_color_schwarz_PRECISION :1652-1804) and GMRES on the
+global odd-even Schur complement (method 4, solve_oddeven_PRECISION src/oddeven_generic.c:740-777), on the fine level
+and on an intermediate level, against dumps and runs of the reference with the same `method:` line
+(oracle/make_golden.py: 4x4_m*, ragged_m*, 8x8_3lvl_m*)."""
 import numpy as np
 import pytest
 from conftest import load_golden, relerr
@@ -13,8 +14,9 @@ from test_gpu_multigrid import make_ctx, lattice, volume, setup_iterations, TOL_
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module", params=[("ref_4x4.npz", "4x4", 1), ("ref_4x4.npz", "4x4", 3), ("ref_ragged.npz", "ragged", 1), ("ref_ragged.npz", "ragged", 3)],
-                ids=["4x4-additive", "4x4-sixteen", "ragged-additive", "ragged-sixteen"])
+@pytest.fixture(scope="module", params=[("ref_4x4.npz", "4x4", 1), ("ref_4x4.npz", "4x4", 3), ("ref_4x4.npz", "4x4", 4),
+                                        ("ref_ragged.npz", "ragged", 1), ("ref_ragged.npz", "ragged", 3), ("ref_ragged.npz", "ragged", 4)],
+                ids=["4x4-additive", "4x4-sixteen", "4x4-gmres", "ragged-additive", "ragged-sixteen", "ragged-gmres"])
 def case(request):
     base, name, method = request.param
     return load_golden(base), load_golden(f"ref_{name}_m{method}.npz"), method
@@ -63,13 +65,14 @@ def test_setup_and_solve_iteration_parity(case):
     assert it == int(gm["ones_solve_iters"][0]) == len(ref_hist)
     assert rr < 1e-10
     hist = c.residual_history()
-    assert len(hist) == len(ref_hist) and np.all(np.abs(hist / ref_hist - 1.0) < 5e-3)
+    # same curve; an entry below 1e-13 (the last one of the easy ragged system with the GMRES smoother: 5e-15) is fp32 noise
+    assert len(hist) == len(ref_hist) and np.all(np.abs(hist / ref_hist - 1.0) < np.where(ref_hist > 1e-13, 5e-3, 0.5))
     assert abs(cit - int(gm["ones_solve_iters"][1])) <= max(8, int(gm["ones_solve_iters"][1]) // 20)
     c.close()
 
 
 @pytest.mark.parametrize("mp", [1, 2])
-@pytest.mark.parametrize("method", [1, 3])
+@pytest.mark.parametrize("method", [1, 3, 4])
 def test_three_level_kcycle_solve(method, mp):
     """the reference's sample.ini hierarchy on conf/8x8x8x8b6.0000id3n1 (3 levels, K-cycle) with the additive / sixteen-colour
     schedule on both smoothing levels.  Mixed precision 2 has no reference run here: it must agree with mixed precision 1

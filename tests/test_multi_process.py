@@ -80,15 +80,16 @@ def test_decomposed_two_level_amg(nproc, grid, mp):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nproc,grid,method,mp", [(2, "2,1,1,1", 1, 1), (2, "1,1,1,2", 1, 2), (2, "1,2,1,1", 3, 1), (4, "2,1,2,1", 3, 1)])
+@pytest.mark.parametrize("nproc,grid,method,mp", [(2, "2,1,1,1", 1, 1), (2, "1,1,1,2", 1, 2), (2, "1,2,1,1", 3, 1), (4, "2,1,2,1", 3, 1), (2, "1,1,2,1", 4, 1), (4, "2,2,1,1", 4, 2)])
 def test_decomposed_two_level_amg_other_schedules(nproc, grid, method, mp):
     """additive and sixteen-colour Schwarz on a process grid: the halo of the previous generation of block updates
-    (additive) and of the iterate (first cycle) travel between the colour stages"""
+    (additive) and of the iterate (first cycle) travel between the colour stages; GMRES smoother (method 4): global
+    reductions and the hopping terms of the odd-even Schur complement across the process boundary"""
     launch(nproc, "--mode", "amg", "--grid", grid, "--prec", str(mp), "--method", str(method), "--tol", "1e-6", timeout=600)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nproc,grid,lattice,method", [(2, "2,1,1,1", "8,8,8,8", 3), (2, "1,1,2,1", "8,8,8,8", 1)])
+@pytest.mark.parametrize("nproc,grid,lattice,method", [(2, "2,1,1,1", "8,8,8,8", 3), (2, "1,1,2,1", "8,8,8,8", 1), (2, "1,2,1,1", "8,8,8,8", 4)])
 def test_decomposed_three_level_amg_other_schedules(nproc, grid, lattice, method):
     """the same on three levels; with sixteen colours the decomposed coarse level has an odd number of blocks in the
     split direction and runs the reference's two-colour fall-back there (src/schwarz_generic.c:323-333)"""

@@ -79,14 +79,15 @@ def test_solve_iteration_count(hier):
     assert relerr(mo.reim(x), np.asarray(g["solve_x"]).reshape(-1, 2)) < 1e-8
 
 
-# ---- the other Schwarz schedules: additive (method 1) and sixteen colours (method 3) ---------------------------
-@pytest.fixture(scope="module", params=[("4x4", 1), ("4x4", 3), ("ragged", 1), ("ragged", 3)], ids=lambda p: f"{p[0]}-method{p[1]}")
+# ---- the other smoothers: additive (method 1), sixteen colours (method 3), GMRES on the odd-even system (method 4) ---------------------------
+@pytest.fixture(scope="module", params=[("4x4", 1), ("4x4", 3), ("4x4", 4), ("ragged", 1), ("ragged", 3), ("ragged", 4)], ids=lambda p: f"{p[0]}-method{p[1]}")
 def schedule(request):
     name, method = request.param
     g = load_golden(f"ref_{name}.npz"); gm = load_golden(f"ref_{name}_m{method}.npz")
     L = [int(x) for x in g["meta_int"][:4]]
     B = [int(x) for x in g["meta_int"][4:8]]
-    return g, gm, mo.Schwarz(L, B, mo.fine_matrix(L, g["D"], g["clover"]), 4, method)
+    A = mo.fine_matrix(L, g["D"], g["clover"])
+    return g, gm, (mo.GmresSmoother(L, A, 4) if method == 4 else mo.Schwarz(L, B, A, 4, method))
 
 
 @pytest.mark.parametrize("cycles", [1, 2, 3])
