@@ -63,6 +63,9 @@ template <typename T> void vec_plus(T* z, const T* x, const T* y, View v, hipStr
 template <typename T> void vec_multi_axpy_dev(T* w, const T* X, size_t xstride, int m, const double* d_coef, double sign, View v, hipStream_t st);
 // d_out[2i..2i+1] = < X+i*xstride , w >  for i<m  (conjugate-linear in the first argument)
 template <typename T> void vec_multi_dot(const T* X, size_t xstride, int m, const T* w, View v, ReduceWork& rw, double* d_out, hipStream_t st);
+// single-allreduce Arnoldi (src/linsolve_generic.c:776-797): d_h holds m+1 inner products <V_i, w>, the last one <w,w>;
+// d_h[2m] <- sqrt( <w,w> - sum_i |h_i|^2 ), or -1 when the difference is negative (the reference restarts then)
+void arnoldi_norm_from_dots(double* d_h, int m, hipStream_t st);
 // d_out[0] = ||x||_2
 template <typename T> void vec_norm(const T* x, View v, ReduceWork& rw, double* d_out, hipStream_t st);
 // fused pair used by MinRes-type updates:  d_out[0..1] = <x,y>, d_out[2] = <x,x>

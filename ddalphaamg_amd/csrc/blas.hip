@@ -117,6 +117,17 @@ static void launch_ew(T* z, const T* x, const T* y, double ar, double ai, const 
 
 template <typename T> void vec_zero(T* x, View v, hipStream_t st) { launch_ew<T, OP_ZERO>(x, nullptr, nullptr, 0, 0, nullptr, v, st); }
 template <typename T> void vec_copy(T* y, const T* x, View v, hipStream_t st) { launch_ew<T, OP_COPY>(y, x, nullptr, 0, 0, nullptr, v, st); }
+__global__ void arnoldi_norm_kernel(double* __restrict__ h, int m) {
+  double s = h[2 * m];
+  for (int i = 0; i < m; i++) s -= h[2 * i] * h[2 * i] + h[2 * i + 1] * h[2 * i + 1];
+  h[2 * m] = s < 0 ? -1.0 : sqrt(s);
+  h[2 * m + 1] = 0;
+}
+void arnoldi_norm_from_dots(double* d_h, int m, hipStream_t st) {
+  hipLaunchKernelGGL(arnoldi_norm_kernel, dim3(1), dim3(1), 0, st, d_h, m);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
 template <typename T> void vec_axpy(T* z, const T* x, const T* y, double are, double aim, View v, hipStream_t st) { launch_ew<T, OP_AXPY>(z, x, y, are, aim, nullptr, v, st); }
 template <typename T> void vec_scale(T* z, const T* x, double are, double aim, View v, hipStream_t st) { launch_ew<T, OP_SCALE>(z, x, nullptr, are, aim, nullptr, v, st); }
 template <typename T> void vec_scale_inv_dev(T* z, const T* x, const double* d, View v, hipStream_t st) { launch_ew<T, OP_SCALE_INV_DEV>(z, x, nullptr, 0, 0, d, v, st); }

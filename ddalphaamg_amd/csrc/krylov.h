@@ -15,6 +15,7 @@
 #include <functional>
 #include <vector>
 #include <cmath>
+#include <cstdlib>
 
 namespace ddamg {
 
@@ -35,6 +36,9 @@ struct Gmres {
   std::function<void(T*, const T*)> op;                                   // out = A in
   std::function<void(T* phi, T* Dphi, const T* eta, int res)> prec;       // right preconditioner (may be empty)
   bool prec_gives_Dphi = false;  // preconditioner also returns A*phi in Dphi (src/linsolve_generic.c:832-835)
+  // the reference's SINGLE_ALLREDUCE_ARNOLDI build option (src/linsolve_generic.c:735-800): the new vector's norm comes out
+  // of the same reduction as the Gram-Schmidt coefficients, ||w||^2 - sum |h_i|^2 -- one global sum per step instead of two
+  bool single_allreduce = getenv("DDAMG_SINGLE_ALLREDUCE_ARNOLDI") != nullptr;
   // storage (owned)
   T* slab = nullptr;
   T *x = nullptr, *b = nullptr, *r = nullptr, *w = nullptr, *Vb = nullptr, *Zb = nullptr;
@@ -94,7 +98,7 @@ struct Gmres {
       j = -1;
       for (int il = 0; il < restart_length && !finish; il++) {
         j = il; iter++;
-        arnoldi_step(j, right);
+        if (!arnoldi_step(j, right)) { j--; iter--; break; }   // negative ||w||^2 - sum |h|^2: restart from the columns completed so far
         cd* Hj = &H[(size_t)j * (restart_length + 2)];
         if (std::abs(Hj[j + 1]) > (breakdown_tol < 0 ? tol / 10 : breakdown_tol)) {
           qr_update(j);
@@ -124,7 +128,8 @@ struct Gmres {
  private:
   std::vector<cd> H, y, gamma, c, s;  // H column-major: H[j*(m+2) + i] = reference H[j][i]
 
-  void arnoldi_step(int j, bool right) {
+  bool arnoldi_step(int j, bool right) {
+    T* w = single_allreduce ? V(j + 1) : this->w;      // the reference builds w in place in V[j+1] there
     if (right) {
       if (prec_gives_Dphi) {
         prec(Z(j), w, V(j), NO_RES);
@@ -136,6 +141,18 @@ struct Gmres {
       op(w, V(j));
     }
     double* dh = rw->d_result;
+    if (single_allreduce) {
+      vec_multi_dot<T>(Vb, vstride, j + 2, w, view, *rw, dh, st);     // <V_0..V_j, w> and <w, w>
+      arnoldi_norm_from_dots(dh, j + 1, st);
+      vec_multi_axpy_dev<T>(w, Vb, vstride, j + 1, dh, -1.0, view, st);
+      vec_scale_inv_dev<T>(w, w, dh + 2 * (j + 1), view, st);
+      DDAMG_HIP_CHECK(hipMemcpyAsync(rw->h_result, dh, sizeof(double) * (2 * (j + 1) + 1), hipMemcpyDeviceToHost, st));
+      DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+      cd* Hj = &H[(size_t)j * (restart_length + 2)];
+      for (int i = 0; i <= j; i++) Hj[i] = cd(rw->h_result[2 * i], rw->h_result[2 * i + 1]);
+      Hj[j + 1] = rw->h_result[2 * (j + 1)];
+      return rw->h_result[2 * (j + 1)] >= 0;
+    }
     vec_multi_dot<T>(Vb, vstride, j + 1, w, view, *rw, dh, st);
     vec_multi_axpy_dev<T>(w, Vb, vstride, j + 1, dh, -1.0, view, st);
     vec_norm<T>(w, view, *rw, dh + 2 * (j + 1), st);
@@ -145,6 +162,7 @@ struct Gmres {
     cd* Hj = &H[(size_t)j * (restart_length + 2)];
     for (int i = 0; i <= j; i++) Hj[i] = cd(rw->h_result[2 * i], rw->h_result[2 * i + 1]);
     Hj[j + 1] = rw->h_result[2 * (j + 1)];
+    return true;
   }
 
   void qr_update(int j) {
