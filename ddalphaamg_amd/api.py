@@ -60,8 +60,8 @@ def library_path():
 
 
 def declared_symbols():
-    """every function include/ddamg_hip.h declares"""
-    txt = open(_HEADER).read()
+    """every function include/ddamg_hip.h and include/ddamg_hip_io.h declare"""
+    txt = open(_HEADER).read() + open(os.path.join(os.path.dirname(_HEADER), "ddamg_hip_io.h")).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(ddamg_hip_[a-z0-9_]+)\s*\(", txt)))
 
@@ -98,6 +98,7 @@ def load_library():
         "ddamg_hip_setup_update": [vp, ctypes.c_int, ctypes.POINTER(ctypes.c_int)],
         "ddamg_hip_set_test_vectors": [vp, dp, ctypes.c_int],
         "ddamg_hip_get_interpolation": [vp, dp],
+        "ddamg_hip_get_test_vectors": [vp, dp],
         "ddamg_hip_get_coarse_operator": [vp, dp, dp],
         "ddamg_hip_set_coarse_operator": [vp, dp, dp],
         "ddamg_hip_smoother": [vp, vp, vp, ctypes.c_int, ctypes.c_int],
@@ -125,6 +126,83 @@ def load_library():
         fn.restype = ctypes.c_int
     _lib = lib
     return lib
+
+
+class VectorHeader(ctypes.Structure):
+    """mirror of ddamg_hip_vector_header (include/ddamg_hip_io.h)"""
+    _fields_ = [("vector_type", ctypes.c_char_p), ("m0", ctypes.c_double), ("csw", ctypes.c_double), ("clov_plaq", ctypes.c_double),
+                ("hopp_plaq", ctypes.c_double), ("clov_conf_name", ctypes.c_char_p), ("hopp_conf_name", ctypes.c_char_p),
+                ("has_eigenvalues", ctypes.c_int), ("eigenvalues", ctypes.POINTER(ctypes.c_double))]
+
+
+def _io():
+    lib = load_library()
+    if not getattr(lib, "_io_ready", False):
+        ip = ctypes.POINTER(ctypes.c_int); dp = ctypes.POINTER(ctypes.c_double); cs = ctypes.c_char_p
+        lib.ddamg_hip_io_last_error.restype = ctypes.c_char_p
+        lib.ddamg_hip_conf_info.argtypes = [cs, ctypes.c_int, ip, dp]
+        lib.ddamg_hip_read_conf.argtypes = [cs, ip, ip, ip, ctypes.c_int, dp, dp]
+        lib.ddamg_hip_write_conf.argtypes = [cs, ip, ip, ip, ctypes.c_int, dp, ctypes.c_double]
+        lib.ddamg_hip_read_vectors.argtypes = [cs, ip, ip, ip, ctypes.c_int, ctypes.c_int, dp]
+        lib.ddamg_hip_write_vectors.argtypes = [cs, ip, ip, ip, ctypes.c_int, ctypes.c_int, ctypes.POINTER(VectorHeader), dp]
+        lib._io_ready = True
+    return lib
+
+
+def _io_check(rc):
+    if rc != 0:
+        raise DDAMGError(_io().ddamg_hip_io_last_error().decode())
+
+
+def _i4(v):
+    return (ctypes.c_int * 4)(*[int(x) for x in v])
+
+
+def conf_info(path, big_endian=False):
+    """(lattice [T,Z,Y,X], plaquette) stored in a configuration file of the reference's format (src/io.c:489-507)"""
+    L = (ctypes.c_int * 4)(); plaq = ctypes.c_double(0)
+    _io_check(_io().ddamg_hip_conf_info(os.fsencode(path), int(big_endian), L, ctypes.byref(plaq)))
+    return list(L), plaq.value
+
+
+def read_conf(path, global_lattice, process_grid=(1, 1, 1, 1), process_coords=(0, 0, 0, 0), big_endian=False):
+    """this process's part of a configuration file: ([V_local][4][9][2] links, plaquette of the header)"""
+    Vloc = int(np.prod([g // max(p, 1) for g, p in zip(global_lattice, process_grid)]))
+    out = np.zeros((Vloc, 4, 9, 2)); plaq = ctypes.c_double(0)
+    _io_check(_io().ddamg_hip_read_conf(os.fsencode(path), _i4(global_lattice), _i4(process_grid), _i4(process_coords), int(big_endian), _dp(out), ctypes.byref(plaq)))
+    return out, plaq.value
+
+
+def write_conf(path, global_lattice, gauge_local, plaq, process_grid=(1, 1, 1, 1), process_coords=(0, 0, 0, 0), big_endian=False):
+    a = np.ascontiguousarray(gauge_local, dtype=np.float64)
+    _io_check(_io().ddamg_hip_write_conf(os.fsencode(path), _i4(global_lattice), _i4(process_grid), _i4(process_coords), int(big_endian), _dp(a), float(plaq)))
+
+
+def read_vectors(path, global_lattice, n=1, process_grid=(1, 1, 1, 1), process_coords=(0, 0, 0, 0), big_endian=False):
+    """n spinors ([n][V_local][12][2]) from a vector / test-vector file of the reference (src/io.c:704-846, 951-1124)"""
+    Vloc = int(np.prod([g // max(p, 1) for g, p in zip(global_lattice, process_grid)]))
+    out = np.zeros((n, Vloc, 12, 2))
+    _io_check(_io().ddamg_hip_read_vectors(os.fsencode(path), _i4(global_lattice), _i4(process_grid), _i4(process_coords), int(n), int(big_endian), _dp(out)))
+    return out
+
+
+def write_vectors(path, global_lattice, vectors_local, header=None, process_grid=(1, 1, 1, 1), process_coords=(0, 0, 0, 0), big_endian=False):
+    """header: None (bare data, one spinor) or a dict with the fields of write_header (src/io.c:671-702):
+    vector_type, m0, csw, clov_plaq, hopp_plaq, clov_conf_name, hopp_conf_name, eigenvalues"""
+    a = np.ascontiguousarray(vectors_local, dtype=np.float64)
+    Vloc = int(np.prod([g // max(p, 1) for g, p in zip(global_lattice, process_grid)]))
+    if a.size % (Vloc * 24):
+        raise DDAMGError("write_vectors: expected [n][V_local][12] complex numbers")
+    n = a.size // (Vloc * 24)
+    hp = None
+    if header is not None:
+        ev = header.get("eigenvalues")
+        evbuf = np.ascontiguousarray(ev, dtype=np.float64) if ev is not None else None
+        h = VectorHeader(str(header.get("vector_type", "")).encode(), float(header.get("m0", 0)), float(header.get("csw", 0)),
+                         float(header.get("clov_plaq", 0)), float(header.get("hopp_plaq", 0)), str(header.get("clov_conf_name", "")).encode(),
+                         str(header.get("hopp_conf_name", "")).encode(), int(ev is not None), _dp(evbuf) if evbuf is not None else None)
+        hp = ctypes.byref(h)
+    _io_check(_io().ddamg_hip_write_vectors(os.fsencode(path), _i4(global_lattice), _i4(process_grid), _i4(process_coords), n, int(big_endian), hp, _dp(a)))
 
 
 def _check(rc):
@@ -248,6 +326,11 @@ class Context:
     def get_interpolation(self):
         out = np.empty((self.params.num_vect[0], self.volume(0), 12, 2))
         _check(self._lib.ddamg_hip_get_interpolation(self._h, _dp(out)))
+        return out
+
+    def get_test_vectors(self):
+        out = np.zeros((self.params.num_vect[0], self.volume(0), 12, 2))
+        _check(self._lib.ddamg_hip_get_test_vectors(self._h, _dp(out)))
         return out
 
     def get_coarse_operator(self):

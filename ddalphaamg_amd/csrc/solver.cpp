@@ -190,6 +190,22 @@ int ddamg_hip_get_interpolation(ddamg_hip_ctx* c, double* P_lex) {
   DDAMG_API_END
 }
 
+int ddamg_hip_get_test_vectors(ddamg_hip_ctx* c, double* tv_lex) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && c->setup_done && tv_lex, "setup has not been run");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  const size_t V = c->levels[0]->geom.V, nel = 24 * V;
+  const int nvec = c->par.num_vect[0];
+  double* st = c->stage(sizeof(double) * nel);
+  for (int k = 0; k < nvec; k++) {
+    if (c->mg32) vec_to_lex<float>(st, c->mg32->level(0).fip.test_vector(k), c->levels[0]->d_lex_of_site, (int)V, 12, c->stream);
+    else vec_to_lex<double>(st, c->mg64->level(0).fip.test_vector(k), c->levels[0]->d_lex_of_site, (int)V, 12, c->stream);
+    DDAMG_HIP_CHECK(hipMemcpyAsync(tv_lex + (size_t)k * nel, st, sizeof(double) * nel, hipMemcpyDeviceToHost, c->stream));
+    DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
+  }
+  DDAMG_API_END
+}
+
 int ddamg_hip_get_coarse_operator(ddamg_hip_ctx* c, double* D_lex, double* clover_lex) {
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c && c->setup_done, "setup has not been run");

@@ -115,6 +115,9 @@ int ddamg_hip_setup_update(ddamg_hip_ctx* ctx, int iterations, int* coarse_itera
  * the aggregate-orthonormal interpolation vectors and are used as they are. */
 int ddamg_hip_set_test_vectors(ddamg_hip_ctx* ctx, const double* tv_lex, int orthonormalised);
 int ddamg_hip_get_interpolation(ddamg_hip_ctx* ctx, double* P_lex);
+/* the level-0 test vectors themselves, same shape (what the reference writes for setup persistence: vector_io_single_file
+ * "test vectors", src/io.c:951-1124; see ddamg_hip_io.h) */
+int ddamg_hip_get_test_vectors(ddamg_hip_ctx* ctx, double* tv_lex);
 /* coarse operator in the reference's storage, lexicographic coarse sites: D [Vc][4][n*n] complex as blocks
  * A,C,B,D column-major, clover [Vc][n(n+1)/2] complex packed (src/coarse_operator_generic.h:124-143,
  * src/coarse_operator_generic.c:109-111) */

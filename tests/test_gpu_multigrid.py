@@ -446,3 +446,25 @@ def test_single_allreduce_arnoldi(gold4, monkeypatch):
     from oracle import orc
     assert relerr(orc.dirac_apply(lattice(gold4), gold4["D"], gold4["clover"], x, 64), b) < 1e-9
     ctx.close()
+
+
+def test_setup_persistence_through_a_test_vector_file(gold4, tmp_path):
+    """the reference keeps a setup by writing the test vectors (vector_io_single_file "test vectors", src/io.c:951-1124) and
+    reading them back into a fresh method (src/setup_generic.c:131-160): the file written from one context rebuilds the same
+    hierarchy in another -- same iteration count, same residual curve, same solution"""
+    L = lattice(gold4)
+    ctx = make_ctx(gold4)
+    ctx.setup(setup_iterations(gold4))
+    b = np.zeros((volume(gold4), 12, 2)); b[..., 0] = 1.0
+    x1, it1, cit1, rr1 = ctx.solve(b, 1e-10)
+    h1 = ctx.residual_history()
+    path = tmp_path / "test_vectors"
+    api.write_vectors(path, L, ctx.get_test_vectors(), dict(vector_type="test vectors", m0=float(gold4["meta_f64"][0]), csw=float(gold4["meta_f64"][1])))
+    ctx.close()
+    ctx = make_ctx(gold4)
+    ctx.set_test_vectors(api.read_vectors(path, L, int(gold4["meta_int"][9])))
+    x2, it2, cit2, rr2 = ctx.solve(b, 1e-10)
+    assert (it2, cit2) == (it1, cit1)
+    assert np.allclose(ctx.residual_history(), h1, rtol=1e-6)
+    assert relerr(x2, x1) < 1e-9
+    ctx.close()
