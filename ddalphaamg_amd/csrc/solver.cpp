@@ -43,7 +43,8 @@ static void ensure_outer(ddamg_hip_ctx* c) {
   if (c->outer_ready) return;
   const size_t n = (size_t)24 * c->levels[0]->geom.V;
   c->rw_outer.init(c->par.restart + 4);
-  c->outer.alloc(n, c->par.restart, c->par.method > 0);
+  // pure CGN keeps its 8 vectors in a 4-vector Krylov structure, as the reference does (src/init.c:178-180)
+  c->outer.alloc(n, c->par.method == -1 ? 4 : c->par.restart, c->par.method > 0);
   c->outer.num_restart = c->par.max_restart;
   c->outer.view = whole(n);
   c->outer.st = c->stream;
@@ -66,6 +67,83 @@ static void ensure_outer(ddamg_hip_ctx* c) {
     }
   }
   c->outer_ready = true;
+}
+
+// cgn_double (src/linsolve_generic.c:503-640; method -1, src/top_level.c:82-83): conjugate gradients on the normal
+// equations D^H D x = D^H b with D^H = g5 D g5 (apply_operator_dagger_PRECISION, src/linalg_generic.c / dirac_generic.c);
+// once the normal-equation residual has dropped by tol the loop goes on on the true residual of D x = b (CGNR phase).
+// At most restart*max_restart iterations (src/init.c:179).
+static int solve_cgn(ddamg_hip_ctx* c, double tol, double* relres) {
+  typedef std::complex<double> cd;
+  Gmres<double>& g = c->outer;
+  const size_t n = g.vec_elems;
+  const View all = whole(n), upper = View{1, 0, 0, n / 2}, lower = View{1, 0, n / 2, n / 2};
+  ReduceWork& rw = c->rw_outer;
+  hipStream_t st = c->stream;
+  double *x = g.x, *b = g.b, *r_true = g.r, *p = g.w, *pp = g.V(0), *Dp = g.V(1), *r_old = g.V(2), *r_new = g.V(3), *tmp = g.V(4);
+  // g5: the spin components 0,1 (the first half of the component-major vector) change sign (g5_PRECISION, src/oddeven_generic.c:780-800)
+  auto g5 = [&](double* out, const double* in) {
+    vec_scale<double>(out, in, -1.0, 0.0, upper, st);
+    if (out != in) vec_copy<double>(out, in, lower, st);
+  };
+  auto D = [&](double* out, const double* in) { c->fop64.apply(out, in, st); };
+  auto Ddag = [&](double* out, const double* in) { g5(tmp, in); D(out, tmp); g5(out, out); };
+  auto dot = [&](const double* a, const double* v) {   // <a, v>, conjugate-linear in a
+    vec_multi_dot<double>(a, 0, 1, v, all, rw, rw.d_result, st);
+    DDAMG_HIP_CHECK(hipMemcpyAsync(rw.h_result, rw.d_result, 2 * sizeof(double), hipMemcpyDeviceToHost, st));
+    DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+    return cd(rw.h_result[0], rw.h_result[1]);
+  };
+  auto norm = [&](const double* a) {
+    vec_norm<double>(a, all, rw, rw.d_result, st);
+    DDAMG_HIP_CHECK(hipMemcpyAsync(rw.h_result, rw.d_result, sizeof(double), hipMemcpyDeviceToHost, st));
+    DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+    return rw.h_result[0];
+  };
+  auto axpy = [&](double* z, const double* xx, const double* y, cd a) { vec_axpy<double>(z, xx, y, a.real(), a.imag(), all, st); };
+  const int maxiter = c->par.restart * c->par.max_restart;
+  int iter = 0;
+  vec_zero<double>(x, all, st);
+  D(Dp, x);
+  vec_minus<double>(pp, b, Dp, all, st);
+  Ddag(r_old, pp);
+  vec_copy<double>(p, r_old, all, st);
+  double r0_norm = norm(r_old);
+  cd prod_rr_old = dot(r_old, r_old);
+  c->last_history.clear();
+  if (!(r0_norm > 0)) { *relres = 0; return 0; }
+  auto step = [&](bool true_residual, double* r_norm) {
+    D(pp, p);
+    Ddag(Dp, pp);
+    const cd alpha = prod_rr_old / dot(p, Dp);
+    axpy(x, x, p, alpha);
+    axpy(r_new, r_old, Dp, -alpha);
+    if (true_residual) { axpy(r_true, r_true, pp, -alpha); *r_norm = norm(r_true); }
+    const cd gamma = dot(r_new, r_new);
+    const cd beta = gamma / prod_rr_old;
+    axpy(p, r_new, p, beta);
+    vec_copy<double>(r_old, r_new, all, st);
+    prod_rr_old = gamma;
+  };
+  while (std::sqrt(prod_rr_old.real()) / r0_norm > tol && iter < maxiter) {
+    iter++;
+    step(false, nullptr);
+    c->last_history.push_back(std::sqrt(prod_rr_old.real()) / r0_norm);
+  }
+  r0_norm = norm(b);
+  D(Dp, x);
+  vec_minus<double>(r_true, b, Dp, all, st);
+  double r_norm = norm(r_true);
+  while (r_norm / r0_norm > tol && iter < maxiter) {
+    iter++;
+    step(true, &r_norm);
+    c->last_history.push_back(r_norm / r0_norm);
+  }
+  // reported residual: the true one, recomputed (the reference prints it the same way, :612-615)
+  D(Dp, x);
+  vec_minus<double>(pp, b, Dp, all, st);
+  *relres = norm(pp) / r0_norm;
+  return iter;
 }
 
 // fgmres_MP (src/linsolve.c:153-300): outer loop in fp64 (true residual, solution update), one restart
@@ -311,12 +389,17 @@ int ddamg_hip_vcycle(ddamg_hip_ctx* c, ddamg_hip_vec* phi, const ddamg_hip_vec* 
 template <typename LoadB, typename StoreX>
 static void solve_core(ddamg_hip_ctx* c, double tol, LoadB load_b, StoreX store_x, int* iterations, int* coarse_iterations, double* relres) {
   DDAMG_REQUIRE(c->have_operator, "no operator set");
-  DDAMG_REQUIRE(c->par.method == 0 || c->setup_done, "setup has not been run");
+  DDAMG_REQUIRE(c->par.method <= 0 || c->setup_done, "setup has not been run");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
   int it; double rr = 0;
   if (c->mg32) c->mg32->coarse_iter_count = 0;
   if (c->mg64) c->mg64->coarse_iter_count = 0;
-  if (c->par.mixed_precision == 2) {
+  if (c->par.method == -1) {
+    ensure_outer(c);
+    load_b(c->outer.b);
+    it = solve_cgn(c, tol > 0 ? tol : c->par.tol, &rr);
+    store_x(c->outer.x);
+  } else if (c->par.mixed_precision == 2) {
     ensure_mp(c);
     load_b(c->mp_b);
     it = solve_mp(c, tol > 0 ? tol : c->par.tol, &rr);

@@ -106,6 +106,9 @@ CASES = {
                       extra="d1 global lattice: 2 2 2 2\nd1 local lattice: 2 2 2 2", method=4, mp=1, keep=["meta_int", "meta_f64", "smoother_nores_out_c1", "smoother_nores_out_c2", "smoother_nores_out_c3", "smoother_res_out_c2", "solve_iters", "solve_norm_res", "ones_solve_iters", "ones_solve_norm_res"]),
     "8x8_3lvl_m4": dict(conf="conf/8x8x8x8b6.0000id3n1", levels=3, L="8 8 8 8", B="2 2 2 2", nvec=28, setup=4,
                         extra=CASE_3LVL_EXTRA, method=4, mp=1, keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),
+    # pure CGN (method -1): conjugate gradients on the normal equations, needs D^dagger = g5 D g5
+    "4x4_cgn": dict(conf="conf/4x4x4x4b6.0000id3n1", levels=2, L="4 4 4 4", B="2 2 2 2", nvec=20, setup=0, extra="", method=-1, mp=1,
+                    keep=["meta_int", "meta_f64", "cgn_x"]),
     "8x8_gmres_mp2": dict(conf="conf/8x8x8x8b6.0000id3n1", levels=1, L="8 8 8 8", B="2 2 2 2", nvec=4, setup=0, extra="", method=0, mp=2,
                           keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),
 }
@@ -167,6 +170,10 @@ def run_case(name):
         lines = log.stdout.splitlines()
         hist = [float(l.split(":")[1].split("|")[0]) for l in lines if "approx. rel. res. after" in l]
         arrays["ref_log_residual_history"] = np.array(hist)
+        if "BEGIN_CGN_SOLVE" in lines:
+            seg = lines[lines.index("BEGIN_CGN_SOLVE"):lines.index("END_CGN_SOLVE")]
+            arrays["ref_log_cgn_iterations"] = np.array([int(l.split(":")[1].split("|")[0]) for l in seg if "CGN iterations:" in l])
+            arrays["ref_log_cgn_switch"] = np.array([[float(l.split("iter")[1].split("true")[0]), float(l.split("res:")[1].split("|")[0])] for l in seg if "switching to CGNR" in l])
         if "BEGIN_ONES_SOLVE" in lines:
             seg = lines[lines.index("BEGIN_ONES_SOLVE"):lines.index("END_ONES_SOLVE")]
             arrays["ref_log_ones_history"] = np.array([float(l.split(":")[1].split("|")[0]) for l in seg if "approx. rel. res. after" in l])

@@ -219,6 +219,18 @@ static void dump_two_level(level_struct *l, struct Thread *threading)
 /* ---- stage 3: full solve with rhs = ones on any hierarchy (src/top_level.c:31-104) --------- */
 static void dump_solve_ones(level_struct *l, struct Thread *threading)
 {
+  if (g.method == -1) {
+    /* pure CGN (cgn_double, src/linsolve_generic.c:503-640, called from solve_driver src/top_level.c:82-83); the routine
+       prints its iteration count, the harness keeps the solution */
+    char sh[64];
+    for (int i = 0; i < l->inner_vector_size; i++) g.p.b[i] = 1.0;
+    printf0("BEGIN_CGN_SOLVE\n");
+    cgn_double(&(g.p), l, threading);
+    printf0("END_CGN_SOLVE\n");
+    sprintf(sh, "%d,12,2", l->num_inner_lattice_sites);
+    dump("cgn_x", "f8", g.p.x, sizeof(complex_double) * l->inner_vector_size, sh);   /* fp64 fine vectors are lexicographic */
+    return;
+  }
   if (g.method < 0 || g.mixed_precision == 0) return;
   vector_double rhs = g.mixed_precision == 2 ? g.p_MP.dp.b : g.p.b;
   for (int i = 0; i < l->inner_vector_size; i++) rhs[i] = 1.0;

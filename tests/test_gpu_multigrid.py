@@ -468,3 +468,28 @@ def test_setup_persistence_through_a_test_vector_file(gold4, tmp_path):
     assert np.allclose(ctx.residual_history(), h1, rtol=1e-6)
     assert relerr(x2, x1) < 1e-9
     ctx.close()
+
+
+def test_pure_cgn_method_minus_1():
+    """method -1: conjugate gradients on the normal equations with D^H = g5 D g5 (cgn_double, src/linsolve_generic.c:503-640)
+    on conf/4x4x4x4b6.0000id3n1, rhs = ones, against the reference's run (tests/golden/ref_4x4_cgn.npz): 195 iterations, the
+    switch to the true residual after 191, and its solution."""
+    from conftest import load_golden
+    g = load_golden("ref_4x4.npz"); gc = load_golden("ref_4x4_cgn.npz")
+    p = api.default_params(); p.num_levels = 1
+    for mu in range(4):
+        p.local_lattice[0][mu] = 4; p.block_lattice[0][mu] = 2
+    p.method, p.mixed_precision, p.restart, p.max_restart, p.tol = -1, 1, 50, 20, 1e-10
+    ctx = dd.Context(p)
+    ctx.set_operator(g["D"], g["clover"])
+    b = np.zeros((256, 12, 2)); b[..., 0] = 1.0
+    x, it, cit, rr = ctx.solve(b, 1e-10)
+    ref_it = int(gc["ref_log_cgn_iterations"][0]); switch_it, switch_res = gc["ref_log_cgn_switch"][0]
+    assert abs(it - ref_it) <= 2 and rr < 1e-10            # 200-step recurrences in fp64: a step more or less at the threshold
+    hist = ctx.residual_history()
+    first_true = int(np.argmax(np.diff(hist) > 0)) + 1 if np.any(np.diff(hist) > 0) else len(hist)
+    assert abs(first_true - switch_it) <= 2                  # normal-equation phase ends where the reference's does
+    assert relerr(x, gc["cgn_x"]) < 1e-8
+    from oracle import orc
+    assert relerr(orc.dirac_apply([4, 4, 4, 4], g["D"], g["clover"], x, 64), b) < 2e-10
+    ctx.close()
