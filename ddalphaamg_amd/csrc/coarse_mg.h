@@ -45,6 +45,7 @@ class CoarseSap {
   std::vector<int> nblk_;         // per colour (+ for red-black: colour 1 without the reference's lists 4 and 5)
   std::vector<int*> d_blocks_, d_sites_;
   unsigned char* d_blk_face_ = nullptr;
+  typename CoarseOp<T>::BlockPlan plan_;   // fused block solver (CoarseOp<T>::block_minres)
 };
 
 // y(x) = x(x) or y(x) += x(x) on the listed sites (AoS, n dof per site)

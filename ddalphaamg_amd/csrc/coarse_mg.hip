@@ -235,6 +235,7 @@ template <typename T> CoarseSap<T>::~CoarseSap() {
   for (int* p : d_blocks_) if (p) (void)hipFree(p);
   for (int* p : d_sites_) if (p) (void)hipFree(p);
   if (d_blk_face_) (void)hipFree(d_blk_face_);
+  CoarseOp<T>::free_block_plan(plan_);
 }
 
 template <typename T>
@@ -270,6 +271,7 @@ void CoarseSap<T>::setup(const Geometry& g, const CoarseOp<T>* op, int block_ite
   DDAMG_HIP_CHECK(device_alloc(&d_blk_face_, V_));
   DDAMG_HIP_CHECK(hipMemcpyAsync(d_blk_face_, g.blk_face.data(), V_, hipMemcpyHostToDevice, st));
   DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+  plan_ = CoarseOp<T>::make_block_plan(g);
 }
 
 template <typename T>
@@ -313,12 +315,15 @@ void CoarseSap<T>::smooth(T* phi, T* Dphi, const T* eta, int cycles, int res, hi
       }
       // local_minres on every block of this colour (with one colour all reads of the previous generation of updates are
       // done by now, so the same buffer takes the new one)
-      hipLaunchKernelGGL((block_ew_kernel<T, BOP_ZERO>), dim3(nblk_[li]), dim3(256), 0, st, latest, (const T*)nullptr, (const T*)nullptr, d_blocks_[li], blen);
-      for (int it = 0; it < block_iter_; it++) {
-        op_->apply_masked(tmp, r, d_sites_[li], nblk_[li] * BS_, d_blk_face_, true, 1.0, -1.0, false, st);   // Dr = D_block r
-        hipLaunchKernelGGL(block_minres_kernel<T>, dim3(nblk_[li]), dim3(256), 0, st, latest, r, tmp, d_blocks_[li], blen / 2, eps);
+      if (!op_->block_minres(x, r, latest, d_blocks_[li], nblk_[li], plan_, block_iter_, eps, st)) {
+        // step-by-step form (blocks that do not fit the fused kernel)
+        hipLaunchKernelGGL((block_ew_kernel<T, BOP_ZERO>), dim3(nblk_[li]), dim3(256), 0, st, latest, (const T*)nullptr, (const T*)nullptr, d_blocks_[li], blen);
+        for (int it = 0; it < block_iter_; it++) {
+          op_->apply_masked(tmp, r, d_sites_[li], nblk_[li] * BS_, d_blk_face_, true, 1.0, -1.0, false, st);   // Dr = D_block r
+          hipLaunchKernelGGL(block_minres_kernel<T>, dim3(nblk_[li]), dim3(256), 0, st, latest, r, tmp, d_blocks_[li], blen / 2, eps);
+        }
+        hipLaunchKernelGGL((block_ew_kernel<T, BOP_ADD>), dim3(nblk_[li]), dim3(256), 0, st, x, latest, (const T*)nullptr, d_blocks_[li], blen);
       }
-      hipLaunchKernelGGL((block_ew_kernel<T, BOP_ADD>), dim3(nblk_[li]), dim3(256), 0, st, x, latest, (const T*)nullptr, d_blocks_[li], blen);
       res = RES;
     }
   DDAMG_HIP_CHECK(hipGetLastError());

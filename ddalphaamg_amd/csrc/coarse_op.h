@@ -71,6 +71,16 @@ class CoarseOp {
   // masked / listed form used by the coarse Schwarz smoother and the coarse Galerkin construction
   void apply_masked(T* out, const T* in, const int* site_list, int nsites, const unsigned char* dir_mask, bool mask_invert,
                     double sign_self, double sign_hop, bool accumulate, hipStream_t st) const;
+  // fused block solver of the coarse Schwarz smoother (local_minres_PRECISION src/linsolve_generic.c:985-1029 on
+  // coarse_block_operator src/coarse_operator_generic.c:208-235): for every listed block of `block_sites` consecutive
+  // sites, `iters` MinRes steps  Dr = D_block r; alpha = <Dr,r>/<Dr,Dr>; lphi += alpha r; r -= alpha Dr  from lphi = 0,
+  // then latest = lphi, x += lphi.  One workgroup per block keeps r and lphi in LDS and streams every coupling of the
+  // block ONCE per step (a link serves both of its end points).  plan: see make_block_plan.  Returns false when the
+  // block does not fit the kernel's LDS / register budget (the caller then runs the step-by-step path).
+  struct BlockPlan { int* d_items = nullptr; int* d_contrib = nullptr; int nitems = 0, block_sites = 0; };
+  static BlockPlan make_block_plan(const Geometry& g);
+  static void free_block_plan(BlockPlan& p);
+  bool block_minres(T* x, T* r, T* latest, const int* blocks, int nblocks, const BlockPlan& plan, int iters, double eps, hipStream_t st) const;
   // out[s0,s1) = M0 in   or   M0^-1 in
   void self_mul(T* out, const T* in, int s0, int s1, bool inverse, hipStream_t st) const;
   // the same on listed sites (global odd-even on a level whose sites are ordered by Schwarz block)

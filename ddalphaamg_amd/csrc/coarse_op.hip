@@ -126,6 +126,195 @@ __global__ void coarse_site_kernel(T* __restrict__ out, const T* __restrict__ in
   }
 }
 
+// one wavefront, one link L streamed once: res_fwd = L vj (the term of the link's owner) and res_bwd = G5 L^H G5 vi (the
+// term of its +mu neighbour)
+template <typename T, int NT>
+__device__ __forceinline__ void wave_mv2(const T* __restrict__ Mbase, const T* __restrict__ vj, const T* __restrict__ vi, int n,
+                                         T* __restrict__ res_fwd, T* __restrict__ res_bwd) {
+  using c2 = typename C2<T>::t;
+  const int l = threadIdx.x & 63, a = l >> 3, b = l & 7;
+  const int half = n >> 1;
+  T xr[NT], xi[NT], wr[NT], wi[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const int k = b + 8 * t;
+    if (k < n) { xr[t] = vj[2 * k]; xi[t] = vj[2 * k + 1]; } else { xr[t] = 0; xi[t] = 0; }
+    const int k2 = a + 8 * t;
+    if (k2 < n) {
+      const T sg = k2 >= half ? (T)-1 : (T)1;
+      wr[t] = sg * vi[2 * k2]; wi[t] = sg * vi[2 * k2 + 1];
+    } else { wr[t] = 0; wi[t] = 0; }
+  }
+  T ar[NT], ai[NT], br[NT], bi[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) { ar[t] = 0; ai[t] = 0; br[t] = 0; bi[t] = 0; }
+  const c2* M = reinterpret_cast<const c2*>(Mbase) + l;
+#pragma unroll
+  for (int p = 0; p < NT; p++)
+#pragma unroll
+    for (int q = 0; q < NT; q++) {
+      const c2 m = M[(p * NT + q) * 64];
+      ar[p] += m.x * xr[q] - m.y * xi[q];
+      ai[p] += m.x * xi[q] + m.y * xr[q];
+      br[q] += m.x * wr[p] + m.y * wi[p];
+      bi[q] += m.x * wi[p] - m.y * wr[p];
+    }
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { ar[t] += __shfl_xor(ar[t], o, 64); ai[t] += __shfl_xor(ai[t], o, 64); }
+    if (b == 0) { res_fwd[2 * (a + 8 * t)] = ar[t]; res_fwd[2 * (a + 8 * t) + 1] = ai[t]; }
+#pragma unroll
+    for (int o = 8; o < 64; o <<= 1) { br[t] += __shfl_xor(br[t], o, 64); bi[t] += __shfl_xor(bi[t], o, 64); }
+    if (a == 0) {
+      const int k = b + 8 * t;
+      const T sg = (k >= half) ? (T)-1 : (T)1;
+      res_bwd[2 * k] = sg * br[t]; res_bwd[2 * k + 1] = sg * bi[t];
+    }
+  }
+}
+
+// see CoarseOp<T>::block_minres.  items: [nitems][3] = (block-local site i, direction mu or -1 for the self coupling,
+// block-local +mu neighbour j); contrib: [block_sites][10] = number of products that enter (D_block r)(i), then their slots
+// (the self coupling first, with sign +, the hopping terms with sign -); slot 2*item is the product for the item's own
+// site, slot 2*item+1 the one for the neighbour.
+constexpr int BLOCK_MINRES_THREADS = 512, BLOCK_MINRES_MAXE = 4;
+template <typename T, int NT>
+__global__ __launch_bounds__(BLOCK_MINRES_THREADS) void coarse_block_minres_kernel(T* __restrict__ x, T* __restrict__ r, T* __restrict__ latest, CoarseOpDev<T> op,
+                                                                                   const int* __restrict__ blocks, const int* __restrict__ items, int nitems,
+                                                                                   const int* __restrict__ contrib, int BS, int iters, double eps) {
+  extern __shared__ double smem_d[];
+  constexpr int np = 8 * NT, NTH = BLOCK_MINRES_THREADS;
+  double* red = smem_d;                                   // [3][16]
+  T* rl = reinterpret_cast<T*>(smem_d + 48);              // [BS][2 np]
+  T* lphi = rl + (size_t)BS * 2 * np;                     // [BS][2 np]
+  T* slots = lphi + (size_t)BS * 2 * np;                  // [2 nitems][2 np]
+  const int n = op.n, tid = threadIdx.x, w = tid >> 6, nw = NTH >> 6;
+  const size_t s0 = (size_t)blocks[blockIdx.x] * BS;
+  for (int e = tid; e < BS * 2 * np; e += NTH) {
+    const int i = e / (2 * np), k = e - i * 2 * np;
+    rl[e] = k < 2 * n ? r[(s0 + i) * n * 2 + k] : (T)0;
+    lphi[e] = 0;
+  }
+  __syncthreads();
+  for (int it = 0; it < iters; it++) {
+    for (int item = w; item < nitems; item += nw) {
+      const int i = items[3 * item], mu = items[3 * item + 1], j = items[3 * item + 2];
+      const T* Mx = op.M + (s0 + i) * 5 * op.msize * 2;
+      if (mu < 0) wave_mv<T, NT, false>(Mx, rl + (size_t)i * 2 * np, n, slots + (size_t)(2 * item) * 2 * np);
+      else wave_mv2<T, NT>(Mx + (size_t)(1 + mu) * op.msize * 2, rl + (size_t)j * 2 * np, rl + (size_t)i * 2 * np, n,
+                           slots + (size_t)(2 * item) * 2 * np, slots + (size_t)(2 * item + 1) * 2 * np);
+    }
+    __syncthreads();
+    double s[3] = {0, 0, 0};
+    T dre[BLOCK_MINRES_MAXE], dim[BLOCK_MINRES_MAXE];
+#pragma unroll
+    for (int u = 0; u < BLOCK_MINRES_MAXE; u++) {
+      const int c = tid + u * NTH;
+      dre[u] = 0; dim[u] = 0;
+      if (c < BS * n) {
+        const int i = c / n, k = c - i * n;
+        const int* ct = contrib + i * 10;
+        const int cnt = ct[0];
+        T dr = slots[(size_t)ct[1] * 2 * np + 2 * k], di = slots[(size_t)ct[1] * 2 * np + 2 * k + 1];
+        for (int q = 2; q <= cnt; q++) { dr -= slots[(size_t)ct[q] * 2 * np + 2 * k]; di -= slots[(size_t)ct[q] * 2 * np + 2 * k + 1]; }
+        const double rr = rl[(size_t)i * 2 * np + 2 * k], ri = rl[(size_t)i * 2 * np + 2 * k + 1];
+        s[0] += (double)dr * rr + (double)di * ri; s[1] += (double)dr * ri - (double)di * rr; s[2] += (double)dr * dr + (double)di * di;
+        dre[u] = dr; dim[u] = di;
+      }
+    }
+    // block sum (every thread gets it; the helper synchronises, so the slots may be overwritten afterwards)
+    {
+      const int lane = tid & 63;
+#pragma unroll
+      for (int k = 0; k < 3; k++)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s[k] += __shfl_xor(s[k], o, 64);
+      if (lane == 0) { red[w] = s[0]; red[16 + w] = s[1]; red[32 + w] = s[2]; }
+      __syncthreads();
+      s[0] = 0; s[1] = 0; s[2] = 0;
+      for (int ww = 0; ww < nw; ww++) { s[0] += red[ww]; s[1] += red[16 + ww]; s[2] += red[32 + ww]; }
+    }
+    T ar = 0, ai = 0;
+    if (fabs(s[2]) >= eps) { ar = (T)(s[0] / s[2]); ai = (T)(s[1] / s[2]); }
+#pragma unroll
+    for (int u = 0; u < BLOCK_MINRES_MAXE; u++) {
+      const int c = tid + u * NTH;
+      if (c < BS * n) {
+        const int i = c / n, k = c - i * n;
+        const size_t o = (size_t)i * 2 * np + 2 * k;
+        const T rr = rl[o], ri = rl[o + 1];
+        lphi[o] += ar * rr - ai * ri; lphi[o + 1] += ar * ri + ai * rr;
+        rl[o] = rr - (ar * dre[u] - ai * dim[u]); rl[o + 1] = ri - (ar * dim[u] + ai * dre[u]);
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < BS * 2 * n; e += NTH) {
+    const int i = e / (2 * n), k = e - i * 2 * n;
+    const size_t g = (s0 + i) * n * 2 + k;
+    const T d = lphi[(size_t)i * 2 * np + k];
+    r[g] = rl[(size_t)i * 2 * np + k];
+    latest[g] = d;
+    x[g] += d;
+  }
+}
+
+template <typename T>
+typename CoarseOp<T>::BlockPlan CoarseOp<T>::make_block_plan(const Geometry& g) {
+  BlockPlan p;
+  const int BS = g.block_sites;
+  std::vector<int> items, contrib((size_t)BS * 10, 0);
+  std::vector<std::vector<int>> slots_of(BS);
+  for (int i = 0; i < BS; i++) { slots_of[i].push_back(2 * (int)(items.size() / 3)); items.insert(items.end(), {i, -1, i}); }
+  for (int i = 0; i < BS; i++)
+    for (int mu = 0; mu < 4; mu++) {
+      const int j = g.blk_nb[(size_t)mu * BS + i];
+      if (j < 0) continue;
+      const int item = (int)(items.size() / 3);
+      items.insert(items.end(), {i, mu, j});
+      slots_of[i].push_back(2 * item);        // L r(j) enters (D r)(i)
+      slots_of[j].push_back(2 * item + 1);    // G5 L^H G5 r(i) enters (D r)(j)
+    }
+  for (int i = 0; i < BS; i++) {
+    contrib[(size_t)i * 10] = (int)slots_of[i].size();    // at most 1 + 8
+    for (size_t q = 0; q < slots_of[i].size(); q++) contrib[(size_t)i * 10 + 1 + q] = slots_of[i][q];
+  }
+  p.nitems = (int)(items.size() / 3); p.block_sites = BS;
+  DDAMG_HIP_CHECK(device_alloc(&p.d_items, sizeof(int) * items.size()));
+  DDAMG_HIP_CHECK(hipMemcpy(p.d_items, items.data(), sizeof(int) * items.size(), hipMemcpyHostToDevice));
+  DDAMG_HIP_CHECK(device_alloc(&p.d_contrib, sizeof(int) * contrib.size()));
+  DDAMG_HIP_CHECK(hipMemcpy(p.d_contrib, contrib.data(), sizeof(int) * contrib.size(), hipMemcpyHostToDevice));
+  return p;
+}
+template <typename T>
+void CoarseOp<T>::free_block_plan(BlockPlan& p) {
+  if (p.d_items) (void)hipFree(p.d_items);
+  if (p.d_contrib) (void)hipFree(p.d_contrib);
+  p = BlockPlan();
+}
+
+template <typename T>
+bool CoarseOp<T>::block_minres(T* x, T* r, T* latest, const int* blocks, int nblocks, const BlockPlan& plan, int iters, double eps, hipStream_t st) const {
+  static const bool off = getenv("DDAMG_COARSE_SAP_UNFUSED") != nullptr;
+  const int np = 8 * nt_, BS = plan.block_sites;
+  const size_t lds = 48 * sizeof(double) + sizeof(T) * 2 * np * ((size_t)2 * BS + (size_t)2 * plan.nitems);
+  if (off || plan.nitems == 0 || (size_t)BS * n_ > (size_t)BLOCK_MINRES_THREADS * BLOCK_MINRES_MAXE || lds > 150 * 1024) return false;
+  if (nblocks <= 0) return true;
+  const CoarseOpDev<T> op = dev();
+#define DDAMG_CASE(NTV) case NTV: \
+    DDAMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&coarse_block_minres_kernel<T, NTV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((coarse_block_minres_kernel<T, NTV>), dim3(nblocks), dim3(BLOCK_MINRES_THREADS), lds, st, x, r, latest, op, blocks, plan.d_items, plan.nitems, \
+                       plan.d_contrib, BS, iters, eps); break;
+  switch (nt_) {
+    DDAMG_CASE(1) DDAMG_CASE(2) DDAMG_CASE(3) DDAMG_CASE(4) DDAMG_CASE(5) DDAMG_CASE(6) DDAMG_CASE(7) DDAMG_CASE(8)
+    default: return false;
+  }
+#undef DDAMG_CASE
+  DDAMG_HIP_CHECK(hipGetLastError());
+  return true;
+}
+
 // boundary data for the neighbouring processes: one wavefront per face site
 template <typename T, int NT>
 __global__ void coarse_halo_pack_kernel(T* __restrict__ send, const T* __restrict__ in, CoarseOpDev<T> op, const int* __restrict__ face_sites,
