@@ -89,6 +89,7 @@ class CoarseOp {
  private:
   T* M_ = nullptr;
   T* Minv_ = nullptr;
+  mutable T* bwd_ = nullptr;   // [4][V][n] backward products of apply()'s first phase
   int* nb_ = nullptr;
   int V_ = 0, n_ = 0, nt_ = 0;
   size_t msize_ = 0;

@@ -260,6 +260,55 @@ __global__ __launch_bounds__(BLOCK_MINRES_THREADS) void coarse_block_minres_kern
   }
 }
 
+// ---- full operator with every link read once -------------------------------------------------------------------
+// Phase 1, one workgroup per site x: wavefront 0 the self coupling, wavefronts 1-4 one forward link each -- L in(x+mu) for
+// x itself and G5 L^H G5 in(x), the backward term of x+mu, which goes to bwd[mu][x+mu] (n complex per site and direction).
+// out(x) = M0 in(x) - sum_mu L_mu in(x+mu).  Phase 2: out(x) -= sum_mu bwd[mu][x].  (coarse_site_kernel computes the
+// backward terms from the neighbour's link as well, which costs a second read of every link: 9 instead of 5 matrices
+// per site.)  Across a process boundary the backward products travel in the halo as before.
+template <typename T, int NT>
+__global__ __launch_bounds__(320) void coarse_apply_once_kernel(T* __restrict__ out, T* __restrict__ bwd, const T* __restrict__ in, CoarseOpDev<T> op) {
+  constexpr int np = 8 * NT;
+  __shared__ T res[5 * 2 * np];
+  __shared__ T tmpb[4 * 2 * np];
+  int bid = blockIdx.x;
+  { const int chunk = gridDim.x >> 3; if (bid < chunk * 8) bid = (bid & 7) * chunk + (bid >> 3); }
+  const int x = bid, w = threadIdx.x >> 6, n = op.n;
+  const size_t V = op.V;
+  const T* Mx = op.M + (size_t)x * 5 * op.msize * 2;
+  int y = -1;
+  if (w == 0) {
+    wave_mv<T, NT, false>(Mx, in + (size_t)x * n * 2, n, res);
+  } else {
+    const int mu = w - 1;
+    y = op.nb[(size_t)mu * V + x];
+    const T* vin = y >= 0 ? in + (size_t)y * n * 2 : op.halo + op.hoff[mu] + (size_t)(-1 - y) * n * 2;
+    wave_mv2<T, NT>(Mx + (size_t)(1 + mu) * op.msize * 2, vin, in + (size_t)x * n * 2, n, res + (size_t)w * 2 * np, tmpb + (size_t)mu * 2 * np);
+  }
+  __syncthreads();
+  if (w > 0 && y >= 0) {
+    const int mu = w - 1;
+    T* dst = bwd + ((size_t)mu * V + y) * n * 2;
+    for (int k = threadIdx.x & 63; k < 2 * n; k += 64) dst[k] = tmpb[(size_t)mu * 2 * np + k];
+  }
+  for (int k = threadIdx.x; k < 2 * n; k += blockDim.x)
+    out[(size_t)x * n * 2 + k] = res[k] - (res[2 * np + k] + res[4 * np + k] + res[6 * np + k] + res[8 * np + k]);
+}
+template <typename T>
+__global__ void coarse_apply_once_finish_kernel(T* __restrict__ out, const T* __restrict__ bwd, CoarseOpDev<T> op) {
+  const size_t V = op.V, n2 = (size_t)op.n * 2;
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= V * n2) return;
+  const size_t x = i / n2, k = i - x * n2;
+  T s = 0;
+#pragma unroll
+  for (int mu = 0; mu < 4; mu++) {
+    const int y = op.nb[(size_t)(4 + mu) * V + x];
+    s += y >= 0 ? bwd[((size_t)mu * V + x) * n2 + k] : op.halo[op.hoff[4 + mu] + (size_t)(-1 - y) * n2 + k];
+  }
+  out[i] -= s;
+}
+
 template <typename T>
 typename CoarseOp<T>::BlockPlan CoarseOp<T>::make_block_plan(const Geometry& g) {
   BlockPlan p;
@@ -381,7 +430,22 @@ static void launch_site(const CoarseOpDev<T>& op, T* out, const T* in, int s0, i
 template <typename T> void CoarseOp<T>::apply(T* out, const T* in, hipStream_t st) const {
   DDAMG_REQUIRE(out != in, "coarse apply cannot run in place");
   halo_exchange(in, st);
-  launch_site<T>(dev(), out, in, 0, V_, MODE_FULL, 1.0, -1.0, false, st);
+  static const bool twice = getenv("DDAMG_COARSE_APPLY_TWICE") != nullptr;
+  if (twice || V_ < 2048) {   // small (coarsest) lattices sit in the Infinity Cache: the second read is free, the extra launch is not
+    launch_site<T>(dev(), out, in, 0, V_, MODE_FULL, 1.0, -1.0, false, st);
+    return;
+  }
+  if (!bwd_) DDAMG_HIP_CHECK(device_alloc(&bwd_, sizeof(T) * 4 * (size_t)V_ * n_ * 2));
+  const CoarseOpDev<T> op = dev();
+#define DDAMG_CASE(NTV) case NTV: hipLaunchKernelGGL((coarse_apply_once_kernel<T, NTV>), dim3(V_), dim3(320), 0, st, out, bwd_, in, op); break;
+  switch (nt_) {
+    DDAMG_CASE(1) DDAMG_CASE(2) DDAMG_CASE(3) DDAMG_CASE(4) DDAMG_CASE(5) DDAMG_CASE(6) DDAMG_CASE(7) DDAMG_CASE(8)
+    default: DDAMG_REQUIRE(false, "coarse operator: more than 64 dof per site are not supported");
+  }
+#undef DDAMG_CASE
+  const size_t total = (size_t)V_ * n_ * 2;
+  hipLaunchKernelGGL(coarse_apply_once_finish_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, bwd_, op);
+  DDAMG_HIP_CHECK(hipGetLastError());
 }
 template <typename T> void CoarseOp<T>::hop(T* out, const T* in, int s0, int s1, double sign, bool accumulate, hipStream_t st) const {
   DDAMG_REQUIRE(out != in, "coarse hopping term cannot run in place");
@@ -469,6 +533,7 @@ void CoarseOp<T>::compute_self_inverse(hipStream_t st) {
 template <typename T> CoarseOp<T>::~CoarseOp() {
   if (M_) (void)hipFree(M_);
   if (Minv_) (void)hipFree(Minv_);
+  if (bwd_) (void)hipFree(bwd_);
   if (nb_) (void)hipFree(nb_);
 }
 template <typename T>
