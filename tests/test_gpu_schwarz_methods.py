@@ -112,3 +112,17 @@ def test_three_level_kcycle_solve(method, mp):
     D, cl, _ = orc.gauge_to_operator([8, 8, 8, 8], gold8["gauge"], 1, p.m0, p.csw)
     assert relerr(orc.dirac_apply([8, 8, 8, 8], D, cl, x, 64), b) < 1e-9
     c.close()
+
+
+def test_fp64_vcycle_mode(case):
+    """mixed_precision 0 (the whole V-cycle in fp64, double instantiations of the same kernels) with each smoother: the
+    solve on the reference's hierarchy needs the reference's iteration count within one"""
+    g, gm, method = case
+    c = make_ctx(g, mixed_precision=0, method=method)
+    c.setup(setup_iterations(g))
+    b = np.zeros((volume(g), 12, 2)); b[..., 0] = 1.0
+    x, it, cit, rr = c.solve(b, 1e-10)
+    assert abs(it - int(gm["ones_solve_iters"][0])) <= 1 and rr < 1e-10
+    from oracle import orc
+    assert relerr(orc.dirac_apply(lattice(g), g["D"], g["clover"], x, 64), b) < 1e-9
+    c.close()
