@@ -152,7 +152,7 @@ int ddamg_hip_set_gauge(ddamg_hip_ctx* c, const double* gauge_lex, int anti_pbc,
   if (g.distributed()) {
     DDAMG_REQUIRE(c->comm != nullptr, "set_gauge on a process grid fetches the neighbours' links: install a transport first "
                                       "(ddamg_hip_comm_init_rccl / ddamg_hip_comm_init_host / ddamg_hip_comm_init_mpi)");
-    pl = gauge_to_operator_dist(g, c->comm, gauge_lex, anti_pbc, c->par.m0, c->par.csw, c->D_host.data(), c->clover_host.data());
+    pl = gauge_to_operator_dist(g, c->comm, gauge_lex, anti_pbc, c->par.m0, c->par.csw, c->D_host.data(), c->clover_host.data(), c->stream);
   } else {
     static const bool host_clover = getenv("DDAMG_HOST_CLOVER") != nullptr;
     if (host_clover) pl = gauge_to_operator(g.L, gauge_lex, anti_pbc, c->par.m0, c->par.csw, c->D_host.data(), c->clover_host.data());

@@ -155,7 +155,7 @@ double gauge_to_operator(const int L[4], const double* gauge_in, int anti_pbc, d
 }
 
 double gauge_to_operator_dist(const Geometry& g, Comm* comm, const double* gauge_in, int anti_pbc, double m0, double csw,
-                              double* D_out, double* clover_out) {
+                              double* D_out, double* clover_out, hipStream_t st) {
   const int* L = g.L;
   const int V = g.V;
   Field f; for (int i = 0; i < 4; i++) { f.L[i] = L[i]; f.h[i] = g.split[i] ? 1 : 0; }
@@ -201,7 +201,9 @@ double gauge_to_operator_dist(const Geometry& g, Comm* comm, const double* gauge
     }
   }
   f.U = Ue.data();
-  double acc[2] = {clover_and_plaquette(f, m0, csw, clover_out), (double)V * 6.0};
+  static const bool host_clover = getenv("DDAMG_HOST_CLOVER") != nullptr;
+  double acc[2] = {host_clover ? clover_and_plaquette(f, m0, csw, clover_out) : clover_and_plaquette_extended_device(L, f.h, Ue.data(), m0, csw, clover_out, st),
+                   (double)V * 6.0};
   comm_allreduce_host(comm, acc, 2);
   return acc[0] / acc[1];
 }

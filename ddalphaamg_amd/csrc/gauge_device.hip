@@ -1,5 +1,5 @@
-// gauge_device.hip -- clover term and plaquette on the device (single process; gauge.cpp keeps the host form, which is
-// also the one that fetches the neighbours' links on a process grid).
+// gauge_device.hip -- clover term and plaquette on the device, for the own lattice of a single process and for the
+// lattice extended by the neighbours' links on a process grid (gauge.cpp fetches them and keeps the host form).
 // Reference: compute_clover_term src/dirac.c:24-58, Q / Qdiff / set_clover :304-402, calc_plaq :568-622.
 // One thread per lexicographic site; links are read straight from the reference layout [V][4][3x3] complex fp64.
 #include "gauge.h"
@@ -71,12 +71,17 @@ __device__ M3d leaves(const double* __restrict__ U, const Lat& g, const int x[4]
 
 struct GammaProducts { double re[6][16], im[6][16]; };   // gamma_mu gamma_nu for the six planes mu < nu
 
+// U: links of the lattice g (the own one, or the own one extended by a shell `halo` sites deep in the split directions:
+// then the wrap-around of `shiftd` is never taken in those directions); one thread per site of the own lattice `loc`
 __global__ __launch_bounds__(64) void clover_kernel(double* __restrict__ clover, double* __restrict__ plaq_site, const double* __restrict__ U,
-                                                    Lat g, int V, double m0, double csw, GammaProducts gp) {
-  const int lx = blockIdx.x * 64 + threadIdx.x;
-  if (lx >= V) return;
-  int x[4]; int r = lx;
-  x[3] = r % g.L[3]; r /= g.L[3]; x[2] = r % g.L[2]; r /= g.L[2]; x[1] = r % g.L[1]; r /= g.L[1]; x[0] = r;
+                                                    Lat g, Lat loc, Lat halo, int V, double m0, double csw, GammaProducts gp) {
+  const int site = blockIdx.x * 64 + threadIdx.x;
+  if (site >= V) return;
+  int x[4]; int r = site;
+  x[3] = r % loc.L[3]; r /= loc.L[3]; x[2] = r % loc.L[2]; r /= loc.L[2]; x[1] = r % loc.L[1]; r /= loc.L[1]; x[0] = r;
+#pragma unroll
+  for (int mu = 0; mu < 4; mu++) x[mu] += halo.L[mu];
+  const size_t lx = lexd(g, x);
   double clr[42], cli[42];
   for (int k = 0; k < 42; k++) { clr[k] = k < 12 ? 4.0 + m0 : 0.0; cli[k] = 0.0; }
   double pl = 0;
@@ -103,8 +108,8 @@ __global__ __launch_bounds__(64) void clover_kernel(double* __restrict__ clover,
         for (int i = 6; i < 12; i++) for (int j = i + 1; j < 12; j++, k++) { cplx t = T(i, j); clr[k] += t.r; cli[k] += t.i; }
       }
     }
-  for (int k = 0; k < 42; k++) { clover[((size_t)lx * 42 + k) * 2] = clr[k]; clover[((size_t)lx * 42 + k) * 2 + 1] = cli[k]; }
-  plaq_site[lx] = pl;
+  for (int k = 0; k < 42; k++) { clover[((size_t)site * 42 + k) * 2] = clr[k]; clover[((size_t)site * 42 + k) * 2 + 1] = cli[k]; }
+  plaq_site[site] = pl;
 }
 
 __global__ void scale_links_kernel(double* __restrict__ D, double* __restrict__ U, size_t n, int anti_pbc, size_t first_last_slice, int Lx_links) {
@@ -117,20 +122,7 @@ __global__ void scale_links_kernel(double* __restrict__ D, double* __restrict__ 
   D[i] = 0.5 * u;
   (void)Lx_links;
 }
-}  // namespace
-
-double gauge_to_operator_device(const int L[4], const double* gauge_in, int anti_pbc, double m0, double csw, double* D_out, double* clover_out,
-                                hipStream_t st) {
-  const size_t V = (size_t)L[0] * L[1] * L[2] * L[3];
-  double *dU = nullptr, *dD = nullptr, *dC = nullptr, *dP = nullptr;
-  DDAMG_HIP_CHECK(device_alloc(&dU, sizeof(double) * 72 * V));
-  DDAMG_HIP_CHECK(device_alloc(&dD, sizeof(double) * 72 * V));
-  DDAMG_HIP_CHECK(device_alloc(&dC, sizeof(double) * 84 * V));
-  DDAMG_HIP_CHECK(device_alloc(&dP, sizeof(double) * V));
-  DDAMG_HIP_CHECK(hipMemcpyAsync(dU, gauge_in, sizeof(double) * 72 * V, hipMemcpyHostToDevice, st));
-  const size_t vol3 = (size_t)L[1] * L[2] * L[3];
-  hipLaunchKernelGGL(scale_links_kernel, dim3((unsigned)((72 * V + 255) / 256)), dim3(256), 0, st, dD, dU, 72 * V, anti_pbc,
-                     (size_t)(L[0] - 1) * vol3 * 72, 0);
+static GammaProducts gamma_products() {
   // gamma_mu gamma_nu (BASIS0, src/clifford.h:39-100)
   static const int col[4][4] = {{2, 3, 0, 1}, {3, 2, 1, 0}, {3, 2, 1, 0}, {2, 3, 0, 1}};
   static const double vre[4][4] = {{-1, -1, -1, -1}, {0, 0, 0, 0}, {-1, 1, 1, -1}, {0, 0, 0, 0}};
@@ -146,18 +138,55 @@ double gauge_to_operator_device(const int L[4], const double* gauge_in, int anti
         gp.re[plane][4 * i + j] = ar * br - ai * bi; gp.im[plane][4 * i + j] = ar * bi + ai * br;
       }
     }
-  Lat g; for (int mu = 0; mu < 4; mu++) g.L[mu] = L[mu];
-  hipLaunchKernelGGL(clover_kernel, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, st, dC, dP, dU, g, (int)V, m0, csw, gp);
+  return gp;
+}
+
+// clover term of the V own sites into clover_out (host) and the sum of their plaquette traces; dU: links of the lattice
+// `ext` on the device
+static double clover_and_plaquette_on_device(const double* dU, const Lat& ext, const Lat& loc, const Lat& halo, double m0, double csw, double* clover_out, hipStream_t st) {
+  const size_t V = (size_t)loc.L[0] * loc.L[1] * loc.L[2] * loc.L[3];
+  double *dC = nullptr, *dP = nullptr;
+  DDAMG_HIP_CHECK(device_alloc(&dC, sizeof(double) * 84 * V));
+  DDAMG_HIP_CHECK(device_alloc(&dP, sizeof(double) * V));
+  hipLaunchKernelGGL(clover_kernel, dim3((unsigned)((V + 63) / 64)), dim3(64), 0, st, dC, dP, dU, ext, loc, halo, (int)V, m0, csw, gamma_products());
   DDAMG_HIP_CHECK(hipGetLastError());
   std::vector<double> hp(V);
-  DDAMG_HIP_CHECK(hipMemcpyAsync(D_out, dD, sizeof(double) * 72 * V, hipMemcpyDeviceToHost, st));
   DDAMG_HIP_CHECK(hipMemcpyAsync(clover_out, dC, sizeof(double) * 84 * V, hipMemcpyDeviceToHost, st));
   DDAMG_HIP_CHECK(hipMemcpyAsync(hp.data(), dP, sizeof(double) * V, hipMemcpyDeviceToHost, st));
   DDAMG_HIP_CHECK(hipStreamSynchronize(st));
-  for (double* p : {dU, dD, dC, dP}) DDAMG_HIP_CHECK(hipFree(p));
+  DDAMG_HIP_CHECK(hipFree(dC)); DDAMG_HIP_CHECK(hipFree(dP));
   double plaq = 0;
   for (size_t i = 0; i < V; i++) plaq += hp[i];   // same summation order as the host code
+  return plaq;
+}
+}  // namespace
+
+double gauge_to_operator_device(const int L[4], const double* gauge_in, int anti_pbc, double m0, double csw, double* D_out, double* clover_out,
+                                hipStream_t st) {
+  const size_t V = (size_t)L[0] * L[1] * L[2] * L[3];
+  double *dU = nullptr, *dD = nullptr;
+  DDAMG_HIP_CHECK(device_alloc(&dU, sizeof(double) * 72 * V));
+  DDAMG_HIP_CHECK(device_alloc(&dD, sizeof(double) * 72 * V));
+  DDAMG_HIP_CHECK(hipMemcpyAsync(dU, gauge_in, sizeof(double) * 72 * V, hipMemcpyHostToDevice, st));
+  const size_t vol3 = (size_t)L[1] * L[2] * L[3];
+  hipLaunchKernelGGL(scale_links_kernel, dim3((unsigned)((72 * V + 255) / 256)), dim3(256), 0, st, dD, dU, 72 * V, anti_pbc,
+                     (size_t)(L[0] - 1) * vol3 * 72, 0);
+  DDAMG_HIP_CHECK(hipMemcpyAsync(D_out, dD, sizeof(double) * 72 * V, hipMemcpyDeviceToHost, st));
+  Lat g, none; for (int mu = 0; mu < 4; mu++) { g.L[mu] = L[mu]; none.L[mu] = 0; }
+  const double plaq = clover_and_plaquette_on_device(dU, g, g, none, m0, csw, clover_out, st);
+  DDAMG_HIP_CHECK(hipFree(dU)); DDAMG_HIP_CHECK(hipFree(dD));
   return plaq / ((double)V * 6.0);
+}
+
+double clover_and_plaquette_extended_device(const int L[4], const int halo[4], const double* U_ext_host, double m0, double csw, double* clover_out, hipStream_t st) {
+  Lat ext, loc, h; size_t Ve = 1;
+  for (int mu = 0; mu < 4; mu++) { loc.L[mu] = L[mu]; h.L[mu] = halo[mu]; ext.L[mu] = L[mu] + 2 * halo[mu]; Ve *= ext.L[mu]; }
+  double* dU = nullptr;
+  DDAMG_HIP_CHECK(device_alloc(&dU, sizeof(double) * 72 * Ve));
+  DDAMG_HIP_CHECK(hipMemcpyAsync(dU, U_ext_host, sizeof(double) * 72 * Ve, hipMemcpyHostToDevice, st));
+  const double plaq = clover_and_plaquette_on_device(dU, ext, loc, h, m0, csw, clover_out, st);
+  DDAMG_HIP_CHECK(hipFree(dU));
+  return plaq;
 }
 
 }  // namespace ddamg
