@@ -366,12 +366,15 @@ class Context:
     def vcycle(self, phi, eta):
         _check(self._lib.ddamg_hip_vcycle(self._h, phi._h, eta._h))
 
-    def solve(self, b_lex, tol=0.0):
-        """returns (x_lex, iterations, coarse_iterations, true relative residual)"""
+    def solve(self, b_lex, tol=0.0, out=None):
+        """returns (x_lex, iterations, coarse_iterations, true relative residual); `out` reuses a solution array (a fresh
+        one is first touched page by page while the device writes into it, which costs more than the solve at 32^4)"""
         b = np.ascontiguousarray(b_lex, dtype=np.float64)
         if b.size != self.volume(0) * 24:
             raise DDAMGError("solve: right-hand side must hold V*12 complex numbers")
-        x = np.empty((self.volume(0), 12, 2))
+        x = out if out is not None else np.empty((self.volume(0), 12, 2))
+        if x.dtype != np.float64 or not x.flags.c_contiguous or x.size != b.size:
+            raise DDAMGError("solve: `out` must be a C-contiguous float64 array of V*12 complex numbers")
         it = ctypes.c_int(0); ci = ctypes.c_int(0); rr = ctypes.c_double(0)
         _check(self._lib.ddamg_hip_solve(self._h, _dp(x), _dp(b), float(tol), ctypes.byref(it), ctypes.byref(ci), ctypes.byref(rr)))
         return x, it.value, ci.value, rr.value
