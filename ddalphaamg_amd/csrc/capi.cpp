@@ -59,6 +59,10 @@ int ddamg_hip_create(const ddamg_hip_params* p, ddamg_hip_ctx** out) {
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(p && out, "null argument");
   DDAMG_REQUIRE(p->num_levels >= 1 && p->num_levels <= DDAMG_HIP_MAX_LEVELS, "1 <= num_levels <= 4");
+  DDAMG_REQUIRE(p->method >= -1 && p->method <= 4, "method must be -1 (CGN), 0 (GMRES), 1/2/3 (additive / red-black / sixteen-colour SAP) or 4 (GMRES smoother); "
+                                                   "5 (BiCGstab) and 6 (g5D variant) of the reference are not implemented");
+  DDAMG_REQUIRE(p->method <= 0 || p->odd_even == 1, "only the odd-even preconditioned smoothers and coarsest-level solve are implemented (odd_even = 1)");
+  DDAMG_REQUIRE(p->mixed_precision >= 0 && p->mixed_precision <= 2, "mixed_precision must be 0, 1 or 2");
   int ndev = 0;
   DDAMG_HIP_CHECK(hipGetDeviceCount(&ndev));
   DDAMG_REQUIRE(ndev > 0, "no HIP device visible: the MI355X path has no CPU fallback");

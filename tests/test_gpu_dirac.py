@@ -148,3 +148,16 @@ def test_error_paths():
     with pytest.raises(dd.DDAMGError):
         x.upload(np.zeros(5))
     ctx.close()
+
+
+@pytest.mark.parametrize("field,value,message", [("method", 5, "not implemented"), ("method", 6, "not implemented"), ("method", -2, "method must be"),
+                                                 ("odd_even", 0, "odd-even"), ("mixed_precision", 3, "mixed_precision")])
+def test_unsupported_parameters_are_refused_at_creation(field, value, message):
+    """the variants of the reference that are not implemented fail loudly instead of running something else"""
+    from ddalphaamg_amd import api
+    p = api.default_params(); p.num_levels = 2
+    for mu in range(4):
+        p.local_lattice[0][mu] = 4; p.block_lattice[0][mu] = 2; p.local_lattice[1][mu] = 2
+    setattr(p, field, value)
+    with pytest.raises(dd.DDAMGError, match=message):
+        dd.Context(p)
