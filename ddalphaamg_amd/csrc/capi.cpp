@@ -68,6 +68,13 @@ int ddamg_hip_create(const ddamg_hip_params* p, ddamg_hip_ctx** out) {
   DDAMG_REQUIRE(ndev > 0, "no HIP device visible: the MI355X path has no CPU fallback");
   DDAMG_REQUIRE(p->device >= 0 && p->device < ndev, "device ordinal out of range");
   DDAMG_HIP_CHECK(hipSetDevice(p->device));
+  {
+    // the Krylov loops read one small result back per iteration: a host thread that spins on the completion signal sees it
+    // ~15 us earlier than one that sleeps (2 % of a 32^4 solve); one process per GPU owns its core anyway, as the
+    // reference's MPI ranks do.  Process-wide device flag; DDAMG_SYNC_SPIN=0 leaves the runtime's default.
+    const char* e = getenv("DDAMG_SYNC_SPIN");
+    if (!e || atoi(e) != 0) { (void)hipSetDeviceFlags(hipDeviceScheduleSpin); (void)hipGetLastError(); }
+  }
   std::unique_ptr<ddamg_hip_ctx> c(new ddamg_hip_ctx);
   c->par = *p;
   for (int mu = 0; mu < 4; mu++) if (c->par.process_grid[mu] < 1 && c->par.process_grid[mu] != -1) { c->par.process_grid[mu] = 1; c->par.process_coords[mu] = 0; }
