@@ -240,7 +240,7 @@ def test_pure_gmres_method0(gold4):
     ctx.close()
 
 
-@pytest.mark.parametrize("mp,fixture", [(1, "ref_8x8_3lvl.npz"), (2, "ref_8x8_3lvl_mp2.npz")])
+@pytest.mark.parametrize("mp,fixture", [(1, "ref_8x8_3lvl.npz"), (2, "ref_8x8_3lvl_mp2.npz"), (0, "ref_8x8_3lvl.npz")])
 def test_three_level_kcycle_solve(gold8, mp, fixture):
     """BASELINE config: the reference's sample.ini on conf/8x8x8x8b6.0000id3n1 -- 3 levels (8^4 -> 4^4 -> 2^4),
     Nvec 28/28, 2^4 blocks, K-cycle(5,2,0.1), setup 4 (+3 on level 1), rhs = ones, with mixed precision 1 and 2.
@@ -269,11 +269,15 @@ def test_three_level_kcycle_solve(gold8, mp, fixture):
     x, it, cit, rr = ctx.solve(b, 1e-10)
     ref_it = int(g3["ones_solve_iters"][0]); ref_hist = g3["ref_log_ones_history"]
     # measured: identical to the reference -- 11 iterations, 192 coarse iterations, same history to 3 digits
-    assert it == ref_it and rr < 1e-10
-    hist = ctx.residual_history()
-    assert len(hist) == len(ref_hist) and np.all(np.abs(hist / ref_hist - 1.0) < 5e-3)
-    assert abs(cit - int(g3["ones_solve_iters"][1])) <= 10
-    assert abs(rr / float(g3["ones_solve_norm_res"][0]) - 1.0) < 0.05
+    if mp == 0:
+        # fp64 V-cycle (double instantiations of every multigrid kernel): not the reference's arithmetic, same convergence
+        assert abs(it - ref_it) <= 1 and rr < 1e-10
+    else:
+        assert it == ref_it and rr < 1e-10
+        hist = ctx.residual_history()
+        assert len(hist) == len(ref_hist) and np.all(np.abs(hist / ref_hist - 1.0) < 5e-3)
+        assert abs(cit - int(g3["ones_solve_iters"][1])) <= 10
+        assert abs(rr / float(g3["ones_solve_norm_res"][0]) - 1.0) < 0.05
     from oracle import orc
     D, cl, _ = orc.gauge_to_operator([8, 8, 8, 8], gold8["gauge"], 1, p.m0, p.csw)
     assert relerr(orc.dirac_apply([8, 8, 8, 8], D, cl, x, 64), b) < 1e-9

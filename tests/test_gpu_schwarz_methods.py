@@ -71,11 +71,12 @@ def test_setup_and_solve_iteration_parity(case):
     c.close()
 
 
-@pytest.mark.parametrize("mp", [1, 2])
+@pytest.mark.parametrize("mp", [1, 2, 0])
 @pytest.mark.parametrize("method", [1, 3, 4])
 def test_three_level_kcycle_solve(method, mp):
     """the reference's sample.ini hierarchy on conf/8x8x8x8b6.0000id3n1 (3 levels, K-cycle) with the additive / sixteen-colour
-    schedule on both smoothing levels.  Mixed precision 2 has no reference run here: it must agree with mixed precision 1
+    schedule on both smoothing levels.  Mixed precision 2 and 0 (fp64 V-cycle: the double instantiations of the coarse-level
+    kernels, incl. the fused block solver with its 98 KB of LDS) have no reference run here: they must agree with mixed precision 1
     (the additive smoother then also hands back D*phi, src/schwarz_generic.c:1180-1222)."""
     gold8 = load_golden("ref_8x8_dirac.npz")
     g3 = load_golden(f"ref_8x8_3lvl_m{method}.npz")
