@@ -28,6 +28,7 @@ struct FineOpDev {
   // arithmetic neighbours when a 256-site tile is exactly one Schwarz block (geometry.h); null otherwise
   const int* tile_nb;             // [8][V/256]
   const unsigned short* tnb;      // [256][8]
+  const unsigned char* parity;    // [V] global parity of every site (0 even, 1 odd)
 };
 
 template <typename T>
@@ -43,7 +44,7 @@ class FineOp {
   void upload(const Geometry& g, const double* D_ref, const double* clover_ref, hipStream_t st);
   // eta = D_W phi; with a process grid: pack -> exchange (overlapped with the interior tiles) -> boundary tiles
   void apply(T* eta, const T* phi, hipStream_t st) const;
-  FineOpDev<T> dev() const { return FineOpDev<T>{D_, clover_, clover_inv_, nb_, V_, halo_.recv(), halo_.dev(), tile_nb_, tnb_}; }
+  FineOpDev<T> dev() const { return FineOpDev<T>{D_, clover_, clover_inv_, nb_, V_, halo_.recv(), halo_.dev(), tile_nb_, tnb_, parity_}; }
   int V() const { return V_; }
   void set_comm(Comm* c) { comm_ = c; }
   // fill the receive arena with the boundary half spinors of `v` (for kernels other than apply() that couple
@@ -56,8 +57,14 @@ class FineOp {
   // global odd-even pieces (GMRES smoother, src/oddeven_generic.c:584-760).  Vectors keep their full length; the sites
   // of the other parity hold zeros, so that eta = D phi gives  D_ee phi_e  on the even and the hopping term H_oe phi_e on
   // the odd sites of an even-only phi (and the other way round).
+  //   hop: out = (D - diagonal) in on the sites of parity `par` (the others are left alone); `in` is read on the other parity only
+  //        (hopping_term_PRECISION with _EVEN_SITES / _ODD_SITES: half the sites, every link used once)
+  //   ee_minus: out = D_ee a - b on the even sites, 0 on the odd ones (diag_ee_PRECISION + the final subtraction)
   //   oo_inv: out = D_oo^-1 in on the odd sites, 0 on the even ones (diag_oo_inv_PRECISION :547-582)
   //   parity_select: out = a - b (b may be null) on the sites of parity `keep` (0 even, 1 odd), 0 elsewhere
+  //        post 1: out = D_ss^-1 (hop) ; post 2: out = D_ss a - hop   (the two halves of the Schur complement, fused)
+  void hop(T* out, const T* in, int par, hipStream_t st, int post = 0, const T* a = nullptr) const;
+  void ee_minus(T* out, const T* a, const T* b, hipStream_t st) const;
   void oo_inv(T* out, const T* in, hipStream_t st) const;
   void parity_select(T* out, const T* a, const T* b, int keep, hipStream_t st) const;
 

@@ -184,6 +184,113 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) void dirac_apply_lds
   if (live) store_site<T, 24, DDAMG_NT_STORE>(eta, V, s, e);
 }
 
+// ---- hopping term onto one parity (global odd-even: GMRES smoother) -----------------------------------------------
+// Same tiling as above with the two roles separated: a site of the input parity only produces the backward products of
+// its links (for its +mu neighbours), a site of the output parity only consumes -- its own links for the forward terms,
+// the products of its -mu neighbours for the backward ones.  Every link is read once; with the parity-split order of the
+// sites inside a block whole wavefronts take one role.
+template <typename T, int MU, bool ARITH>
+__device__ __forceinline__ void tile_dir_parity(const T* __restrict__ phi, const FineOpDev<T>& op, size_t s, bool live, bool is_out, int tile0, const uint4& q,
+                                                const T (&p)[24], T (&e)[24], T* __restrict__ sp, T* __restrict__ hb) {
+  const size_t V = op.V;
+  const int t = threadIdx.x;
+  T U[18];
+  if (live) load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, s, U);
+  if (live && !is_out) {
+    T h[12], g[12];
+    spin_project<T, MU, +1>(p, h);
+    su3_mul_dag<T>(U, h, g);
+#pragma unroll
+    for (int c = 0; c < 12; c++) hb[c * 256 + t] = g[c];
+  }
+  if (live && is_out) {
+    const int j = tile_neighbor<ARITH>(op.nb, V, s, MU, tile0, q, op.tile_nb, (int)(V >> 8));
+    if (j >= 0) {
+      T pn[24];
+      if (j - tile0 >= 0 && j - tile0 < 256) {
+#pragma unroll
+        for (int c = 0; c < 24; c++) pn[c] = sp[c * 256 + (j - tile0)];
+      } else {
+        load_site<T, 24>(phi, V, j, pn);
+      }
+      hop_accumulate<T, MU, true>(U, pn, e);
+    } else {
+      halo_forward<T, MU>(op, -1 - j, U, e);
+    }
+  }
+  __syncthreads();
+  if (live && is_out) {
+    const int j = tile_neighbor<ARITH>(op.nb, V, s, 4 + MU, tile0, q, op.tile_nb, (int)(V >> 8));
+    if (j < 0) {
+      halo_backward<T, MU>(op, -1 - j, e);
+    } else if (j - tile0 >= 0 && j - tile0 < 256) {
+      T g[12];
+#pragma unroll
+      for (int c = 0; c < 12; c++) g[c] = hb[c * 256 + (j - tile0)];
+      spin_reconstruct_sub<T, MU, +1>(g, e);
+    } else {
+      T pn[24], Un[18];
+      load_site<T, 24>(phi, V, j, pn);
+      load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, j, Un);
+      hop_accumulate<T, MU, false>(Un, pn, e);
+    }
+  }
+  __syncthreads();
+}
+
+template <typename T, bool ARITH>
+__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) void dirac_hop_parity_kernel(T* __restrict__ eta, const T* __restrict__ phi, FineOpDev<T> op, int ntiles,
+                                                                                         const int* __restrict__ tile_list, int par, int post,
+                                                                                         const T* __restrict__ a) {
+  __shared__ T sp[24 * 256];
+  __shared__ T hb[12 * 256];
+  int tile = blockIdx.x;
+  if ((ntiles & 7) == 0) tile = (blockIdx.x & 7) * (ntiles >> 3) + (blockIdx.x >> 3);
+  if (tile_list) tile = tile_list[tile];
+  const size_t V = op.V;
+  const int tile0 = tile * 256;
+  const size_t s = (size_t)tile0 + threadIdx.x;
+  const bool live = s < V;
+  const bool is_out = live && op.parity[s] == par;
+  T p[24], e[24];
+  uint4 q = make_uint4(0, 0, 0, 0);
+  if constexpr (ARITH) q = reinterpret_cast<const uint4*>(op.tnb)[threadIdx.x];
+#pragma unroll
+  for (int k = 0; k < 24; k++) { p[k] = 0; e[k] = 0; }
+  if (live && !is_out) {
+    load_site<T, 24>(phi, V, s, p);
+#pragma unroll
+    for (int c = 0; c < 24; c++) sp[c * 256 + threadIdx.x] = p[c];
+  }
+  __syncthreads();
+  tile_dir_parity<T, 0, ARITH>(phi, op, s, live, is_out, tile0, q, p, e, sp, hb);
+  tile_dir_parity<T, 1, ARITH>(phi, op, s, live, is_out, tile0, q, p, e, sp, hb);
+  tile_dir_parity<T, 2, ARITH>(phi, op, s, live, is_out, tile0, q, p, e, sp, hb);
+  tile_dir_parity<T, 3, ARITH>(phi, op, s, live, is_out, tile0, q, p, e, sp, hb);
+  if (is_out) {   // the sites of the input parity are left alone
+    if (post == 1) {          // D_ss^-1 (H in): the odd half of the Schur complement
+      T f[24], cl[36];
+      load_site<T, 36>(op.clover_inv, V, s, cl);
+      herm6_mul<T>(cl, e, f);
+      load_site<T, 36>(op.clover_inv + (size_t)36 * V, V, s, cl);
+      herm6_mul<T>(cl, e + 12, f + 12);
+      store_site<T, 24>(eta, V, s, f);
+    } else if (post == 2) {   // D_ss a - H in: its even half
+      T pa[24], f[24], cl[36];
+      load_site<T, 24>(a, V, s, pa);
+      load_site<T, 36>(op.clover, V, s, cl);
+      herm6_mul<T>(cl, pa, f);
+      load_site<T, 36>(op.clover + (size_t)36 * V, V, s, cl);
+      herm6_mul<T>(cl, pa + 12, f + 12);
+#pragma unroll
+      for (int k = 0; k < 24; k++) f[k] -= e[k];
+      store_site<T, 24>(eta, V, s, f);
+    } else {
+      store_site<T, 24>(eta, V, s, e);
+    }
+  }
+}
+
 // the couplings to sites on other GPUs, added after the exchange: one thread per boundary site (a site on an edge or
 // corner of the local lattice takes all its off-process directions here, so no two threads touch the same site)
 template <typename T, int MU>
@@ -252,6 +359,24 @@ void FineOp<T>::apply(T* eta, const T* phi, hipStream_t st) const {
     return;
   }
   // default: tiles without an off-process neighbour during the exchange, the others after it
+  launch(halo_.n_interior(), halo_.interior_tiles());
+  halo_.exchange_finish(comm_, st);
+  launch(halo_.n_boundary(), halo_.boundary_tiles());
+}
+
+template <typename T>
+void FineOp<T>::hop(T* eta, const T* phi, int par, hipStream_t st, int post, const T* a) const {
+  DDAMG_REQUIRE(post == 0 || post == 1 || (post == 2 && a != nullptr && a != eta), "hop: unknown epilogue");
+  DDAMG_REQUIRE(D_ != nullptr, "fine operator not uploaded");
+  auto launch = [&](int ntiles, const int* tile_list) {
+    if (ntiles == 0) return;
+    if (tnb_) hipLaunchKernelGGL((dirac_hop_parity_kernel<T, true>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, tile_list, par, post, a);
+    else hipLaunchKernelGGL((dirac_hop_parity_kernel<T, false>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, tile_list, par, post, a);
+    DDAMG_HIP_CHECK(hipGetLastError());
+  };
+  if (!halo_.active()) { launch((V_ + 255) / 256, nullptr); return; }
+  halo_.pack(phi, D_, V_, st);
+  halo_.exchange_begin(comm_, st);
   launch(halo_.n_interior(), halo_.interior_tiles());
   halo_.exchange_finish(comm_, st);
   launch(halo_.n_boundary(), halo_.boundary_tiles());
@@ -444,6 +569,33 @@ __global__ __launch_bounds__(256) void parity_select_kernel(T* __restrict__ out,
     for (int k = 0; k < 24; k++) e[k] = 0;
   }
   store_site<T, 24>(out, V, s, e);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void ee_minus_kernel(T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ clover,
+                                                       const unsigned char* __restrict__ parity, int V) {
+  const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= (size_t)V) return;
+  T e[24];
+  if (!parity[s]) {
+    T p[24], f[24], cl[36];
+    load_site<T, 24>(a, V, s, p);
+    load_site<T, 36>(clover, V, s, cl);
+    herm6_mul<T>(cl, p, e);
+    load_site<T, 36>(clover + (size_t)36 * V, V, s, cl);
+    herm6_mul<T>(cl, p + 12, e + 12);
+    load_site<T, 24>(b, V, s, f);
+#pragma unroll
+    for (int k = 0; k < 24; k++) e[k] -= f[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < 24; k++) e[k] = 0;
+  }
+  store_site<T, 24>(out, V, s, e);
+}
+template <typename T>
+void FineOp<T>::ee_minus(T* out, const T* a, const T* b, hipStream_t st) const {
+  hipLaunchKernelGGL(ee_minus_kernel<T>, dim3((unsigned)((V_ + 255) / 256)), dim3(256), 0, st, out, a, b, clover_, parity_, (int)V_);
+  DDAMG_HIP_CHECK(hipGetLastError());
 }
 template <typename T>
 void FineOp<T>::oo_inv(T* out, const T* in, hipStream_t st) const {

@@ -41,7 +41,11 @@ Multigrid<T>::Multigrid(const ddamg_hip_params& par, const std::vector<const Geo
         lv.srw.init(par.block_iter[d] + 8);
         lv.sgm.alloc(lv.nel, par.block_iter[d], false);
         lv.sgm.tol = sizeof(T) == 4 ? 1e-6 : 1e-14;
-        lv.sgm.view = whole(lv.nel);
+        // fine level: the Krylov vectors live on the even sites, which the site order keeps as the first half of every
+        // Schwarz block -- a strided view (one row per 16-byte chunk row and block), so that no BLAS-1 pass touches the odd half
+        lv.sgm.view = (d == 0 && g.block_even_sites * 2 == g.block_sites)
+                          ? View{(24 / Chunk<T>::CH) * g.num_blocks, (size_t)g.block_sites * Chunk<T>::CH, 0, (size_t)g.block_even_sites * Chunk<T>::CH}
+                          : whole(lv.nel);
         lv.sgm.st = st_; lv.sgm.rw = &lv.srw;
         lv.sgm.op = [this, d](T* out, const T* in) { this->smoother_schur(d, out, in); };
         if (d > 0) {
@@ -181,10 +185,9 @@ void Multigrid<T>::smoother_schur(int l, T* out, const T* in) {
   T *t = lv.sbuf[0], *u = lv.sbuf[1];
   if (l == 0) {
     const FineOp<T>& D = *lv.fop;
-    D.apply(t, in, st_);                    // even: D_ee in_e        odd: H_oe in_e
-    D.oo_inv(u, t, st_);                    // odd: D_oo^-1 H_oe in_e  even: 0
-    D.apply(lv.sbuf[3], u, st_);            // even: H_eo D_oo^-1 H_oe in_e
-    D.parity_select(out, t, lv.sbuf[3], 0, st_);
+    D.hop(u, in, 1, st_, 1);                // odd: D_oo^-1 H_oe in_e
+    D.hop(out, u, 0, st_, 2, in);           // even: D_ee in_e - H_eo D_oo^-1 H_oe in_e
+    (void)t;
   } else {
     const int *Le = lv.d_parity_sites[0], *Lo = lv.d_parity_sites[1];
     const int ne = lv.n_parity_sites[0], no = lv.n_parity_sites[1];
@@ -214,11 +217,11 @@ void Multigrid<T>::gmres_smoother(int l, T* phi, const T* eta, int cycles, int r
   if (l == 0) {
     const FineOp<T>& D = *lv.fop;
     D.oo_inv(u, b, st_);                          // u_o = D_oo^-1 b_o
-    D.apply(t, u, st_);                           // t_e = H_eo D_oo^-1 b_o
+    D.hop(t, u, 0, st_);                          // t_e = H_eo D_oo^-1 b_o
     D.parity_select(gm.b, b, t, 0, st_);          // b_e - D_eo D_oo^-1 b_o
     gm.num_restart = cycles; gm.initial_guess_zero = true;
     gm.solve();                                   // S x_e = b_e
-    D.apply(t, gm.x, st_);                        // t_o = H_oe x_e
+    D.hop(t, gm.x, 1, st_);                       // t_o = H_oe x_e
     D.parity_select(u, b, t, 1, st_);             // b_o - D_oe x_e on the odd sites
     D.oo_inv(t, u, st_);                          // x_o
     if (res == NO_RES) vec_plus<T>(phi, gm.x, t, all, st_);

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--agg1", type=int, nargs=4, default=[2, 2, 2, 2], help="level-1 aggregates (= blocks) for --levels 3")
     ap.add_argument("--nvec1", type=int, default=28)
     ap.add_argument("--mixed-precision", type=int, default=1)
+    ap.add_argument("--method", type=int, default=2, help="smoother: 1 additive, 2 red-black, 3 sixteen-colour SAP, 4 GMRES")
     ap.add_argument("--gauge", default="near_unit", choices=["near_unit", "random"])
     ap.add_argument("--self-exchange", default=None, help="e.g. -1,-1,-1,1: the process is its own neighbour in these directions (RCCL)")
     ap.add_argument("--rng", type=int, default=1, help="0: libc rand() in the reference's order, 1: device generator")
@@ -44,7 +45,7 @@ def main():
         p.num_vect[1] = args.nvec1; p.post_smooth_iter[1] = 2; p.block_iter[1] = 4; p.setup_iter[1] = 2
     p.restart, p.max_restart, p.tol = 50, 20, 1e-10
     p.coarse_iter, p.coarse_restart, p.coarse_tol = 100, 5, 5e-2
-    p.mixed_precision, p.method, p.odd_even = args.mixed_precision, 2, 1
+    p.mixed_precision, p.method, p.odd_even = args.mixed_precision, args.method, 1
     p.m0, p.csw = args.m0, args.csw
     p.test_vector_rng, p.rng_seed = args.rng, 20260101
     if args.self_exchange:
