@@ -59,12 +59,10 @@ class FineOp {
   // the odd sites of an even-only phi (and the other way round).
   //   hop: out = (D - diagonal) in on the sites of parity `par` (the others are left alone); `in` is read on the other parity only
   //        (hopping_term_PRECISION with _EVEN_SITES / _ODD_SITES: half the sites, every link used once)
-  //   ee_minus: out = D_ee a - b on the even sites, 0 on the odd ones (diag_ee_PRECISION + the final subtraction)
   //   oo_inv: out = D_oo^-1 in on the odd sites, 0 on the even ones (diag_oo_inv_PRECISION :547-582)
   //   parity_select: out = a - b (b may be null) on the sites of parity `keep` (0 even, 1 odd), 0 elsewhere
   //        post 1: out = D_ss^-1 (hop) ; post 2: out = D_ss a - hop   (the two halves of the Schur complement, fused)
   void hop(T* out, const T* in, int par, hipStream_t st, int post = 0, const T* a = nullptr) const;
-  void ee_minus(T* out, const T* a, const T* b, hipStream_t st) const;
   void oo_inv(T* out, const T* in, hipStream_t st) const;
   void parity_select(T* out, const T* a, const T* b, int keep, hipStream_t st) const;
 

@@ -571,33 +571,6 @@ __global__ __launch_bounds__(256) void parity_select_kernel(T* __restrict__ out,
   store_site<T, 24>(out, V, s, e);
 }
 template <typename T>
-__global__ __launch_bounds__(256) void ee_minus_kernel(T* __restrict__ out, const T* __restrict__ a, const T* __restrict__ b, const T* __restrict__ clover,
-                                                       const unsigned char* __restrict__ parity, int V) {
-  const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
-  if (s >= (size_t)V) return;
-  T e[24];
-  if (!parity[s]) {
-    T p[24], f[24], cl[36];
-    load_site<T, 24>(a, V, s, p);
-    load_site<T, 36>(clover, V, s, cl);
-    herm6_mul<T>(cl, p, e);
-    load_site<T, 36>(clover + (size_t)36 * V, V, s, cl);
-    herm6_mul<T>(cl, p + 12, e + 12);
-    load_site<T, 24>(b, V, s, f);
-#pragma unroll
-    for (int k = 0; k < 24; k++) e[k] -= f[k];
-  } else {
-#pragma unroll
-    for (int k = 0; k < 24; k++) e[k] = 0;
-  }
-  store_site<T, 24>(out, V, s, e);
-}
-template <typename T>
-void FineOp<T>::ee_minus(T* out, const T* a, const T* b, hipStream_t st) const {
-  hipLaunchKernelGGL(ee_minus_kernel<T>, dim3((unsigned)((V_ + 255) / 256)), dim3(256), 0, st, out, a, b, clover_, parity_, (int)V_);
-  DDAMG_HIP_CHECK(hipGetLastError());
-}
-template <typename T>
 void FineOp<T>::oo_inv(T* out, const T* in, hipStream_t st) const {
   hipLaunchKernelGGL(oo_inv_kernel<T>, dim3((unsigned)((V_ + 255) / 256)), dim3(256), 0, st, out, in, clover_inv_, parity_, (int)V_);
   DDAMG_HIP_CHECK(hipGetLastError());

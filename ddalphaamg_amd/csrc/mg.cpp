@@ -37,7 +37,7 @@ Multigrid<T>::Multigrid(const ddamg_hip_params& par, const std::vector<const Geo
         // smoother = GMRES on the odd-even Schur complement of this level (schwarz_PRECISION_alloc, src/schwarz_generic.c:78-83:
         // restart length block_iter, tolerance EPS_PRECISION, no preconditioner; the V-cycle sets the number of restarts)
         DDAMG_REQUIRE(par.odd_even == 1, "the GMRES smoother is implemented on the odd-even preconditioned operator (odd_even = 1)");
-        for (int i = 0; i < 4; i++) { DDAMG_HIP_CHECK(device_alloc(&lv.sbuf[i], sizeof(T) * lv.nel)); DDAMG_HIP_CHECK(device_zero(lv.sbuf[i], sizeof(T) * lv.nel)); }
+        for (int i = 0; i < 3; i++) { DDAMG_HIP_CHECK(device_alloc(&lv.sbuf[i], sizeof(T) * lv.nel)); DDAMG_HIP_CHECK(device_zero(lv.sbuf[i], sizeof(T) * lv.nel)); }
         lv.srw.init(par.block_iter[d] + 8);
         lv.sgm.alloc(lv.nel, par.block_iter[d], false);
         lv.sgm.tol = sizeof(T) == 4 ? 1e-6 : 1e-14;
@@ -136,6 +136,9 @@ Multigrid<T>::~Multigrid() {
     if (!lv.coarsest) { if (lv.depth == 0) lv.fip.release(); else lv.cip.release(); }
     if (lv.gm.slab) lv.gm.release();
     lv.rw.destroy();
+    if (lv.sgm.slab) { lv.sgm.release(); lv.srw.destroy(); }
+    for (int i = 0; i < 3; i++) if (lv.sbuf[i]) (void)hipFree(lv.sbuf[i]);
+    for (int q = 0; q < 2; q++) if (lv.d_parity_sites[q]) (void)hipFree(lv.d_parity_sites[q]);
     if (lv.d_agg_face) (void)hipFree(lv.d_agg_face);
     for (int mu = 0; mu < 4; mu++) if (lv.d_dir_mask[mu]) (void)hipFree(lv.d_dir_mask[mu]);
   }
@@ -178,7 +181,8 @@ template <typename T> void Multigrid<T>::set_kcycle_tol(double tol) {
 // ---- GMRES smoother on the odd-even Schur complement of a smoothing level (method 4) ----------------------------
 // S = D_ee - D_eo D_oo^-1 D_oe on the even sites (apply_schur_complement_PRECISION src/oddeven_generic.c:704-740,
 // coarse_apply_schur_complement_PRECISION src/coarse_oddeven_generic.c).  Vectors keep the level's full length and
-// site order; the Krylov vectors are zero on the odd sites.
+// site order; only their even sites carry the Krylov vectors (fine level: BLAS-1 through a strided even-site view;
+// coarse levels: listed kernels, the odd sites stay zero).
 template <typename T>
 void Multigrid<T>::smoother_schur(int l, T* out, const T* in) {
   MGLevel<T>& lv = *lv_[l];
@@ -187,7 +191,6 @@ void Multigrid<T>::smoother_schur(int l, T* out, const T* in) {
     const FineOp<T>& D = *lv.fop;
     D.hop(u, in, 1, st_, 1);                // odd: D_oo^-1 H_oe in_e
     D.hop(out, u, 0, st_, 2, in);           // even: D_ee in_e - H_eo D_oo^-1 H_oe in_e
-    (void)t;
   } else {
     const int *Le = lv.d_parity_sites[0], *Lo = lv.d_parity_sites[1];
     const int ne = lv.n_parity_sites[0], no = lv.n_parity_sites[1];

@@ -44,7 +44,7 @@ struct MGLevel {
   // GMRES smoother (method 4): GMRES(block_iter) restarted post_smooth_iter times on the global odd-even Schur complement
   Gmres<T> sgm;
   ReduceWork srw;
-  T* sbuf[4] = {nullptr, nullptr, nullptr, nullptr};
+  T* sbuf[3] = {nullptr, nullptr, nullptr};
   int* d_parity_sites[2] = {nullptr, nullptr};   // depth > 0: even / odd sites of this level
   int n_parity_sites[2] = {0, 0};
   // setup helpers
