@@ -21,6 +21,10 @@ def launch(nproc, *args, timeout=300):
            os.path.join(HERE, "dist_worker.py"), *args]
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    if r.returncode != 0 and any(k in r.stderr for k in ("Address already in use", "EADDRINUSE", "RendezvousConnectionError", "RendezvousTimeoutError")):
+        # the port found by free_port() was taken between the probe and torchrun's bind: once more on another one
+        cmd[cmd.index("--master-port") + 1] = str(free_port())
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "DIST_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     return r.stdout
