@@ -431,7 +431,8 @@ template <typename T> void CoarseOp<T>::apply(T* out, const T* in, hipStream_t s
   DDAMG_REQUIRE(out != in, "coarse apply cannot run in place");
   halo_exchange(in, st);
   static const bool twice = getenv("DDAMG_COARSE_APPLY_TWICE") != nullptr;
-  if (twice || V_ < 2048) {   // small (coarsest) lattices sit in the Infinity Cache: the second read is free, the extra launch is not
+  static const int min_sites = getenv("DDAMG_COARSE_APPLY_ONCE_MIN_SITES") ? atoi(getenv("DDAMG_COARSE_APPLY_ONCE_MIN_SITES")) : 2048;
+  if (twice || V_ < min_sites) {   // small (coarsest) lattices sit in the Infinity Cache: the second read is free, the extra launch is not
     launch_site<T>(dev(), out, in, 0, V_, MODE_FULL, 1.0, -1.0, false, st);
     return;
   }

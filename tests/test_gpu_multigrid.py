@@ -497,3 +497,30 @@ def test_pure_cgn_method_minus_1():
     from oracle import orc
     assert relerr(orc.dirac_apply([4, 4, 4, 4], g["D"], g["clover"], x, 64), b) < 2e-10
     ctx.close()
+
+
+def test_coarse_operator_single_read_form(gold4, monkeypatch):
+    """CoarseOp::apply has two forms: small lattices read every link from both of its end points in one launch, large ones
+    read it once (coarse_apply_once_kernel + finish).  The second form, forced here onto the golden lattices, must give the
+    reference's coarse apply as well."""
+    monkeypatch.setenv("DDAMG_COARSE_APPLY_ONCE_MIN_SITES", "0")
+    import subprocess, sys, os, textwrap
+    # the threshold is read once per process: run the comparison in a child
+    name = "ref_4x4.npz" if volume(gold4) == 256 else "ref_ragged.npz"
+    code = textwrap.dedent(f'''
+        import sys, numpy as np
+        sys.path.insert(0, {os.path.dirname(os.path.abspath(__file__))!r}); sys.path.insert(0, {os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")!r})
+        from conftest import load_golden, relerr
+        import test_gpu_multigrid as t
+        g = load_golden({name!r})
+        ctx = t.make_ctx(g)
+        ctx.set_test_vectors(g["interp_vectors"], orthonormalised=True)
+        ctx.set_coarse_operator(g["coarse_D"], g["coarse_clover"])
+        vi = ctx.vector(1, 32).upload(g["coarse_apply_in"]); vo = ctx.vector(1, 32)
+        ctx.coarse_apply(vo, vi)
+        err = relerr(vo.download(), g["coarse_apply_out"])
+        print("ERR", err)
+        assert err < t.TOL_KERNEL, err
+    ''')
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ), timeout=300)
+    assert r.returncode == 0 and "ERR" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
