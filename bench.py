@@ -194,8 +194,8 @@ def solve_leg(ctx_params, U, V, L, world=1, rank=0, transport="rccl", group=None
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--lattice", type=int, nargs=4, default=[32, 32, 32, 32])
     ap.add_argument("--global-lattice", type=int, nargs=4, default=None,
                     help="strong scaling: fixed global lattice divided over the process grid (overrides --lattice, which is "
