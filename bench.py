@@ -3,30 +3,102 @@
 
   python bench.py --gpus N --steps K --warmup W
 
-A "step" is one fine Wilson-Clover apply (d_plus_clover_float, reference src/dirac_generic.c:159-277)
-over a 32^4 local lattice of synthetic random SU(3) gauge links (BASELINE.json: the >=40 %-of-HBM
-target is quoted on exactly this; the 8^4 reference configuration lives in L2 and is a parity
-case, not a bandwidth case).  Inputs are resident in HBM before the timed region.  Rank 0 prints
-ONE JSON line: metric fine_wilson_clover_gflops (reference flop model: 1920 flop/site,
-src/init_generic.c:59,61), plus `roofline` (algorithmic 816 B/site, HIP-event time per launch on
-the library's stream) and `cpu_baseline` (the oracle port, or the real reference when it runs,
-timed on the host cores of the same box), plus `solve` (configs[2]: two-level FGMRES+AMG at 32^4) and, with
---small-lattice, `small_lattice` (BASELINE configs[1], the reference's 8^4 configuration: cache-resident, not used for
-the roofline).
+Headline (`metric`, `value`, `roofline`): a "step" is one fine Wilson-Clover apply (d_plus_clover_float, reference
+src/dirac_generic.c:159-277) over a 32^4 local lattice per GPU of synthetic random SU(3) links (BASELINE.json quotes the
+>= 40 %-of-HBM target on exactly this volume); inputs are resident in HBM before the timed region; on N GPUs every rank
+holds 32^4 sites of a decomposed lattice (weak scaling, halo exchange over RCCL overlapped with the interior tiles).
+
+Secondary objects of the same JSON line:
+  solve           (N = 1) BASELINE configs[2]: two-level FGMRES+AMG on 32^4, next to the reference's own run of the same case
+  strong_scaling  BASELINE configs[4] / SURVEY 8(d) config 5: ONE global 64^4 lattice, 3-level AMG, divided over process
+                  grids 1 / 2 (T) / 4 (T,Z) / 8 (T,Z,Y): same global gauge field and right-hand side at every N; seconds per
+                  solve, iterations, and the speed-up against the committed N = 1 time
+  cpu_baseline    (N = 1) the REAL reference (oracle/_ref, SSE build) on the host cores of this box: its fp32 d_plus_clover
+                  on the headline volume, and a bounded sample of the solve
+
+N > 1 without a launcher: `python bench.py --gpus N` starts the N ranks itself (one child process per GPU, before anything
+touches the GPU in the parent); under torchrun (WORLD_SIZE set) it is one of the ranks and checks N against the world size.
 """
-import argparse, json, os, sys, time
-import numpy as np
+import argparse, hashlib, json, os, subprocess, sys, time
 
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
+sys.path.insert(0, os.path.join(REPO, "tools"))
 
 FLOP_PER_SITE = 1920          # reference model, src/init_generic.c:59,61
 BYTES_PER_SITE_F32 = 816      # 4 B x (24 in + 24 out + 72 links + 84 clover reals), SURVEY.md 8(d)
 HBM_PEAK_GBS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+GAUGE_SEED, GAUGE_EPS = 20260101, 0.35   # near-unit links exp(i eps H): a system on which the multigrid has work to do
 
 
-def synth_gauge(V, seed):
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=None)
+    ap.add_argument("--steps", type=int, default=1000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--lattice", type=int, nargs=4, default=[32, 32, 32, 32], help="local lattice per GPU of the headline measurement")
+    ap.add_argument("--strong-lattice", type=int, nargs=4, default=[64, 64, 64, 64],
+                    help="global lattice of the strong-scaling solve (BASELINE configs[4]); every extent a multiple of 8 x the process grid")
+    ap.add_argument("--precision", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-solve", action="store_true", help="skip the 32^4 two-level solve (N = 1)")
+    ap.add_argument("--no-strong", action="store_true", help="skip the strong-scaling solve")
+    ap.add_argument("--small-lattice", action="store_true",
+                    help="also time BASELINE configs[1] (the reference's 8^4 configuration, cache-resident)")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
+                    help="halo transport for N > 1; 'host' (gloo, staged through pinned memory) lets several processes share one "
+                         "card for a rehearsal and is never the reported configuration")
+    ap.add_argument("--self-exchange", default=None,
+                    help="single GPU only, e.g. -1,-1,-1,1: run the fine operator through the multi-GPU machinery with the process "
+                         "as its own neighbour in the directions marked -1 (RCCL transport); not a reported configuration")
+    ap.add_argument("--leg-timeout", type=float, default=900.0, help="watchdog for the solve legs on N > 1 (seconds)")
+    return ap.parse_args()
+
+
+# ---- N > 1 without a launcher: the parent only starts and reaps the ranks ------------------------------------------
+def spawn_ranks(n):
+    """one child process per GPU; the parent imports neither torch nor the library and never touches a GPU"""
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    deadline = time.time() + 3300
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            c = p.poll()
+            if c is None:
+                continue
+            live.remove(p)
+            if c != 0 and rc == 0:
+                rc = c if c > 0 else 1
+        if (rc != 0 or time.time() > deadline) and live:
+            # a rank failed (or the job overran): the others would wait in a collective for ever
+            for p in live:
+                p.terminate()
+            t_end = time.time() + 10
+            for p in live:
+                try:
+                    p.wait(timeout=max(0.1, t_end - time.time()))
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            if rc == 0:
+                rc = 3
+            break
+    return rc
+
+
+# ---- inputs ---------------------------------------------------------------------------------------------------------
+def synth_gauge_random(V, seed):
+    """random SU(3) links of the headline measurement (conftest.random_su3, numpy)"""
+    import numpy as np
     from conftest import random_su3
     out = np.empty((V, 4, 9, 2))
     chunk = 1 << 18
@@ -38,7 +110,8 @@ def synth_gauge(V, seed):
 
 
 def near_unit_gauge(V, eps, seed):
-    """SU(3) links exp(i eps H) with Gaussian Hermitian traceless H (smooth, solvable at m0 ~ -0.1...-0.5)"""
+    """SU(3) links exp(i eps H) with Gaussian Hermitian traceless H (numpy form, kept for the golden-fixture generators)"""
+    import numpy as np
     rng = np.random.default_rng(seed)
     n = V * 4
     a = rng.standard_normal((n, 3, 3)) + 1j * rng.standard_normal((n, 3, 3))
@@ -51,46 +124,49 @@ def near_unit_gauge(V, eps, seed):
 
 
 def write_conf(path, L, U, plaq):
-    """gauge file in the reference's format (src/io.c:489-520): 4 x int32 (T,Z,Y,X), double plaquette, links"""
-    with open(path, "wb") as f:
-        f.write(np.asarray(L, dtype="<i4").tobytes()); f.write(np.asarray([plaq], dtype="<f8").tobytes())
-        f.write(np.ascontiguousarray(U, dtype="<f8").tobytes())
+    import synth
+    synth.write_conf(path, L, U, plaq)
 
 
-def cpu_baseline_reference(threads):
-    """the REAL reference (oracle/_ref/dd_alpha_amg_sse, SSE build) on a bounded sample: pure GMRES
-    (method 0, mixed precision 2) on a 16^4 random-gauge lattice; the fp32 d_plus_clover time is read from
-    the reference's own profiling counters (self coupling + neighbor coupling, src/init_generic.c:58-61)"""
-    import subprocess, tempfile, re
+# ---- CPU baseline: the real reference on this box's host cores -------------------------------------------------------
+def _run_reference(ini_text, tmp, timeout):
     exe = os.path.join(REPO, "oracle", "_ref", "dd_alpha_amg_sse")
-    if not os.path.exists(exe):
+    open(os.path.join(tmp, "b.ini"), "w").write(ini_text)
+    return subprocess.run([exe, os.path.join(tmp, "b.ini")], capture_output=True, text=True, timeout=timeout, cwd=tmp).stdout
+
+
+def cpu_baseline_reference(threads, L=(32, 32, 32, 32)):
+    """the REAL reference (oracle/_ref/dd_alpha_amg_sse) on the headline volume: pure GMRES (method 0, mixed precision 2),
+    one restart cycle of 25 on the same near-unit gauge field as the solve leg; the fp32 d_plus_clover time is read from the
+    reference's own profiling counters (self coupling + neighbor coupling, src/init_generic.c:58-61)"""
+    import re, tempfile, shutil
+    import numpy as np
+    import synth
+    if not os.path.exists(os.path.join(REPO, "oracle", "_ref", "dd_alpha_amg_sse")):
         return None
-    Lr = [16, 16, 16, 16]; Vr = int(np.prod(Lr))
+    Lr = list(L); Vr = int(np.prod(Lr)); Ls = " ".join(map(str, Lr))
     tmp = tempfile.mkdtemp(prefix="ddamg_cpu_")
     try:
-        U = synth_gauge(Vr, 777)
-        write_conf(os.path.join(tmp, "conf"), Lr, U, 0.0)
-        ini = f"""configuration: {tmp}/conf
+        synth.write_conf(os.path.join(tmp, "conf"), Lr, synth.synth_gauge(Lr, GAUGE_EPS, GAUGE_SEED), 0.0)
+        out = _run_reference(f"""configuration: {tmp}/conf
 format: 0
 right hand side: 0
 antiperiodic boundary conditions: 1
 number of levels: 1
 number of openmp threads: {threads}
-d0 global lattice: 16 16 16 16
-d0 local lattice: 16 16 16 16
+d0 global lattice: {Ls}
+d0 local lattice: {Ls}
 d0 block lattice: 4 4 4 4
 m0: -0.1
 csw: 1.0
 tolerance for relative residual: 1E-30
-iterations between restarts: 50
-maximum of restarts: 4
+iterations between restarts: 25
+maximum of restarts: 1
 print mode: 1
 method: 0
 mixed precision: 2
 randomize test vectors: 0
-"""
-        open(os.path.join(tmp, "b.ini"), "w").write(ini)
-        out = subprocess.run([exe, os.path.join(tmp, "b.ini")], capture_output=True, text=True, timeout=240, cwd=tmp).stdout
+""", tmp, 400)
         m1 = re.search(r"self coupling, float:\s*([0-9.e+-]+)\(\s*(\d+)\)", out)
         m2 = re.search(r"neighbor coupling, float:\s*([0-9.e+-]+)\(\s*(\d+)\)", out)
         if not (m1 and m2):
@@ -98,45 +174,127 @@ randomize test vectors: 0
         t = float(m1.group(1)) + float(m2.group(1)); n = int(m2.group(2))
         return {"value": FLOP_PER_SITE * Vr * n / t / 1e9, "unit": "GFLOP/s", "cores": threads, "kind": "reference",
                 "sample": f"{n} d_plus_clover_float applies inside the reference's pure-GMRES run (SSE build, {threads} OpenMP threads, "
-                          f"16^4 random gauge), {t / n * 1e3:.2f} ms/apply from its own profiling counters"}
+                          f"{'x'.join(map(str, Lr))} lattice = the headline volume), {t / n * 1e3:.2f} ms/apply from its own profiling counters"}
     except Exception:
         return None
     finally:
-        import shutil
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def cpu_baseline_solve(threads):
+    """the reference's FGMRES+AMG solve beside ours: a bounded live sample (16^4, same parameters and gauge generator as the
+    solve leg, 1/16 of its volume) on this box's cores, and the committed full-size run (tests/golden/ref_32x32_2lvl.json:
+    the same 32^4 gauge field as the `solve` leg, run in the build container by oracle/run_reference_big.py)"""
+    import re, tempfile, shutil
+    import synth
+    out = {}
+    try:
+        g = json.load(open(os.path.join(REPO, "tests", "golden", "ref_32x32_2lvl.json")))
+        out["reference_32"] = {"seconds": g["solve_seconds"], "iterations": g["iterations"], "setup_seconds": sum(g["setup_seconds"]),
+                               "cores": g["threads"], "kind": "reference", "where": "build container, " + g["host"],
+                               "true_relres": g["true_relres"]}
+    except Exception:
+        pass
+    if not os.path.exists(os.path.join(REPO, "oracle", "_ref", "dd_alpha_amg_sse")):
+        return out or None
+    tmp = tempfile.mkdtemp(prefix="ddamg_cpu_")
+    try:
+        Lr = [16] * 4
+        synth.write_conf(os.path.join(tmp, "conf"), Lr, synth.synth_gauge(Lr, GAUGE_EPS, GAUGE_SEED), 0.0)
+        t0 = time.time()
+        log = _run_reference(f"""configuration: {tmp}/conf
+format: 0
+right hand side: 0
+antiperiodic boundary conditions: 1
+number of levels: 2
+number of openmp threads: {threads}
+d0 global lattice: 16 16 16 16
+d0 local lattice: 16 16 16 16
+d0 block lattice: 4 4 4 4
+d0 post smooth iter: 2
+d0 block iter: 4
+d0 test vectors: 24
+d0 setup iter: 4
+d1 global lattice: 4 4 4 4
+d1 local lattice: 4 4 4 4
+m0: -0.3
+csw: 1.0
+tolerance for relative residual: 1E-10
+iterations between restarts: 50
+maximum of restarts: 20
+coarse grid tolerance: 5E-2
+coarse grid iterations: 100
+coarse grid restarts: 5
+print mode: 1
+method: 2
+odd even preconditioning: 1
+mixed precision: 1
+randomize test vectors: 0
+""", tmp, 600)
+        wall = time.time() - t0
+        it = re.search(r"FGMRES iterations:\s*(\d+)", log)
+        ts = re.findall(r"elapsed wall clock time:\s*([0-9.]+)\s+seconds", log)
+        st = re.findall(r"elapsed time: ([0-9.]+) seconds", log)
+        if it and ts:
+            out.update({"seconds": float(ts[-1]), "iterations": int(it.group(1)), "setup_seconds": sum(float(x) for x in st),
+                        "cores": threads, "kind": "reference",
+                        "sample": f"16^4 lattice (1/16 of the solve leg's volume), same generator, parameters and right-hand side; "
+                                  f"SSE build, {threads} OpenMP threads, {wall:.1f} s wall for setup + solve"})
+    except Exception as e:
+        out["error"] = str(e)[:200]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return out or None
+
+
 def cpu_baseline(L, D, cl, phi, budget_s=12.0):
-    """CPU baseline on the host cores of this box: the real reference when oracle/_ref runs here, else the
-    oracle port (bounded sample of the same workload)"""
+    """CPU baseline on the host cores of this box: the real reference when oracle/_ref runs here, else the oracle port"""
+    import numpy as np
     from oracle import orc
-    ref = cpu_baseline_reference(orc.host_threads())
-    if ref is not None:
-        return ref
-    t1, nt = orc.dirac_time_f32(L, D, cl, phi, 1)
-    reps = int(max(2, min(200, budget_s / max(t1, 1e-4))))
-    t, nt = orc.dirac_time_f32(L, D, cl, phi, reps)
-    V = int(np.prod(L))
-    return {"value": FLOP_PER_SITE * V / t / 1e9, "unit": "GFLOP/s", "cores": nt, "kind": "port",
-            "sample": f"{reps} fp32 applies of the same {'x'.join(map(str, L))} operator, OpenMP over sites, "
-                      f"{t*1e3:.2f} ms/apply"}
+    threads = orc.host_threads()
+    ref = cpu_baseline_reference(threads, L) if all(x % 4 == 0 for x in L) else None
+    if ref is None:
+        t1, nt = orc.dirac_time_f32(L, D, cl, phi, 1)
+        reps = int(max(2, min(200, budget_s / max(t1, 1e-4))))
+        t, nt = orc.dirac_time_f32(L, D, cl, phi, reps)
+        V = int(np.prod(L))
+        ref = {"value": FLOP_PER_SITE * V / t / 1e9, "unit": "GFLOP/s", "cores": nt, "kind": "port",
+               "sample": f"{reps} fp32 applies of the same {'x'.join(map(str, L))} operator, OpenMP over sites, {t*1e3:.2f} ms/apply"}
+    return ref
+
+
+# ---- roofline.traffic: a measured constant with its provenance --------------------------------------------------------
+def kernel_source_hash():
+    h = hashlib.sha256()
+    for f in ("fine_op.hip", "dirac_device.h", "common.h"):
+        h.update(open(os.path.join(REPO, "ddalphaamg_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def pmc_traffic(precision):
-    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes
-    (profiles/r01_traffic.json: 2*FETCH_SIZE + WRITE_SIZE, calibrated as MI355X_MICROARCH.md prescribes);
-    measured on this same workload (32^4 fp32), None for any other"""
-    try:
-        d = json.load(open(os.path.join(REPO, "profiles", "r01_traffic.json")))
-        return d["dirac_apply_lds_kernel<float>"]["bytes_per_launch"] if precision == 32 else None
-    except Exception:
-        return None
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (2*FETCH_SIZE + WRITE_SIZE,
+    calibrated as MI355X_MICROARCH.md prescribes).  The file records the hash of the kernel sources it was measured on; when
+    the kernel has changed since, the number is stale and null is reported instead."""
+    for name in ("r02_traffic.json", "r01_traffic.json"):
+        try:
+            d = json.load(open(os.path.join(REPO, "profiles", name)))
+            e = d["dirac_apply_lds_kernel<float>"]
+            if precision != 32:
+                return None, None
+            src = d.get("kernel_source_sha16")
+            if src is not None and src != kernel_source_hash():
+                return None, f"profiles/{name} was measured on kernel sources {src}, current {kernel_source_hash()}"
+            return e["bytes_per_launch"], f"profiles/{name}, commit {d.get('commit', 'unrecorded')}, kernel sources {src or 'unrecorded'}"
+        except Exception:
+            continue
+    return None, None
 
 
 def small_lattice_leg(device):
     """BASELINE configs[1]: the reference's own 8^4 sample configuration (gauge field from tests/golden), fine operator
     only, fp32, 1000 timed applies after 50 warm-ups.  Its 3 MB working set lives in the caches, so it is reported
     next to the headline and not used for the HBM roofline."""
+    import numpy as np
     import ddalphaamg_amd as dd
     from ddalphaamg_amd import api
     g = np.load(os.path.join(REPO, "tests", "golden", "ref_8x8_dirac.npz"))
@@ -160,69 +318,91 @@ def small_lattice_leg(device):
             "rel_err_vs_reference_output": err}
 
 
-def solve_leg(ctx_params, U, V, L, world=1, rank=0, transport="rccl", group=None):
-    """secondary measurement: two-level FGMRES+AMG solve (BASELINE config 3) on the same gauge field; on N GPUs the
-    global lattice is N times larger (process grid as in the headline measurement), operator as described there"""
+# ---- solve legs ---------------------------------------------------------------------------------------------------------
+def amg_params(api, Lloc, levels, device):
+    q = api.default_params(); q.num_levels = levels
+    for mu in range(4):
+        q.local_lattice[0][mu] = Lloc[mu]; q.block_lattice[0][mu] = 4; q.local_lattice[1][mu] = Lloc[mu] // 4
+        if levels == 3:
+            q.block_lattice[1][mu] = 2; q.local_lattice[2][mu] = Lloc[mu] // 8
+    q.num_vect[0] = 24; q.post_smooth_iter[0] = 2; q.block_iter[0] = 4; q.setup_iter[0] = 4
+    q.num_vect[1] = 28; q.post_smooth_iter[1] = 2; q.block_iter[1] = 4; q.setup_iter[1] = 2
+    q.restart, q.max_restart, q.tol = 50, 20, 1e-10
+    q.coarse_iter, q.coarse_restart, q.coarse_tol = 100, 5, 5e-2
+    q.mixed_precision, q.method, q.odd_even = 1, 2, 1
+    q.m0, q.csw, q.device = -0.3, 1.0, device
+    q.test_vector_rng, q.rng_seed = 1, 20260101     # device generator for the random test vectors
+    return q
+
+
+def run_solve(q, G, grid, coords, world, rank, transport, group):
+    """set-up + solve of one decomposed (or undivided) lattice: global lattice G over `grid`, this process at `coords`"""
+    import numpy as np
+    import synth
     import ddalphaamg_amd as dd
-    p = ctx_params
-    if world == 1:
-        ctx = dd.Context(p)
-        ctx.set_gauge(U, anti_pbc=True)
-    else:
+    for mu in range(4):
+        q.process_grid[mu] = grid[mu]; q.process_coords[mu] = coords[mu]
+    V = int(np.prod([G[mu] // grid[mu] for mu in range(4)]))
+    t0 = time.perf_counter()
+    U = synth.synth_gauge(G, GAUGE_EPS, GAUGE_SEED, grid, coords)
+    t_gauge = time.perf_counter() - t0
+    ctx = dd.Context(q)
+    if world > 1:
         from ddalphaamg_amd import dist as ddist
-        grid = ddist.process_grid_for(world); coords = ddist.coords_of(rank, grid)
-        for mu in range(4):
-            p.process_grid[mu] = grid[mu]; p.process_coords[mu] = coords[mu]
-        ctx = dd.Context(p)
         ddist.attach_host(ctx, group)
-        ctx.set_gauge(U, anti_pbc=True)     # global clover term: neighbours' links over the host transport
-        if transport == "rccl":
-            ddist.attach_rccl(ctx, rank)
-    t0 = time.perf_counter(); ctx.setup(p.setup_iter[0]); ctx.sync(); t_setup = time.perf_counter() - t0
+    ctx.set_gauge(U, anti_pbc=True)     # global clover term: on a process grid the neighbours' links travel over the host transport
+    del U
+    if world > 1 and transport == "rccl":
+        ddist.attach_rccl(ctx, rank)
+    t0 = time.perf_counter(); ctx.setup(q.setup_iter[0]); ctx.sync(); t_setup = time.perf_counter() - t0
     b = np.zeros((V, 12, 2)); b[..., 0] = 1.0
-    x, it, cit, rr = ctx.solve(b, 1e-10)
-    t0 = time.perf_counter(); x, it, cit, rr = ctx.solve(b, 1e-10, out=x); t_host = time.perf_counter() - t0   # host arrays of a caller that keeps its vectors
     bv = ctx.vector(0, 64).upload(b); xv = ctx.vector(0, 64)
-    ctx.solve_vec(xv, bv, 1e-10)
+    ctx.solve_vec(xv, bv, 1e-10)                                    # warm-up
     t0 = time.perf_counter(); it, cit, rr = ctx.solve_vec(xv, bv, 1e-10); t_solve = time.perf_counter() - t0
+    res = {"seconds_per_solve": t_solve, "setup_seconds": t_setup, "iterations": it, "coarse_iterations": cit, "true_relres": rr,
+           "gauge_generation_seconds": t_gauge}
+    if world == 1:
+        x, it2, _, _ = ctx.solve(b, 1e-10)
+        t0 = time.perf_counter(); ctx.solve(b, 1e-10, out=x); res["seconds_per_solve_host_vectors"] = time.perf_counter() - t0
     ctx.close()
-    return {"workload": f"{'x'.join(map(str, L))} per GPU x {world} GPU(s), near-unit gauge exp(0.35 i H), m0 -0.3, 2-level AMG (4^4 blocks/aggregates, Nvec 24, SAP 2x4, coarse tol 5e-2), "
-                        "FGMRES(50) to 1e-10, rhs=ones",
-            "seconds_per_solve": t_solve, "seconds_per_solve_host_vectors": t_host, "setup_seconds": t_setup, "iterations": it, "coarse_iterations": cit, "true_relres": rr}
+    return res
+
+
+def committed_n1_strong(G):
+    """seconds per solve of the strong-scaling configuration on ONE GPU, measured by the build on its own MI355X box and
+    committed with its provenance (profiles/r02_strong_scaling_n1.json): the denominator of `speedup_vs_n1` on N > 1"""
+    try:
+        d = json.load(open(os.path.join(REPO, "profiles", "r02_strong_scaling_n1.json")))
+        if list(d["global_lattice"]) == list(G):
+            return d
+    except Exception:
+        pass
+    return None
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)
-    ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--lattice", type=int, nargs=4, default=[32, 32, 32, 32])
-    ap.add_argument("--global-lattice", type=int, nargs=4, default=None,
-                    help="strong scaling: fixed global lattice divided over the process grid (overrides --lattice, which is "
-                         "the per-GPU lattice of the default weak-scaling run)")
-    ap.add_argument("--precision", type=int, default=32)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-solve", action="store_true")
-    ap.add_argument("--small-lattice", action="store_true",
-                    help="also time BASELINE configs[1] (the reference's 8^4 configuration, cache-resident); off by default so that "
-                         "a kernel profile of the default run holds only launches of the headline workload")
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
-                    help="halo transport for --gpus > 1; 'host' (gloo, staged through pinned memory) lets several "
-                         "processes share one card for a rehearsal and is never the reported configuration")
-    ap.add_argument("--self-exchange", default=None,
-                    help="single GPU only, e.g. -1,-1,-1,1: run the fine operator through the multi-GPU machinery with the process "
-                         "as its own neighbour in the directions marked -1 (RCCL transport): cost of pack + exchange + "
-                         "interior/boundary split, not a reported configuration")
-    args = ap.parse_args()
+    args = parse_args()
+    env_world = os.environ.get("WORLD_SIZE")
+    if args.gpus is None:
+        args.gpus = int(env_world) if env_world else 1
+    if args.gpus > 1 and env_world is None:
+        sys.exit(spawn_ranks(args.gpus))     # nothing below runs in the parent
 
+    import numpy as np
     import torch
     rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    world = int(env_world or "1")
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    gloo = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.transport == "rccl":
+            if torch.cuda.device_count() < world:
+                raise SystemExit(f"bench.py: {world} ranks over RCCL need {world} GPUs, {torch.cuda.device_count()} visible "
+                                 "(use --transport host to rehearse on fewer)")
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend="gloo")
@@ -231,24 +411,19 @@ def main():
 
     import ddalphaamg_amd as dd
     from ddalphaamg_amd import api
+    from ddalphaamg_amd import dist as ddist
     from conftest import splitmix_uniform
 
-    strong = args.global_lattice is not None
-    if strong:
-        from ddalphaamg_amd import dist as _d
-        _g = _d.process_grid_for(world)
-        if any(args.global_lattice[mu] % (_g[mu] * 8) for mu in range(4)):
-            raise SystemExit("--global-lattice: every extent must be a multiple of 8 x the process grid " + str(_g))
-        args.lattice = [args.global_lattice[mu] // _g[mu] for mu in range(4)]
     L = list(args.lattice); V = int(np.prod(L))
     p = api.default_params()
     p.num_levels = 1
     for mu in range(4):
         p.local_lattice[0][mu] = L[mu]; p.block_lattice[0][mu] = 4
     p.m0, p.csw, p.device = -0.1, 1.0, local_rank
-    U = synth_gauge(V, 20260101 + rank)
+    U = synth_gauge_random(V, 20260101 + rank)
     phi = splitmix_uniform(V * 24, 1234 + rank).reshape(V, 12, 2)
     halo_check = None
+    grid = ddist.process_grid_for(world); coords = ddist.coords_of(rank, grid)
     if world == 1:
         if args.self_exchange:
             for mu, v in enumerate(int(x) for x in args.self_exchange.split(",")):
@@ -257,20 +432,17 @@ def main():
         if args.self_exchange:
             ctx.comm_init_rccl(api.rccl_unique_id())
         ctx.set_gauge(U, anti_pbc=True)
-        grid = [1, 1, 1, 1]
     else:
-        # domain decomposition: one process per GPU on a Cartesian grid, `--lattice` sites per GPU (weak
-        # scaling), halo exchange over RCCL.  Every process draws the random links of its own part; the clover
-        # term is built on the global field (neighbours' links fetched over the host transport).
-        from ddalphaamg_amd import dist as ddist
-        grid = ddist.process_grid_for(world)
-        coords = ddist.coords_of(rank, grid)
+        # domain decomposition: one process per GPU on a Cartesian grid, `--lattice` sites per GPU, halo exchange over
+        # RCCL.  Every process draws the random links of its own part; the clover term is built on the global field
+        # (neighbours' links fetched over the host transport).
         for mu in range(4):
             p.process_grid[mu] = grid[mu]; p.process_coords[mu] = coords[mu]
         ctx = dd.Context(p)
         gloo = dist.new_group(backend="gloo")
         ddist.attach_host(ctx, gloo)
         ctx.set_gauge(U, anti_pbc=True)
+    del U
     x = ctx.vector(0, args.precision).upload(phi)
     y = ctx.vector(0, args.precision)
     if world > 1:
@@ -304,73 +476,126 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    out = None
     if rank == 0:
         bytes_site = BYTES_PER_SITE_F32 * (args.precision // 32)
         launch_s = ev_ms * 1e-3 / args.steps
         achieved = bytes_site * V / launch_s / 1e9
+        traffic, traffic_src = pmc_traffic(args.precision)
         out = {
             "metric": "fine_wilson_clover_gflops", "value": FLOP_PER_SITE * V * world * args.steps / dt / 1e9,
             "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": f"f{args.precision}", "data": "synthetic",
             "config": {"workload": f"fine Wilson-Clover apply (d_plus_clover), {'x'.join(map(str, L))} local lattice per GPU, "
                                    "random SU(3) gauge, csw=1.0, anti-periodic T",
                        "flop_per_site": FLOP_PER_SITE,
                        "parallelism": ("domain decomposition, process grid " + "x".join(map(str, grid)) + " (T,Z,Y,X), " + args.transport.upper() + " halo exchange "
                                        "overlapped with the interior tiles") if world > 1 else ("single" if not args.self_exchange else "single GPU, self-exchange " + args.self_exchange + " through RCCL"),
-                       "halo_check_vs_host_transport": halo_check},
+                       "ranks": world, "halo_check_vs_host_transport": halo_check},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(args.precision),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "dirac_apply_lds_kernel<float>" if args.precision == 32 else "dirac_apply_lds_kernel<double>", "us_per_launch": launch_s * 1e6,
                          "algorithmic_bytes_per_site": bytes_site},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:   # "on rank 0 at N=1 only"
             D, cl = ctx.get_operator()
-            if world == 1:   # "on rank 0 at N=1 only"
-                out["cpu_baseline"] = cpu_baseline(L, D, cl, phi)
+            out["cpu_baseline"] = cpu_baseline(L, D, cl, phi)
+            del D, cl
         if world == 1 and not args.self_exchange and args.small_lattice:
             try:
                 out["small_lattice"] = small_lattice_leg(local_rank)
             except Exception as e:
                 out["small_lattice"] = {"error": str(e)[:200]}
     ctx.close()
-    if not args.no_solve and all(x % 8 == 0 for x in L):
-        q = api.default_params(); q.num_levels = 2
-        for mu in range(4):
-            q.local_lattice[0][mu] = L[mu]; q.block_lattice[0][mu] = 4; q.local_lattice[1][mu] = L[mu] // 4
-        q.num_vect[0] = 24; q.post_smooth_iter[0] = 2; q.block_iter[0] = 4; q.setup_iter[0] = 4
-        q.restart, q.max_restart, q.tol = 50, 20, 1e-10
-        q.coarse_iter, q.coarse_restart, q.coarse_tol = 100, 5, 5e-2
-        q.mixed_precision, q.method, q.odd_even = 1, 2, 1
-        q.m0, q.csw, q.device = -0.3, 1.0, local_rank
-        q.test_vector_rng, q.rng_seed = 1, 20260101     # device generator for the random test vectors
-        U = near_unit_gauge(V, 0.35, 20260101 + rank)   # smooth links: a system on which the multigrid has work to do
-        # the headline number must survive the secondary leg: an exception is recorded, and on several GPUs a
-        # watchdog prints the headline line and ends the process if the leg does not come back (a process that
-        # failed alone would leave the others waiting in a collective)
-        import threading
+    del phi
 
-        def give_up():
+    # ---- the solve legs: the headline line must survive them.  On several GPUs a watchdog prints the headline with the
+    # failure recorded and ends the process with a NON-ZERO code if a leg does not come back (a rank that failed alone would
+    # leave the others waiting in a collective); an exception on one rank does the same.
+    failed = False
+    die_lock = __import__("threading").Lock()
+
+    def emit_and_die(msg):
+        with die_lock:      # first caller wins; the process ends inside
             if rank == 0:
-                out["solve"] = {"error": "distributed solve leg did not finish within 400 s"}
+                out.setdefault("strong_scaling", {})["error"] = msg
                 print(json.dumps(out), flush=True)
-            os._exit(0)
-        dog = threading.Timer(400.0, give_up) if world > 1 else None
-        if dog:
+            os._exit(3)
+
+    if world > 1:
+        # a launcher that lost another rank sends SIGTERM (torchrun, or spawn_ranks above).  The main thread may sit in a
+        # collective inside the library and never return to the interpreter, so the signal is picked up through the wake-up
+        # descriptor by a thread of its own: rank 0 still prints the headline, every rank ends non-zero.
+        import signal, socket, threading
+        rs, ws = socket.socketpair(); ws.setblocking(False)
+        signal.signal(signal.SIGTERM, lambda *_: None)
+        signal.set_wakeup_fd(ws.fileno())
+
+        def on_signal():
+            rs.recv(1)
+            emit_and_die("terminated by the launcher: another rank failed or the job overran")
+        threading.Thread(target=on_signal, daemon=True).start()
+
+    if world == 1 and not args.no_solve and not args.self_exchange and all(v % 8 == 0 for v in L):
+        try:
+            res = run_solve(amg_params(api, L, 2, local_rank), L, [1, 1, 1, 1], [0, 0, 0, 0], 1, 0, args.transport, None)
+            res["workload"] = (f"{'x'.join(map(str, L))}, near-unit gauge exp({GAUGE_EPS} i H) seed {GAUGE_SEED} (tools/synth_gauge.c), m0 -0.3, 2-level AMG "
+                               "(4^4 blocks/aggregates, Nvec 24, SAP 2x4, coarse tol 5e-2), FGMRES(50) to 1e-10, rhs=ones (BASELINE configs[2])")
+            if not args.no_cpu_baseline:
+                cb = cpu_baseline_solve(out["cpu_baseline"]["cores"] if out.get("cpu_baseline") else (os.cpu_count() or 1))
+                if cb:
+                    if not isinstance(out.get("cpu_baseline"), dict):
+                        out["cpu_baseline"] = {}
+                    out["cpu_baseline"]["solve"] = cb
+                    if "reference_32" in cb and L == [32, 32, 32, 32]:
+                        res["iterations_reference"] = cb["reference_32"]["iterations"]
+                        res["speedup_vs_reference_32"] = cb["reference_32"]["seconds"] / res["seconds_per_solve"]
+            out["solve"] = res
+        except Exception as e:
+            out["solve"] = {"error": str(e)[:300]}
+
+    G = list(args.strong_lattice)
+    if not args.no_strong and not args.self_exchange:
+        if any(G[mu] % (grid[mu] * 8) for mu in range(4)):
+            raise SystemExit("--strong-lattice: every extent must be a multiple of 8 x the process grid " + str(grid))
+        import threading
+        dog = None
+        if world > 1:
+            dog = threading.Timer(args.leg_timeout, emit_and_die, args=(f"strong-scaling leg did not finish within {args.leg_timeout:.0f} s",))
             dog.daemon = True; dog.start()
         try:
-            res = solve_leg(q, U, V, L, world, rank, args.transport, gloo if world > 1 else None)
+            Lloc = [G[mu] // grid[mu] for mu in range(4)]
+            res = run_solve(amg_params(api, Lloc, 3, local_rank), G, grid, coords, world, rank, args.transport, gloo)
+            if world > 1:
+                t = torch.tensor([res["seconds_per_solve"]], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX, group=gloo)
+                res["seconds_per_solve"] = float(t.item())
+            res["workload"] = (f"ONE global {'x'.join(map(str, G))} lattice over the process grid {'x'.join(map(str, grid))} (T,Z,Y,X), local "
+                               f"{'x'.join(map(str, Lloc))}; near-unit gauge exp({GAUGE_EPS} i H) seed {GAUGE_SEED}, m0 -0.3, csw 1, 3-level AMG (4^4 then 2^4 "
+                               "aggregates, Nvec 24/28, SAP 2x4 on both smoothing levels, K-cycle 5/2/0.1, coarsest odd-even GMRES to 5e-2), "
+                               "fp64 FGMRES(50) to 1e-10 with the fp32 V-cycle, rhs=ones (BASELINE configs[4])")
+            res["scaling"] = "strong"; res["n_gpus"] = world; res["transport"] = args.transport if world > 1 else None
+            n1 = committed_n1_strong(G)
+            if n1:
+                res["n1_seconds_per_solve"] = n1["seconds_per_solve"]; res["n1_source"] = n1.get("source")
+                res["speedup_vs_n1"] = n1["seconds_per_solve"] / res["seconds_per_solve"]
+            if rank == 0:
+                out["strong_scaling"] = res
         except Exception as e:
-            res = {"error": str(e)[:200]}
+            failed = True
+            if world > 1:
+                emit_and_die(f"rank {rank}: {str(e)[:300]}")
+            out["strong_scaling"] = {"error": str(e)[:300]}
         if dog:
             dog.cancel()
-        if rank == 0:
-            out["solve"] = res
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

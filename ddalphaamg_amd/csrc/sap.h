@@ -52,7 +52,18 @@ class SapSmoother {
   int* d_block_list_ = nullptr;
   std::vector<int*> d_color_blocks_;               // block indices per colour
   T* latest2_ = nullptr;                           // additive method: the other generation of block updates
-  void launch(int color, int mode_default, unsigned skip_mask, const T* eta, hipStream_t st);
+  // production shape (fp32, 4^4 blocks, multiplicative schedules): two blocks per workgroup, block-boundary couplings through
+  // face buffers (sap_pair.h).  faces_d_: projected faces of every block's latest update; faces_x_: of the iterate x
+  bool pair_ = false;
+  float4 *faces_d_ = nullptr, *faces_x_ = nullptr;
+  unsigned char* d_frank_ = nullptr;
+  const int* d_block_nb_ = nullptr;                // FineOp's [8][num_blocks] table
+  int* d_block_nb_own_ = nullptr;
+  std::vector<int*> d_other_blocks_;               // red-black: blocks of the other colour (their x faces feed the first full residual)
+  std::vector<int> n_other_blocks_;
+  int* d_all_blocks_ = nullptr;
+  // face_in: 0 none, 1 faces_d_, 2 faces_x_;  face_out bit 0: write faces_d_, bit 1: write faces_x_
+  void launch(int color, int mode_default, unsigned skip_mask, const T* eta, hipStream_t st, int face_out = 1);
 };
 
 }  // namespace ddamg

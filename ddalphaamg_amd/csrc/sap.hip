@@ -3,14 +3,15 @@
 // pairs for its temporaries and tips this kernel into heavy spilling, so it stays scalar here
 #define DDAMG_PK 0
 #include "sap.h"
+#include "sap_pair.h"
+#include "sap_modes.h"
 #include "dirac_device.h"
 #include "blas.h"
 #include "krylov.h"
 #include <vector>
+#include <algorithm>
 
 namespace ddamg {
-
-enum { MODE_NONE = 0, MODE_NBOUNDARY = 1, MODE_FULLRES = 2 };
 
 template <typename T>
 struct SapArgs {
@@ -563,6 +564,9 @@ __global__ __launch_bounds__((BS < 64 ? 64 : BS), (sizeof(T) == 4 ? 2 : 1)) void
 #undef DDAMG_EMIT
 #undef DDAMG_COLLECT
 
+static int g_sap_variant = -1;  // 1: site-pair kernel, 2: thread-per-site kernel with resident operator, 3 (default): two blocks per
+                                // workgroup + face buffers where the shape allows (fp32, 4^4 blocks), else 2
+
 template <typename T>
 SapSmoother<T>::~SapSmoother() {
   if (r) (void)hipFree(r);
@@ -572,6 +576,12 @@ SapSmoother<T>::~SapSmoother() {
   if (d_blk_nb_) (void)hipFree(d_blk_nb_);
   if (d_block_list_) (void)hipFree(d_block_list_);
   for (int* p : d_color_blocks_) if (p) (void)hipFree(p);
+  for (int* p : d_other_blocks_) if (p) (void)hipFree(p);
+  if (faces_d_) (void)hipFree(faces_d_);
+  if (faces_x_) (void)hipFree(faces_x_);
+  if (d_frank_) (void)hipFree(d_frank_);
+  if (d_block_nb_own_) (void)hipFree(d_block_nb_own_);
+  if (d_all_blocks_) (void)hipFree(d_all_blocks_);
 }
 
 template <typename T>
@@ -622,14 +632,52 @@ void SapSmoother<T>::setup(const Geometry& g, const FineOp<T>* op, int block_ite
     DDAMG_HIP_CHECK(device_alloc(&d_color_blocks_[c], sizeof(int) * ncol_[c]));
     DDAMG_HIP_CHECK(hipMemcpyAsync(d_color_blocks_[c], cb[c].data(), sizeof(int) * ncol_[c], hipMemcpyHostToDevice, st));
   }
+  // production shape: paired-block kernel with face buffers (sap_pair.hip)
+  if (g_sap_variant < 0) { const char* e = getenv("DDAMG_SAP_VARIANT"); g_sap_variant = e ? atoi(e) : 3; }
+  pair_ = sizeof(T) == 4 && BS_ == 256 && schedule_ != ADDITIVE && g_sap_variant == 3;
+  for (int mu = 0; mu < 4 && pair_; mu++) if (g.B[mu] != 4) pair_ = false;
+  if (pair_) {
+    // rank of every block site among the sites of its parity class on its face, in transverse lexicographic order: the
+    // site across a block face has the other parity class and the same rank
+    std::vector<unsigned char> fr((size_t)4 * BS_ / 4 * 4, 0);
+    std::vector<unsigned> packed(BS_, 0);
+    for (int mu = 0; mu < 4; mu++)
+      for (int plane = 0; plane < g.B[mu]; plane += g.B[mu] - 1)
+        for (int cls = 0; cls < 2; cls++) {
+          std::vector<std::pair<int, int>> on;   // (transverse lexicographic index, block site)
+          for (int i = cls * HS_; i < (cls + 1) * HS_; i++) {
+            const int* c = &g.coord[(size_t)i * 4];   // block 0 starts at the origin: local == block coordinates
+            if (c[mu] != plane) continue;
+            int t = 0;
+            for (int nu = 0; nu < 4; nu++) if (nu != mu) t = t * g.B[nu] + c[nu];
+            on.emplace_back(t, i);
+          }
+          std::sort(on.begin(), on.end());
+          DDAMG_REQUIRE((int)on.size() == 32, "a 4^4 block has 32 sites of each parity class on every face");
+          for (int k = 0; k < (int)on.size(); k++) packed[on[k].second] |= (unsigned)k << (8 * mu);
+        }
+    DDAMG_HIP_CHECK(device_alloc(&d_frank_, sizeof(unsigned) * BS_));
+    DDAMG_HIP_CHECK(hipMemcpyAsync(d_frank_, packed.data(), sizeof(unsigned) * BS_, hipMemcpyHostToDevice, st));
+    DDAMG_HIP_CHECK(device_alloc(&d_block_nb_own_, sizeof(int) * 8 * nblocks_));
+    DDAMG_HIP_CHECK(hipMemcpyAsync(d_block_nb_own_, g.block_nb.data(), sizeof(int) * 8 * nblocks_, hipMemcpyHostToDevice, st));
+    d_block_nb_ = d_block_nb_own_;
+    const size_t fe = sap_face_elems(nblocks_);
+    DDAMG_HIP_CHECK(device_alloc(&faces_d_, sizeof(float4) * fe));
+    DDAMG_HIP_CHECK(device_alloc(&faces_x_, sizeof(float4) * fe));
+    DDAMG_HIP_CHECK(hipMemsetAsync(faces_d_, 0, sizeof(float4) * fe, st));
+    DDAMG_HIP_CHECK(hipMemsetAsync(faces_x_, 0, sizeof(float4) * fe, st));
+    std::vector<int> all(nblocks_);
+    for (int b = 0; b < nblocks_; b++) all[b] = b;
+    DDAMG_HIP_CHECK(device_alloc(&d_all_blocks_, sizeof(int) * nblocks_));
+    DDAMG_HIP_CHECK(hipMemcpyAsync(d_all_blocks_, all.data(), sizeof(int) * nblocks_, hipMemcpyHostToDevice, st));
+    DDAMG_HIP_CHECK(hipStreamSynchronize(st));   // the host vectors above go out of scope
+  }
   DDAMG_HIP_CHECK(hipStreamSynchronize(st));
 }
 
-static int g_sap_variant = -1;  // 1: site-pair kernel (v1), 2: thread-per-site kernel with resident links (default)
-
 template <typename T, int HS>
 static void launch_hs(const SapArgs<T>& a, hipStream_t st) {
-  if (g_sap_variant < 0) { const char* e = getenv("DDAMG_SAP_VARIANT"); g_sap_variant = e ? atoi(e) : 2; }
+  if (g_sap_variant < 0) { const char* e = getenv("DDAMG_SAP_VARIANT"); g_sap_variant = e ? atoi(e) : 3; }
   // the resident-operator kernel addresses the operator through buffer descriptors (32-bit offsets, 2 GiB of records):
   // the largest field (72 reals per site) must stay below that, i.e. V < 7.4e6 sites in fp32 -- beyond it (e.g. 64^4 on
   // one GPU) the site-pair kernel with 64-bit addressing takes over
@@ -652,7 +700,32 @@ static void launch_hs(const SapArgs<T>& a, hipStream_t st) {
 }
 
 template <typename T>
-void SapSmoother<T>::launch(int color, int mode, unsigned skip_mask, const T* eta, hipStream_t st) {
+void SapSmoother<T>::launch(int color, int mode, unsigned skip_mask, const T* eta, hipStream_t st, int face_out) {
+  if constexpr (sizeof(T) == 4) {
+    if (pair_) {
+      SapPairArgs p;
+      p.op = op_->dev(); p.blk_nb = d_blk_nb_; p.frank = d_frank_; p.block_list = d_block_list_; p.block_nb = d_block_nb_;
+      p.num_blocks = nblocks_; p.x = x; p.r = r; p.res_src = x; p.eta = eta;
+      p.latest_out = op_->distributed() ? latest : nullptr;   // only the halo pack reads the full-vector copy
+      p.mode = mode < 0 ? MODE_NBOUNDARY : mode; p.skip_mask = skip_mask; p.solve = mode < 0 ? 0 : 1; p.block_iter = block_iter_;
+      p.faces_in = p.mode == MODE_FULLRES ? faces_x_ : faces_d_;
+      p.faces_d_out = (face_out & 1) ? faces_d_ : nullptr;
+      p.faces_x_out = (face_out & 2) ? faces_x_ : nullptr;
+      const bool dist = op_->distributed();
+      if (dist && p.mode != MODE_NONE) {
+        op_->halo_begin(p.mode == MODE_FULLRES ? x : latest, st);
+        p.blocks = d_color_blocks_[color]; p.nblocks = ncol_interior_[color];
+        sap_pair_launch(p, true, st);
+        op_->halo_finish(st);
+        p.blocks = d_color_blocks_[color] + ncol_interior_[color]; p.nblocks = ncol_[color] - ncol_interior_[color];
+        sap_pair_launch(p, true, st);
+      } else {
+        p.blocks = d_color_blocks_[color]; p.nblocks = ncol_[color];
+        sap_pair_launch(p, dist, st);
+      }
+      return;
+    }
+  }
   SapArgs<T> a;
   a.s.op = op_->dev(); a.s.blk_nb = d_blk_nb_; a.s.block_list = d_block_list_;
   a.s.block_sites = BS_; a.s.half_sites = HS_; a.s.block_iter = block_iter_;
@@ -726,7 +799,22 @@ void SapSmoother<T>::smooth(T* phi, T* Dphi, const T* eta, int cycles, int res, 
         if (res == NO_RES) mode = MODE_NONE;
         else mode = k == 0 ? MODE_FULLRES : MODE_NBOUNDARY;
       }
-      launch(color, mode, skip, eta, st);
+      int face_out = 1;
+      if constexpr (sizeof(T) == 4) {
+        if (pair_ && mode == MODE_FULLRES) {
+          // the full residual couples to the iterate x on the neighbouring blocks through their faces.  Two colours: the
+          // faces of the other colour are packed once before the first launch, whose epilogue then leaves the faces of the
+          // updated x for the second one; sixteen colours: all faces are packed before every such launch
+          const bool two = schedule_ == RED_BLACK || schedule_ == TWO_COLOR;
+          if (two && color == 0) {
+            sap_face_pack(op_->dev(), d_blk_nb_, d_frank_, x, faces_x_, d_color_blocks_[1], ncol_[1], st);
+            face_out = 2;
+          } else if (!two) {
+            sap_face_pack(op_->dev(), d_blk_nb_, d_frank_, x, faces_x_, d_all_blocks_, nblocks_, st);
+          }
+        }
+      }
+      launch(color, mode, skip, eta, st, face_out);
       res = RES;
     }
     if (schedule_ == ADDITIVE) std::swap(latest, latest2_);
