@@ -658,8 +658,11 @@ void SapSmoother<T>::setup(const Geometry& g, const FineOp<T>* op, int block_ite
         }
     DDAMG_HIP_CHECK(device_alloc(&d_frank_, sizeof(unsigned) * BS_));
     DDAMG_HIP_CHECK(hipMemcpyAsync(d_frank_, packed.data(), sizeof(unsigned) * BS_, hipMemcpyHostToDevice, st));
+    std::vector<int> nb8((size_t)8 * nblocks_);   // [block][8]: the eight neighbours of a block in one scalar load
+    for (int b = 0; b < nblocks_; b++)
+      for (int d = 0; d < 8; d++) nb8[(size_t)b * 8 + d] = g.block_nb[(size_t)d * nblocks_ + b];
     DDAMG_HIP_CHECK(device_alloc(&d_block_nb_own_, sizeof(int) * 8 * nblocks_));
-    DDAMG_HIP_CHECK(hipMemcpyAsync(d_block_nb_own_, g.block_nb.data(), sizeof(int) * 8 * nblocks_, hipMemcpyHostToDevice, st));
+    DDAMG_HIP_CHECK(hipMemcpyAsync(d_block_nb_own_, nb8.data(), sizeof(int) * 8 * nblocks_, hipMemcpyHostToDevice, st));
     d_block_nb_ = d_block_nb_own_;
     const size_t fe = sap_face_elems(nblocks_);
     DDAMG_HIP_CHECK(device_alloc(&faces_d_, sizeof(float4) * fe));
@@ -705,7 +708,8 @@ void SapSmoother<T>::launch(int color, int mode, unsigned skip_mask, const T* et
     if (pair_) {
       SapPairArgs p;
       p.op = op_->dev(); p.blk_nb = d_blk_nb_; p.frank = d_frank_; p.block_list = d_block_list_; p.block_nb = d_block_nb_;
-      p.num_blocks = nblocks_; p.x = x; p.r = r; p.res_src = x; p.eta = eta;
+      p.num_blocks = nblocks_; p.r = r; p.eta = eta;
+      p.x_in = (const float*)pio_.x_in; p.x_out = (float*)pio_.x_out; p.r_in = (const float*)pio_.r_in; p.res_src = (const float*)pio_.res_src;
       p.latest_out = op_->distributed() ? latest : nullptr;   // only the halo pack reads the full-vector copy
       p.mode = mode < 0 ? MODE_NBOUNDARY : mode; p.skip_mask = skip_mask; p.solve = mode < 0 ? 0 : 1; p.block_iter = block_iter_;
       p.faces_in = p.mode == MODE_FULLRES ? faces_x_ : faces_d_;
@@ -713,7 +717,7 @@ void SapSmoother<T>::launch(int color, int mode, unsigned skip_mask, const T* et
       p.faces_x_out = (face_out & 2) ? faces_x_ : nullptr;
       const bool dist = op_->distributed();
       if (dist && p.mode != MODE_NONE) {
-        op_->halo_begin(p.mode == MODE_FULLRES ? x : latest, st);
+        op_->halo_begin(p.mode == MODE_FULLRES ? pio_.res_src : latest, st);
         p.blocks = d_color_blocks_[color]; p.nblocks = ncol_interior_[color];
         sap_pair_launch(p, true, st);
         op_->halo_finish(st);
@@ -770,7 +774,12 @@ void SapSmoother<T>::smooth(T* phi, T* Dphi, const T* eta, int cycles, int res, 
   const View all = whole((size_t)24 * V_);
   const int init_res = res;
   const int ncolors = (int)ncol_.size();
-  if (res == NO_RES) {
+  // production path: no copies -- the first visit of a block reads the caller's phi (or nothing) and eta, the last one writes
+  // the caller's phi; every site is visited exactly once per sweep
+  const bool direct = pair_ && cycles >= 1 && (schedule_ == RED_BLACK || schedule_ == TWO_COLOR);
+  pio_.x_in = x; pio_.x_out = x; pio_.r_in = r; pio_.res_src = x;
+  if (direct) {
+  } else if (res == NO_RES) {
     vec_copy<T>(r, eta, all, st);
     vec_zero<T>(x, all, st);
   } else {
@@ -800,6 +809,15 @@ void SapSmoother<T>::smooth(T* phi, T* Dphi, const T* eta, int cycles, int res, 
         else mode = k == 0 ? MODE_FULLRES : MODE_NBOUNDARY;
       }
       int face_out = 1;
+      if (direct) {
+        // first sweep: the iterate comes from phi (start with an iterate) or is zero, the residual of a start without an
+        // iterate from eta; last sweep: the iterate goes to phi
+        pio_.x_in = k == 0 ? (init_res == RES ? phi : nullptr) : x;
+        pio_.x_out = k == cycles - 1 ? phi : x;
+        pio_.r_in = (k == 0 && init_res == NO_RES) ? eta : r;
+        pio_.res_src = phi;
+      }
+      const T* xsrc = direct ? phi : x;
       if constexpr (sizeof(T) == 4) {
         if (pair_ && mode == MODE_FULLRES) {
           // the full residual couples to the iterate x on the neighbouring blocks through their faces.  Two colours: the
@@ -807,10 +825,10 @@ void SapSmoother<T>::smooth(T* phi, T* Dphi, const T* eta, int cycles, int res, 
           // updated x for the second one; sixteen colours: all faces are packed before every such launch
           const bool two = schedule_ == RED_BLACK || schedule_ == TWO_COLOR;
           if (two && color == 0) {
-            sap_face_pack(op_->dev(), d_blk_nb_, d_frank_, x, faces_x_, d_color_blocks_[1], ncol_[1], st);
+            sap_face_pack(op_->dev(), d_blk_nb_, d_frank_, xsrc, faces_x_, d_color_blocks_[1], ncol_[1], st);
             face_out = 2;
           } else if (!two) {
-            sap_face_pack(op_->dev(), d_blk_nb_, d_frank_, x, faces_x_, d_all_blocks_, nblocks_, st);
+            sap_face_pack(op_->dev(), d_blk_nb_, d_frank_, xsrc, faces_x_, d_all_blocks_, nblocks_, st);
           }
         }
       }
@@ -819,8 +837,9 @@ void SapSmoother<T>::smooth(T* phi, T* Dphi, const T* eta, int cycles, int res, 
     }
     if (schedule_ == ADDITIVE) std::swap(latest, latest2_);
   }
-  vec_copy<T>(phi, x, all, st);  // relax_fac == 1 (the reference's default, src/init.c)
+  if (!direct) vec_copy<T>(phi, x, all, st);  // relax_fac == 1 (the reference's default, src/init.c)
   if (Dphi != nullptr) {
+    pio_.r_in = r;
     // D phi = eta - r, after bringing the residuals of the blocks that were solved before their neighbours up to date
     // (red-black: colour 0, src/schwarz_generic.c:1355-1396; additive: every block, :1180-1222); the reference does not
     // offer this by-product with sixteen colours (ASSERT( D_phi == NULL ), :1656)

@@ -13,9 +13,12 @@ struct SapPairArgs {
   const int* blk_nb;             // [8][256] block-local neighbour or -1
   const unsigned char* frank;    // [4][256] rank of a face site among the sites of its parity class on its face
   const int* block_list;         // [num_blocks] red-black list id of the reference
-  const int* block_nb;           // [8][num_blocks] neighbouring block, -1 across a process boundary
+  const int* block_nb;           // [num_blocks][8] neighbouring block, -1 across a process boundary
   int num_blocks;                // blocks of the local lattice
-  float* x; float* r;
+  const float* x_in;             // iterate before this visit (null: zero); == res_src in MODE_FULLRES
+  float* x_out;                  // iterate after it (x, or the caller's phi in the last sweep: no copy at the end)
+  const float* r_in;             // residual before this visit (r, or eta at the very start of a run without an iterate)
+  float* r;
   float* latest_out;             // full-vector copy of the update (only kept on a process grid: source of the halo pack)
   const float* res_src;          // iterate of the full residual (MODE_FULLRES)
   const float* eta;

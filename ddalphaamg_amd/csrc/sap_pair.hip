@@ -21,12 +21,9 @@
 //  * the full residual of the first sweep (block_op + boundary_op) takes its in-block part through the same LDS exchange
 //    and the resident operator instead of re-reading links and spinors through the cache.
 //  * four barriers per MinRes step instead of six (the reduction scratch is double-buffered).
-#ifndef DDAMG_PK
-#define DDAMG_PK 0   // packed fp32 next to 144 resident operator registers: measured per variant, see DESIGN.md
-#endif
 #include "sap_pair.h"
 #include "sap_modes.h"
-#include "dirac_device.h"
+#include "pk_device.h"
 
 namespace ddamg {
 
@@ -35,100 +32,95 @@ namespace {
 constexpr int HS = 128, BS = 256, FH = 32;   // sites per parity, per block, per parity class of a face (64-site faces)
 constexpr float EPS_F = 1e-6f;               // EPS_float (src/main.h:45)
 
+// in-block exchange of projected half spinors through LDS: slot (d, c) of sender j at sl[(d*6 + c)*HS + j]
 template <int MU>
-__device__ __forceinline__ void emit_dir(const float (&v)[24], const float (&U)[18], const int (&nbl)[8], float* __restrict__ sl, int j) {
+__device__ __forceinline__ void emit_dir(const cf (&v)[12], const cf (&U)[9], const int (&nbl)[8], cf* __restrict__ sl, int j) {
   if (nbl[MU] >= 0) {   // my +mu neighbour is in the block: it needs U_mu(me)^dagger (1+gamma_mu) v
-    float h[12], g[12];
-    spin_project<float, MU, +1>(v, h);
-    su3_mul_dag<float>(U, h, g);
+    cf h[6], g[6];
+    pk_project<MU, +1>(v, h);
+    pk_su3_mul_dag(U, h, g);
 #pragma unroll
-    for (int c = 0; c < 12; c++) sl[(MU * 12 + c) * HS + j] = g[c];
+    for (int c = 0; c < 6; c++) sl[(MU * 6 + c) * HS + j] = g[c];
   }
   if (nbl[4 + MU] >= 0) {   // my -mu neighbour multiplies (1-gamma_mu) v with its own link
-    float h[12];
-    spin_project<float, MU, -1>(v, h);
+    cf h[6];
+    pk_project<MU, -1>(v, h);
 #pragma unroll
-    for (int c = 0; c < 12; c++) sl[((4 + MU) * 12 + c) * HS + j] = h[c];
+    for (int c = 0; c < 6; c++) sl[((4 + MU) * 6 + c) * HS + j] = h[c];
   }
 }
 template <int MU>
-__device__ __forceinline__ void collect_dir(float (&acc)[24], const float (&U)[18], const int (&nbl)[8], const float* __restrict__ sl) {
+__device__ __forceinline__ void collect_dir(cf (&acc)[12], const cf (&U)[9], const int (&nbl)[8], const cf* __restrict__ sl) {
   {
     const int n = nbl[4 + MU];   // from x-mu: already multiplied by its link
     if (n >= 0) {
-      float g[12];
+      cf g[6];
 #pragma unroll
-      for (int c = 0; c < 12; c++) g[c] = sl[(MU * 12 + c) * HS + n];
-      spin_reconstruct_sub<float, MU, +1>(g, acc);
+      for (int c = 0; c < 6; c++) g[c] = sl[(MU * 6 + c) * HS + n];
+      pk_reconstruct_sub<MU, +1>(g, acc);
     }
   }
   {
     const int n = nbl[MU];       // from x+mu: multiply with my own link
     if (n >= 0) {
-      float h[12], g[12];
+      cf h[6], g[6];
 #pragma unroll
-      for (int c = 0; c < 12; c++) h[c] = sl[((4 + MU) * 12 + c) * HS + n];
-      su3_mul<float>(U, h, g);
-      spin_reconstruct_sub<float, MU, -1>(g, acc);
+      for (int c = 0; c < 6; c++) h[c] = sl[((4 + MU) * 6 + c) * HS + n];
+      pk_su3_mul(U, h, g);
+      pk_reconstruct_sub<MU, -1>(g, acc);
     }
   }
 }
 
-__device__ __forceinline__ void face_load(const float4* __restrict__ f, float (&h)[12]) {
+__device__ __forceinline__ void face_load(const float4* __restrict__ f, cf (&h)[6]) {
   const float4 a = f[0], b = f[64], c = f[128];
-  h[0] = a.x; h[1] = a.y; h[2] = a.z; h[3] = a.w; h[4] = b.x; h[5] = b.y; h[6] = b.z; h[7] = b.w; h[8] = c.x; h[9] = c.y; h[10] = c.z; h[11] = c.w;
+  h[0] = cf_make(a.x, a.y); h[1] = cf_make(a.z, a.w); h[2] = cf_make(b.x, b.y); h[3] = cf_make(b.z, b.w); h[4] = cf_make(c.x, c.y); h[5] = cf_make(c.z, c.w);
 }
-__device__ __forceinline__ void face_store(float4* __restrict__ f, const float (&h)[12]) {
-  f[0] = make_float4(h[0], h[1], h[2], h[3]); f[64] = make_float4(h[4], h[5], h[6], h[7]); f[128] = make_float4(h[8], h[9], h[10], h[11]);
+__device__ __forceinline__ void face_store(float4* __restrict__ f, const cf (&h)[6]) {
+  f[0] = make_float4(h[0].x, h[0].y, h[1].x, h[1].y); f[64] = make_float4(h[2].x, h[2].y, h[3].x, h[3].y); f[128] = make_float4(h[4].x, h[4].y, h[5].x, h[5].y);
 }
 
-// acc -= (couplings of my site that leave the block), from the neighbouring blocks' faces (or the halo of another process)
-template <int MU, bool DIST>
-__device__ __forceinline__ void ext_dir(float (&acc)[24], const float (&U)[18], unsigned ext, const SapPairArgs& a, int blk, size_t s, int cidx) {
-  __builtin_amdgcn_sched_barrier(0);
+// The couplings of my site that leave the block come from the neighbouring blocks' faces (or the halo of another
+// process).  All of a site's face reads are issued together, before any of them is used: one memory round trip, not one per
+// direction (the block index, the neighbour blocks and the face addresses are a dependent chain as it is).
+template <int D, bool DIST>
+__device__ __forceinline__ void ext_fetch(cf (&h)[6], unsigned ext, const SapPairArgs& a, const int (&nbk)[8], size_t s, int cidx) {
+  constexpr int MU = D & 3;
+  if (ext & (1u << D)) {
+    const int nb = nbk[D];
+    if (DIST && nb < 0) {
+      const int slot = -1 - a.op.nb[(size_t)D * a.op.V + s];
+      pk_load_site<6>(a.op.halo + a.op.hd.off[D], (size_t)a.op.hd.F[MU], (size_t)slot, h);   // what the other process sent for this face
+    } else {
+      // my +mu neighbour left (1-gamma_mu) v on its -mu face; my -mu neighbour left U_mu^dagger (1+gamma_mu) v on its +mu face
+      face_load(a.faces_in + ((size_t)nb * 8 + (D ^ 4)) * 192 + cidx, h);
+    }
+  }
+}
+template <int MU>
+__device__ __forceinline__ void ext_apply(cf (&acc)[12], const cf (&U)[9], unsigned ext, const cf (&hp)[6], const cf (&hm)[6]) {
   if (ext & (1u << MU)) {
-    const int nb = a.block_nb[(size_t)MU * a.num_blocks + blk];
-    if (DIST && nb < 0) {
-      halo_forward<float, MU>(a.op, -1 - a.op.nb[(size_t)MU * a.op.V + s], U, acc);
-    } else {
-      float h[12], g[12];
-      face_load(a.faces_in + ((size_t)nb * 8 + 4 + MU) * 192 + cidx, h);   // (1-gamma_mu) v(x+mu), left on the neighbour's -mu face
-      su3_mul<float>(U, h, g);
-      spin_reconstruct_sub<float, MU, -1>(g, acc);
-    }
+    cf g[6];
+    pk_su3_mul(U, hp, g);
+    pk_reconstruct_sub<MU, -1>(g, acc);
   }
-  __builtin_amdgcn_sched_barrier(0);
-  if (ext & (1u << (4 + MU))) {
-    const int nb = a.block_nb[(size_t)(4 + MU) * a.num_blocks + blk];
-    if (DIST && nb < 0) {
-      halo_backward<float, MU>(a.op, -1 - a.op.nb[(size_t)(4 + MU) * a.op.V + s], acc);
-    } else {
-      float g[12];
-      face_load(a.faces_in + ((size_t)nb * 8 + MU) * 192 + cidx, g);       // U_mu(x-mu)^dagger (1+gamma_mu) v(x-mu), from its +mu face
-      spin_reconstruct_sub<float, MU, +1>(g, acc);
-    }
-  }
+  if (ext & (1u << (4 + MU))) pk_reconstruct_sub<MU, +1>(hm, acc);
 }
 
 // leave the projected half spinors of v on the faces my site lies on
 template <int MU>
-__device__ __forceinline__ void face_emit_dir(const float (&v)[24], const float (&U)[18], unsigned ext, float4* __restrict__ out, int blk, int pidx) {
+__device__ __forceinline__ void face_emit_dir(const cf (&v)[12], const cf (&U)[9], unsigned ext, float4* __restrict__ out, int blk, int pidx) {
   if (ext & (1u << MU)) {
-    float h[12], g[12];
-    spin_project<float, MU, +1>(v, h);
-    su3_mul_dag<float>(U, h, g);
+    cf h[6], g[6];
+    pk_project<MU, +1>(v, h);
+    pk_su3_mul_dag(U, h, g);
     face_store(out + ((size_t)blk * 8 + MU) * 192 + pidx, g);
   }
   if (ext & (1u << (4 + MU))) {
-    float h[12];
-    spin_project<float, MU, -1>(v, h);
+    cf h[6];
+    pk_project<MU, -1>(v, h);
     face_store(out + ((size_t)blk * 8 + 4 + MU) * 192 + pidx, h);
   }
-}
-
-__device__ __forceinline__ void clover_reg(const float (&C)[72], const float (&in)[24], float (&out)[24]) {
-  herm6_mul<float>(C, in, out);
-  herm6_mul<float>(C + 36, in + 12, out + 12);
 }
 
 #define DDAMG_EMIT(v)                                   \
@@ -145,12 +137,29 @@ __device__ __forceinline__ void clover_reg(const float (&C)[72], const float (&i
     collect_dir<2>(acc, U2, nbl, sl);                   \
     collect_dir<3>(acc, U3, nbl, sl);                   \
   } while (0)
+#define DDAMG_EXT_FETCH()                                                \
+  do {                                                                   \
+    ext_fetch<0, DIST>(fh[0], ext, a, nbk, s, cidx[0]);                  \
+    ext_fetch<1, DIST>(fh[1], ext, a, nbk, s, cidx[1]);                  \
+    ext_fetch<2, DIST>(fh[2], ext, a, nbk, s, cidx[2]);                  \
+    ext_fetch<3, DIST>(fh[3], ext, a, nbk, s, cidx[3]);                  \
+    ext_fetch<4, DIST>(fh[4], ext, a, nbk, s, cidx[0]);                  \
+    ext_fetch<5, DIST>(fh[5], ext, a, nbk, s, cidx[1]);                  \
+    ext_fetch<6, DIST>(fh[6], ext, a, nbk, s, cidx[2]);                  \
+    ext_fetch<7, DIST>(fh[7], ext, a, nbk, s, cidx[3]);                  \
+  } while (0)
+#define DDAMG_EXT_APPLY(acc)                                             \
+  do {                                                                   \
+    ext_apply<0>(acc, U0, ext, fh[0], fh[4]);                            \
+    ext_apply<1>(acc, U1, ext, fh[1], fh[5]);                            \
+    ext_apply<2>(acc, U2, ext, fh[2], fh[6]);                            \
+    ext_apply<3>(acc, U3, ext, fh[3], fh[7]);                            \
+  } while (0)
 
-template <bool DIST>
-__global__ __launch_bounds__(512, 2) void sap_pair_kernel(SapPairArgs a) {
-  __shared__ float slots[2][8 * 12 * HS];
-  __shared__ float lphi_s[2][24 * HS];   // MinRes iterate of the even sites
-  __shared__ float red[2][2][8];         // [generation][block of the pair][2 even wavefronts x 3 sums]
+template <bool DIST, int NB>
+__global__ __launch_bounds__(256 * NB, 2) void sap_pair_kernel(SapPairArgs a) {
+  __shared__ cf slots[NB][8 * 6 * HS];
+  __shared__ float red[2][NB][8];        // [generation][block of the workgroup][2 even wavefronts x 3 sums]
   const FineOpDev<float>& op = a.op;
   const size_t V = op.V;
   const int w = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -160,13 +169,15 @@ __global__ __launch_bounds__(512, 2) void sap_pair_kernel(SapPairArgs a) {
   const int hw = wb & 1;                             // which of the two wavefronts of my parity
   const int j = hw * 64 + lane;
   const int i = odd ? HS + j : j;
-  const int bslot = blockIdx.x * 2 + bw;
+  const int bslot = blockIdx.x * NB + bw;
   const bool active = bslot < a.nblocks;
   const int blk = active ? a.blocks[bslot] : a.blocks[0];
   const size_t s = (size_t)blk * BS + i;
-  float* sl = slots[bw];
-  float* lp = lphi_s[bw];
+  cf* sl = slots[bw];
 
+  int nbk[8];   // neighbouring blocks (wavefront-uniform)
+#pragma unroll
+  for (int d = 0; d < 8; d++) nbk[d] = a.block_nb[(size_t)blk * 8 + d];
   int nbl[8];
   unsigned ext = 0;
 #pragma unroll
@@ -187,61 +198,70 @@ __global__ __launch_bounds__(512, 2) void sap_pair_kernel(SapPairArgs a) {
   }
 
   // ---- the block's links: resident from here on ---------------------------------------------------
-  float U0[18], U1[18], U2[18], U3[18];
-  load_site<float, 18, true>(op.D, V, s, U0);
-  load_site<float, 18, true>(op.D + (size_t)18 * V, V, s, U1);
-  load_site<float, 18, true>(op.D + (size_t)36 * V, V, s, U2);
-  load_site<float, 18, true>(op.D + (size_t)54 * V, V, s, U3);
+  cf U0[9], U1[9], U2[9], U3[9];
+  pk_load_site<9, true>(op.D, V, s, U0);
+  pk_load_site<9, true>(op.D + (size_t)18 * V, V, s, U1);
+  pk_load_site<9, true>(op.D + (size_t)36 * V, V, s, U2);
+  pk_load_site<9, true>(op.D + (size_t)54 * V, V, s, U3);
 
   int mode = a.mode;
   if ((a.skip_mask >> a.block_list[blk]) & 1u) mode = MODE_NONE;
 
-  float v0[24];   // r, then (even sites) the MinRes residual
+  cf v0[12];   // r, then (even sites) the MinRes residual
   if (!a.solve) {
     // only bring the residual up to date (by-product D*phi of the smoother, src/schwarz_generic.c:1355-1396)
-    load_site<float, 24>(a.r, V, s, v0);
+    pk_load_site<12>(a.r_in, V, s, v0);
     if (mode == MODE_NBOUNDARY && ext) {
-      float acc[24];
+      cf fh[8][6];
+      DDAMG_EXT_FETCH();
+      cf acc[12];
 #pragma unroll
-      for (int k = 0; k < 24; k++) acc[k] = 0;
-      ext_dir<0, DIST>(acc, U0, ext, a, blk, s, cidx[0]);
-      ext_dir<1, DIST>(acc, U1, ext, a, blk, s, cidx[1]);
-      ext_dir<2, DIST>(acc, U2, ext, a, blk, s, cidx[2]);
-      ext_dir<3, DIST>(acc, U3, ext, a, blk, s, cidx[3]);
+      for (int k = 0; k < 12; k++) acc[k] = cf_make(0.f, 0.f);
+      DDAMG_EXT_APPLY(acc);
 #pragma unroll
-      for (int k = 0; k < 24; k++) v0[k] -= acc[k];
+      for (int k = 0; k < 12; k++) v0[k] -= acc[k];
     }
-    if (active) store_site<float, 24>(a.r, V, s, v0);
+    if (active) pk_store_site<12>(a.r, V, s, v0);
     return;
   }
 
-  float C[72];    // D_ee on even sites, D_oo^-1 on odd sites
-  load_site<float, 72, true>(odd ? op.clover_inv : op.clover, V, s, C);
-
   // ---- prologue: residual of my site --------------------------------------------------------------
+  cf C[36];    // D_ee on even sites, D_oo^-1 on odd sites; loaded behind the face reads (144 + 96 registers do not fit next to
+               // the rest), needed from the first clover product on
   if (a.mode == MODE_FULLRES) {
-    // r = eta - D x with the whole operator (block_op + boundary_op, first sweep of a start with an iterate)
-    float xs[24], e[24];
-    load_site<float, 24>(a.res_src, V, s, xs);
+    // r = eta - D x with the whole operator (block_op + boundary_op, first sweep of a start with an iterate): the clover
+    // term, the couplings that leave the block from the neighbours' x faces, the couplings inside the block through
+    // the LDS exchange with the resident links -- the even sites first, then the odd ones
+    cf xs[12], e[12];
+    pk_load_site<12>(a.res_src, V, s, xs);
+    pk_load_site<12>(a.eta, V, s, v0);
+    {
+      cf fh[8][6];
+      if (ext) DDAMG_EXT_FETCH();
+#pragma unroll
+      for (int k = 0; k < 12; k++) e[k] = cf_make(0.f, 0.f);
+      if (ext) DDAMG_EXT_APPLY(e);
+    }
+    pk_load_site<36, true>(odd ? op.clover_inv : op.clover, V, s, C);
     if (!odd) {
-      clover_reg(C, xs, e);
+      cf t[12];
+      pk_clover(C, xs, t);
+#pragma unroll
+      for (int k = 0; k < 12; k++) e[k] += t[k];
     } else {
-      float c[36];
+      cf c[18], t[6];
       __builtin_amdgcn_sched_barrier(0);
-      load_site<float, 36>(op.clover, V, s, c);
-      herm6_mul<float>(c, xs, e);
+      pk_load_site<18>(op.clover, V, s, c);
+      pk_herm6(c, xs, t);
+#pragma unroll
+      for (int k = 0; k < 6; k++) e[k] += t[k];
       __builtin_amdgcn_sched_barrier(0);
-      load_site<float, 36>(op.clover + (size_t)36 * V, V, s, c);
-      herm6_mul<float>(c, xs + 12, e + 12);
+      pk_load_site<18>(op.clover + (size_t)36 * V, V, s, c);
+      pk_herm6(c, xs + 6, t);
+#pragma unroll
+      for (int k = 0; k < 6; k++) e[6 + k] += t[k];
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (ext) {
-      ext_dir<0, DIST>(e, U0, ext, a, blk, s, cidx[0]);
-      ext_dir<1, DIST>(e, U1, ext, a, blk, s, cidx[1]);
-      ext_dir<2, DIST>(e, U2, ext, a, blk, s, cidx[2]);
-      ext_dir<3, DIST>(e, U3, ext, a, blk, s, cidx[3]);
-    }
-    // couplings inside the block: both parities through the LDS exchange, one after the other
     if (!odd) DDAMG_EMIT(xs);
     __syncthreads();
     if (odd) DDAMG_COLLECT(e);
@@ -250,124 +270,130 @@ __global__ __launch_bounds__(512, 2) void sap_pair_kernel(SapPairArgs a) {
     __syncthreads();
     if (!odd) DDAMG_COLLECT(e);
     __syncthreads();
-    load_site<float, 24>(a.eta, V, s, v0);
 #pragma unroll
-    for (int k = 0; k < 24; k++) v0[k] -= e[k];
+    for (int k = 0; k < 12; k++) v0[k] -= e[k];
   } else {
-    load_site<float, 24>(a.r, V, s, v0);
+    pk_load_site<12>(a.r_in, V, s, v0);
     if (mode == MODE_NBOUNDARY && ext) {
       // r_b -= D_{b,ext} delta_ext (n_boundary_op)
-      float acc[24];
+      cf fh[8][6];
+      DDAMG_EXT_FETCH();
+      cf acc[12];
 #pragma unroll
-      for (int k = 0; k < 24; k++) acc[k] = 0;
-      ext_dir<0, DIST>(acc, U0, ext, a, blk, s, cidx[0]);
-      ext_dir<1, DIST>(acc, U1, ext, a, blk, s, cidx[1]);
-      ext_dir<2, DIST>(acc, U2, ext, a, blk, s, cidx[2]);
-      ext_dir<3, DIST>(acc, U3, ext, a, blk, s, cidx[3]);
+      for (int k = 0; k < 12; k++) acc[k] = cf_make(0.f, 0.f);
+      DDAMG_EXT_APPLY(acc);
 #pragma unroll
-      for (int k = 0; k < 24; k++) v0[k] -= acc[k];
+      for (int k = 0; k < 12; k++) v0[k] -= acc[k];
     }
+    pk_load_site<36, true>(odd ? op.clover_inv : op.clover, V, s, C);
   }
 
-  // ---- block solve (block_solve_oddeven) ------------------------------------------------------------
-  float v1[24];   // odd: D_oo^-1 (...) ; even: D_ee rm / Dr
-  // t_o = D_oo^-1 r_o ; r_e <- r_e - D_eo t_o
-  if (odd) { clover_reg(C, v0, v1); DDAMG_EMIT(v1); }
-  __syncthreads();
-  if (!odd) {
-    float acc[24];
+  // ---- block solve (block_solve_oddeven): the two roles run their own code between the same barriers ---------------
+  cf v1[12];   // the update delta of my site at the end
+  if (odd) {
+    // t_o = D_oo^-1 r_o, sent to the even sites
+    pk_clover(C, v0, v1);
+    DDAMG_EMIT(v1);
+    __syncthreads();                      // S1
+    __syncthreads();                      // S2
+    for (int it = 0; it < a.block_iter; it++) {
+      __syncthreads();                    // B1: the even sites' residual is in the slots
+      cf acc[12];
 #pragma unroll
-    for (int k = 0; k < 24; k++) acc[k] = 0;
+      for (int k = 0; k < 12; k++) acc[k] = cf_make(0.f, 0.f);
+      DDAMG_COLLECT(acc);                 // D_oe rm
+      pk_clover(C, acc, v1);              // D_oo^-1 D_oe rm
+      __syncthreads();                    // B2: every odd site has read the slots
+      DDAMG_EMIT(v1);
+      __syncthreads();                    // B3
+      __syncthreads();                    // B4: (the even sites' reduction)
+    }
+    __syncthreads();                      // F1: delta_e is in the slots
+    // delta_o = D_oo^-1 ( r_o - D_oe delta_e )
+    cf acc[12];
+#pragma unroll
+    for (int k = 0; k < 12; k++) acc[k] = cf_make(0.f, 0.f);
     DDAMG_COLLECT(acc);
 #pragma unroll
-    for (int k = 0; k < 24; k++) { v0[k] -= acc[k]; lp[k * HS + j] = 0; }
-  }
-  __syncthreads();
-  for (int it = 0; it < a.block_iter; it++) {
-    if (!odd) DDAMG_EMIT(v0);
-    __syncthreads();
-    if (odd) {
-      float acc[24];
+    for (int k = 0; k < 12; k++) v0[k] -= acc[k];
+    pk_clover(C, v0, v1);
 #pragma unroll
-      for (int k = 0; k < 24; k++) acc[k] = 0;
-      DDAMG_COLLECT(acc);                 // D_oe rm
-      clover_reg(C, acc, v1);             // D_oo^-1 D_oe rm
+    for (int k = 0; k < 12; k++) v0[k] = cf_make(0.f, 0.f);     // r_o = 0
+  } else {
+    cf lphi[12];   // MinRes iterate
+    __syncthreads();                      // S1
+    {
+      // r_e <- r_e - D_eo t_o
+      cf acc[12];
+#pragma unroll
+      for (int k = 0; k < 12; k++) acc[k] = cf_make(0.f, 0.f);
+      DDAMG_COLLECT(acc);
+#pragma unroll
+      for (int k = 0; k < 12; k++) { v0[k] -= acc[k]; lphi[k] = cf_make(0.f, 0.f); }
     }
-    __syncthreads();                      // every odd site has read the even sites' data: the slots can be rewritten
-    if (odd) DDAMG_EMIT(v1);
-    __syncthreads();
-    float nr = 0, ni = 0, dn = 0;
-    float* rd = red[it & 1][bw];
-    if (!odd) {
-      clover_reg(C, v0, v1);              // D_ee rm
+    __syncthreads();                      // S2: the slots can be rewritten
+    for (int it = 0; it < a.block_iter; it++) {
+      DDAMG_EMIT(v0);
+      __syncthreads();                    // B1
+      __syncthreads();                    // B2
+      pk_clover(C, v0, v1);               // D_ee rm (while the odd sites send)
 #pragma unroll
-      for (int k = 0; k < 24; k++) v1[k] = -v1[k];
+      for (int k = 0; k < 12; k++) v1[k] = -v1[k];
+      __syncthreads();                    // B3: D_oo^-1 D_oe rm is in the slots
       DDAMG_COLLECT(v1);                  // v1 = -(D_ee rm) - H_e(..) = -Dr
-#pragma unroll
-      for (int k = 0; k < 24; k++) v1[k] = -v1[k];
       // alpha = <Dr,rm>/<Dr,Dr>   (local_xy_over_xx, src/linalg_generic.c:158-169)
+      cf pr = cf_make(0.f, 0.f), pi = cf_make(0.f, 0.f), pd = cf_make(0.f, 0.f);
 #pragma unroll
       for (int k = 0; k < 12; k++) {
-        nr += v1[2 * k] * v0[2 * k] + v1[2 * k + 1] * v0[2 * k + 1];
-        ni += v1[2 * k] * v0[2 * k + 1] - v1[2 * k + 1] * v0[2 * k];
-        dn += v1[2 * k] * v1[2 * k] + v1[2 * k + 1] * v1[2 * k + 1];
+        v1[k] = -v1[k];
+        pr = __builtin_elementwise_fma(v1[k], v0[k], pr);                       // re*re, im*im
+        pi = __builtin_elementwise_fma(v1[k], cf_make(v0[k].y, v0[k].x), pi);   // Dr.re*rm.im, Dr.im*rm.re
+        pd = __builtin_elementwise_fma(v1[k], v1[k], pd);
       }
+      float nr = pr.x + pr.y, ni = pi.x - pi.y, dn = pd.x + pd.y;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
         nr += __shfl_xor(nr, o, 64); ni += __shfl_xor(ni, o, 64); dn += __shfl_xor(dn, o, 64);
       }
+      float* rd = red[it & 1][bw];
       if (lane == 0) { rd[hw * 3] = nr; rd[hw * 3 + 1] = ni; rd[hw * 3 + 2] = dn; }
-    }
-    __syncthreads();
-    if (!odd) {
+      __syncthreads();                    // B4
       // both even wavefronts add the two partial sums in the same order: the same alpha on every site
       nr = rd[0] + rd[3]; ni = rd[1] + rd[4]; dn = rd[2] + rd[5];
-      float ar = 0, ai = 0;
-      if (fabsf(dn) >= EPS_F) { ar = nr / dn; ai = ni / dn; }
+      cf al = cf_make(0.f, 0.f);
+      if (fabsf(dn) >= EPS_F) al = cf_make(nr / dn, ni / dn);
 #pragma unroll
       for (int k = 0; k < 12; k++) {
-        lp[(2 * k) * HS + j]     += ar * v0[2 * k] - ai * v0[2 * k + 1];
-        lp[(2 * k + 1) * HS + j] += ar * v0[2 * k + 1] + ai * v0[2 * k];
-        v0[2 * k]     -= ar * v1[2 * k] - ai * v1[2 * k + 1];
-        v0[2 * k + 1] -= ar * v1[2 * k + 1] + ai * v1[2 * k];
+        lphi[k] = cf_mac(lphi[k], al, v0[k]);
+        v0[k] = cf_mac(v0[k], -al, v1[k]);
       }
     }
-    // no barrier here: the even sites finished reading the slots before the reduction barrier, the scratch of the
-    // reduction alternates between two generations
-  }
-  // even to odd: delta_o = D_oo^-1 ( r_o - D_oe delta_e )
-  if (!odd) {
+    // delta_e to the odd sites
 #pragma unroll
-    for (int k = 0; k < 24; k++) v1[k] = lp[k * HS + j];
+    for (int k = 0; k < 12; k++) v1[k] = lphi[k];
     DDAMG_EMIT(v1);
-  }
-  __syncthreads();
-  if (odd) {
-    float acc[24];
-#pragma unroll
-    for (int k = 0; k < 24; k++) acc[k] = 0;
-    DDAMG_COLLECT(acc);
-#pragma unroll
-    for (int k = 0; k < 24; k++) v0[k] -= acc[k];
-    clover_reg(C, v0, v1);
-#pragma unroll
-    for (int k = 0; k < 24; k++) v0[k] = 0;     // r_o = 0
+    __syncthreads();                      // F1
   }
   if (active) {
     // x += delta ; r_e = MinRes residual, r_o = 0 ; the faces of delta (and of the new x) for the neighbouring blocks
-    store_site<float, 24>(a.r, V, s, v0);
-    if (a.latest_out) store_site<float, 24>(a.latest_out, V, s, v1);
+    pk_store_site<12>(a.r, V, s, v0);
+    if (a.latest_out) pk_store_site<12>(a.latest_out, V, s, v1);
     if (a.faces_d_out && ext) {
       face_emit_dir<0>(v1, U0, ext, a.faces_d_out, blk, pidx[0]);
       face_emit_dir<1>(v1, U1, ext, a.faces_d_out, blk, pidx[1]);
       face_emit_dir<2>(v1, U2, ext, a.faces_d_out, blk, pidx[2]);
       face_emit_dir<3>(v1, U3, ext, a.faces_d_out, blk, pidx[3]);
     }
-    float xs[24];
-    load_site<float, 24>(a.x, V, s, xs);
+    cf xs[12];
+    if (a.x_in) {
+      pk_load_site<12>(a.x_in, V, s, xs);
 #pragma unroll
-    for (int k = 0; k < 24; k++) xs[k] += v1[k];
-    store_site<float, 24>(a.x, V, s, xs);
+      for (int k = 0; k < 12; k++) xs[k] += v1[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 12; k++) xs[k] = v1[k];
+    }
+    pk_store_site<12>(a.x_out, V, s, xs);
     if (a.faces_x_out && ext) {
       face_emit_dir<0>(xs, U0, ext, a.faces_x_out, blk, pidx[0]);
       face_emit_dir<1>(xs, U1, ext, a.faces_x_out, blk, pidx[1]);
@@ -378,6 +404,8 @@ __global__ __launch_bounds__(512, 2) void sap_pair_kernel(SapPairArgs a) {
 }
 #undef DDAMG_EMIT
 #undef DDAMG_COLLECT
+#undef DDAMG_EXT_FETCH
+#undef DDAMG_EXT_APPLY
 
 // faces of an arbitrary vector (the iterate handed to the smoother) for the listed blocks: one thread per site
 __global__ __launch_bounds__(256) void sap_face_pack_kernel(FineOpDev<float> op, const int* __restrict__ blk_nb, const unsigned char* __restrict__ frank,
@@ -391,13 +419,13 @@ __global__ __launch_bounds__(256) void sap_face_pack_kernel(FineOpDev<float> op,
   if (!ext) return;
   const bool odd = i >= HS;
   const unsigned fr = reinterpret_cast<const unsigned*>(frank)[i];
-  float val[24];
-  load_site<float, 24>(v, V, s, val);
+  cf val[12];
+  pk_load_site<12>(v, V, s, val);
 #define DDAMG_PACK_DIR(MU)                                                              \
   do {                                                                                  \
     const int pidx = (odd ? FH : 0) + (int)((fr >> (8 * MU)) & 0xffu);                  \
-    float U[18];                                                                        \
-    if (ext & (1u << MU)) load_site<float, 18>(op.D + (size_t)MU * 18 * V, V, s, U);    \
+    cf U[9];                                                                            \
+    if (ext & (1u << MU)) pk_load_site<9>(op.D + (size_t)MU * 18 * V, V, s, U);         \
     face_emit_dir<MU>(val, U, ext, out, blk, pidx);                                     \
   } while (0)
   DDAMG_PACK_DIR(0); DDAMG_PACK_DIR(1); DDAMG_PACK_DIR(2); DDAMG_PACK_DIR(3);
@@ -408,9 +436,17 @@ __global__ __launch_bounds__(256) void sap_face_pack_kernel(FineOpDev<float> op,
 
 void sap_pair_launch(const SapPairArgs& a, bool dist, hipStream_t st) {
   if (a.nblocks <= 0) return;
-  const int grid = (a.nblocks + 1) / 2;
-  if (dist) hipLaunchKernelGGL((sap_pair_kernel<true>), dim3(grid), dim3(512), 0, st, a);
-  else hipLaunchKernelGGL((sap_pair_kernel<false>), dim3(grid), dim3(512), 0, st, a);
+  // blocks per workgroup: 2 (lockstep pair with complementary wavefront roles) or 1 (two independent workgroups per CU,
+  // whose load and compute phases drift apart and overlap); DDAMG_SAP_BLOCKS_PER_WG selects, see DESIGN.md for the numbers
+  static const int nb = [] { const char* e = getenv("DDAMG_SAP_BLOCKS_PER_WG"); return e ? atoi(e) : 1; }();
+  if (nb == 2) {
+    const int grid = (a.nblocks + 1) / 2;
+    if (dist) hipLaunchKernelGGL((sap_pair_kernel<true, 2>), dim3(grid), dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((sap_pair_kernel<false, 2>), dim3(grid), dim3(512), 0, st, a);
+  } else {
+    if (dist) hipLaunchKernelGGL((sap_pair_kernel<true, 1>), dim3(a.nblocks), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((sap_pair_kernel<false, 1>), dim3(a.nblocks), dim3(256), 0, st, a);
+  }
   DDAMG_HIP_CHECK(hipGetLastError());
 }
 
