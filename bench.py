@@ -566,7 +566,15 @@ def main():
             dog.daemon = True; dog.start()
         try:
             Lloc = [G[mu] // grid[mu] for mu in range(4)]
-            res = run_solve(amg_params(api, Lloc, 3, local_rank), G, grid, coords, world, rank, args.transport, gloo)
+            q = amg_params(api, Lloc, 3, local_rank)
+            # the reference's default restart length (src/init.c:861-866: 10 x 100): at 64^4 on ONE GPU an fp64 flexible
+            # Krylov space of 50 would need 2 x 51 vectors of 3.2 GB; the same algorithm is run at every N
+            q.restart, q.max_restart = 10, 100
+            if os.environ.get("DDAMG_BENCH_FAIL_RANK") == str(rank):
+                raise RuntimeError("injected failure (DDAMG_BENCH_FAIL_RANK)")
+            if os.environ.get("DDAMG_BENCH_HANG_RANK") == str(rank):
+                time.sleep(1e6)
+            res = run_solve(q, G, grid, coords, world, rank, args.transport, gloo)
             if world > 1:
                 t = torch.tensor([res["seconds_per_solve"]], dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX, group=gloo)
@@ -574,7 +582,7 @@ def main():
             res["workload"] = (f"ONE global {'x'.join(map(str, G))} lattice over the process grid {'x'.join(map(str, grid))} (T,Z,Y,X), local "
                                f"{'x'.join(map(str, Lloc))}; near-unit gauge exp({GAUGE_EPS} i H) seed {GAUGE_SEED}, m0 -0.3, csw 1, 3-level AMG (4^4 then 2^4 "
                                "aggregates, Nvec 24/28, SAP 2x4 on both smoothing levels, K-cycle 5/2/0.1, coarsest odd-even GMRES to 5e-2), "
-                               "fp64 FGMRES(50) to 1e-10 with the fp32 V-cycle, rhs=ones (BASELINE configs[4])")
+                               "fp64 FGMRES(10) to 1e-10 with the fp32 V-cycle, rhs=ones (BASELINE configs[4])")
             res["scaling"] = "strong"; res["n_gpus"] = world; res["transport"] = args.transport if world > 1 else None
             n1 = committed_n1_strong(G)
             if n1:

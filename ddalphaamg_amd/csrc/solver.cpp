@@ -325,9 +325,10 @@ int ddamg_hip_restrict(ddamg_hip_ctx* c, ddamg_hip_vec* coarse, const ddamg_hip_
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c && c->setup_done, "setup has not been run");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
-  check_vec(c, coarse, 1); check_vec(c, fine, 0);
-  if (c->mg32) c->mg32->restrict_to(0, (float*)coarse->data, (const float*)fine->data);
-  else c->mg64->restrict_to(0, (double*)coarse->data, (const double*)fine->data);
+  DDAMG_REQUIRE(fine && fine->level >= 0 && fine->level + 1 < c->par.num_levels, "restrict: no coarser level below this vector");
+  check_vec(c, coarse, fine->level + 1); check_vec(c, fine, fine->level);
+  if (c->mg32) c->mg32->restrict_to(fine->level, (float*)coarse->data, (const float*)fine->data);
+  else c->mg64->restrict_to(fine->level, (double*)coarse->data, (const double*)fine->data);
   DDAMG_API_END
 }
 
@@ -335,9 +336,10 @@ int ddamg_hip_interpolate(ddamg_hip_ctx* c, ddamg_hip_vec* fine, const ddamg_hip
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c && c->setup_done, "setup has not been run");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
-  check_vec(c, coarse, 1); check_vec(c, fine, 0);
-  if (c->mg32) c->mg32->interpolate(0, (float*)fine->data, (const float*)coarse->data, add != 0);
-  else c->mg64->interpolate(0, (double*)fine->data, (const double*)coarse->data, add != 0);
+  DDAMG_REQUIRE(fine && fine->level >= 0 && fine->level + 1 < c->par.num_levels, "interpolate: no coarser level below this vector");
+  check_vec(c, coarse, fine->level + 1); check_vec(c, fine, fine->level);
+  if (c->mg32) c->mg32->interpolate(fine->level, (float*)fine->data, (const float*)coarse->data, add != 0);
+  else c->mg64->interpolate(fine->level, (double*)fine->data, (const double*)coarse->data, add != 0);
   DDAMG_API_END
 }
 

@@ -1,11 +1,15 @@
 """GPU tests (-m gpu) of bench.py's output contract: one JSON line with the metric, the roofline object of the dominant kernel
-and (N = 1) the CPU baseline; and the N > 1 code path (domain decomposition, max-over-ranks timing) rehearsed with two
-processes on the one GPU through the host transport (RCCL refuses two ranks on one device)."""
-import json, os, subprocess, sys, socket
+and (N = 1) the CPU baseline; the N > 1 paths -- `bench.py --gpus 2` starting its own ranks, and the same under torchrun as the
+driver launches it -- rehearsed with two processes on the one GPU through the host transport (RCCL refuses two ranks on one
+device); and the failure behaviour: a rank that dies or hangs in the solve leg ends the job with a non-zero code, with the
+headline line still printed."""
+import json, os, subprocess, sys
 import pytest
+from launcher import torchrun
 
 pytestmark = pytest.mark.gpu
 REPO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+BENCH = os.path.join(REPO, "bench.py")
 
 
 def last_json_line(text):
@@ -14,13 +18,14 @@ def last_json_line(text):
     return json.loads(lines[0])
 
 
-def check_common(d, n_gpus, steps, warmup):
+def check_common(d, n_gpus, steps, warmup, sites_per_gpu=32 ** 4):
     assert d["metric"] == "fine_wilson_clover_gflops" and d["unit"] == "GFLOP/s" and d["higher_is_better"] is True
     assert (d["n_gpus"], d["steps"], d["warmup"]) == (n_gpus, steps, warmup)
+    assert d["config"]["ranks"] == n_gpus
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["dtype"] == "f32" and d["data"] == "synthetic"
     assert d["value"] > 0 and d["ms_per_step"] > 0 and "workload" in d["config"] and "model" not in d["config"]
     # value is the whole-job rate: flop per site x sites of all ranks / time per step
-    sites = 32 ** 4 * n_gpus
+    sites = sites_per_gpu * n_gpus
     assert abs(d["value"] - d["config"]["flop_per_site"] * sites / (d["ms_per_step"] * 1e-3) / 1e9) < 1e-6 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
@@ -28,22 +33,56 @@ def check_common(d, n_gpus, steps, warmup):
 
 
 def test_single_gpu_line():
-    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--steps", "50", "--warmup", "10", "--no-solve"],
-                       capture_output=True, text=True, timeout=600, cwd=REPO)
+    r = subprocess.run([sys.executable, BENCH, "--steps", "50", "--warmup", "10", "--no-strong"],
+                       capture_output=True, text=True, timeout=900, cwd=REPO)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     d = last_json_line(r.stdout)
     check_common(d, 1, 50, 10)
     assert d["roofline"]["frac"] > 0.4                       # north-star target: >= 40 % of the HBM roofline at 32^4
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
+    s = d["solve"]
+    assert s["true_relres"] < 1e-10 and s["seconds_per_solve"] > 0
+    if "iterations_reference" in s:                          # the reference's run of the same 32^4 case (committed fixture)
+        assert abs(s["iterations"] - s["iterations_reference"]) <= 1
+    if c["kind"] == "reference":
+        assert c["solve"]["seconds"] > 0 and c["solve"]["iterations"] > 0 and c["solve"]["kind"] == "reference"
 
 
-def test_two_processes_through_the_host_transport():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--transport", "host", "--no-cpu-baseline", "--no-solve"]
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=REPO, env=dict(os.environ, OMP_NUM_THREADS="1"))
+SMALL = ["--lattice", "16", "16", "16", "16", "--strong-lattice", "16", "16", "16", "16", "--steps", "5", "--warmup", "2",
+         "--transport", "host", "--no-cpu-baseline"]
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher on the command line: two ranks, the strong-scaling solve on one global lattice"""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + SMALL, capture_output=True, text=True, timeout=900, cwd=REPO,
+                       env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = last_json_line(r.stdout)
+    check_common(d, 2, 5, 2, 16 ** 4)
+    assert "process grid 2x1x1x1" in d["config"]["parallelism"]
+    s = d["strong_scaling"]
+    assert s["n_gpus"] == 2 and s["scaling"] == "strong" and s["true_relres"] < 1e-10 and 8 <= s["iterations"] <= 20
+    assert "16x16x16x16" in s["workload"] and "local 8x16x16x16" in s["workload"]
+
+
+def test_two_processes_under_torchrun():
+    """the driver's form: torchrun starts the ranks, bench.py checks --gpus against the world size"""
+    r = torchrun(2, BENCH, "--gpus", "2", "--steps", "5", "--warmup", "2", "--transport", "host", "--no-cpu-baseline", "--no-strong",
+                 timeout=900, cwd=REPO)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     d = last_json_line(r.stdout)
     check_common(d, 2, 5, 2)
-    assert "process grid 2x1x1x1" in d["config"]["parallelism"]
+    r = torchrun(2, BENCH, "--gpus", "4", "--no-strong", "--transport", "host", timeout=300, cwd=REPO)
+    assert r.returncode != 0 and "--gpus 4 but the launcher started 2" in (r.stdout + r.stderr)
+
+
+@pytest.mark.parametrize("fault,extra", [("DDAMG_BENCH_FAIL_RANK", []), ("DDAMG_BENCH_HANG_RANK", ["--leg-timeout", "20"])])
+def test_failed_or_hung_rank_gives_nonzero_exit_and_keeps_the_headline(fault, extra):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env[fault] = "1"
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2"] + SMALL + extra, capture_output=True, text=True, timeout=600, cwd=REPO, env=env)
+    assert r.returncode != 0, r.stdout[-2000:]
+    d = last_json_line(r.stdout)
+    check_common(d, 2, 5, 2, 16 ** 4)
+    assert "error" in d["strong_scaling"]

@@ -2,7 +2,7 @@
 Wilson-Clover operator on the GPU with 2 and 4 processes (host transport; all on one card).
 Reference: ghost_sendrecv / d_plus_clover boundary phases, src/ghost_generic.c:152-330,
 src/dirac_generic.c:178-262; process grid src/data_layout.c:23-60."""
-import os, subprocess, sys, socket
+import os, subprocess, sys
 import numpy as np
 import pytest
 from ddalphaamg_amd import api, dist as ddist
@@ -10,21 +10,9 @@ from ddalphaamg_amd import api, dist as ddist
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def free_port():
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
-    return p
-
-
 def launch(nproc, *args, timeout=300):
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
-           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
-           os.path.join(HERE, "dist_worker.py"), *args]
-    env = dict(os.environ, OMP_NUM_THREADS="1")
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
-    if r.returncode != 0 and any(k in r.stderr for k in ("Address already in use", "EADDRINUSE", "RendezvousConnectionError", "RendezvousTimeoutError")):
-        # the port found by free_port() was taken between the probe and torchrun's bind: once more on another one
-        cmd[cmd.index("--master-port") + 1] = str(free_port())
-        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env)
+    from launcher import torchrun
+    r = torchrun(nproc, os.path.join(HERE, "dist_worker.py"), *args, timeout=timeout)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "DIST_WORKER_OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
     return r.stdout
