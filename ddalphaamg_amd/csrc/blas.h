@@ -40,9 +40,22 @@ struct ReduceWork {
   double* d_coef = nullptr;     // [2*max_m] coefficients uploaded from the host
   double* h_coef = nullptr;     // pinned
   int max_m = 0, max_blocks = 0;
+  // read-back without a copy engine in the way: the last kernel of a Krylov step writes its few numbers straight into
+  // h_result (pinned, device-visible) and then a sequence number; the host spins on the sequence number.  A DMA copy plus
+  // hipStreamSynchronize costs ~19 us per Arnoldi step, which is 7 % of a 32^4 solve (one step of the coarsest level is
+  // ~150 us of kernels).
+  unsigned long long* h_seq = nullptr;   // pinned
+  unsigned long long seq = 0;
   void init(int max_m_);
   void destroy();
 };
+// h_result[0..n) <- d_src[0..n), visible to the host once wait_published returns (enqueued on st; n <= 2*max_m + 8)
+void publish_to_host(const double* d_src, int n, ReduceWork& rw, hipStream_t st);
+void wait_published(ReduceWork& rw, hipStream_t st);
+// d_coef[0..n) <- h_coef[0..n) by a one-block kernel reading the pinned buffer (no copy engine).  h_coef may be rewritten
+// by the host after the next wait_published on the same stream has returned: the stream is in order, so that read-back
+// can only arrive after this upload has run.
+void upload_coefficients(ReduceWork& rw, int n, hipStream_t st);
 
 template <typename T> void vec_zero(T* x, View v, hipStream_t st);
 // x[i] = uniform(-0.5, 0.5) from a counter-based generator (splitmix64 of seed, stream, i); n reals

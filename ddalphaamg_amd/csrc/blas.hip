@@ -21,6 +21,8 @@ void ReduceWork::init(int max_m_) {
   DDAMG_HIP_CHECK(hipHostMalloc(&h_result, sizeof(double) * (2 * max_m + 8), hipHostMallocDefault));
   DDAMG_HIP_CHECK(device_alloc(&d_coef, sizeof(double) * (2 * max_m + 8)));
   DDAMG_HIP_CHECK(hipHostMalloc(&h_coef, sizeof(double) * (2 * max_m + 8), hipHostMallocDefault));
+  DDAMG_HIP_CHECK(hipHostMalloc(&h_seq, sizeof(unsigned long long), hipHostMallocDefault));
+  *h_seq = 0; seq = 0;
 }
 void ReduceWork::destroy() {
   if (d_partial) (void)hipFree(d_partial);
@@ -28,7 +30,50 @@ void ReduceWork::destroy() {
   if (h_result) (void)hipHostFree(h_result);
   if (d_coef) (void)hipFree(d_coef);
   if (h_coef) (void)hipHostFree(h_coef);
-  d_partial = d_result = h_result = d_coef = h_coef = nullptr;
+  if (h_seq) (void)hipHostFree(h_seq);
+  d_partial = d_result = h_result = d_coef = h_coef = nullptr; h_seq = nullptr;
+}
+
+__global__ __launch_bounds__(64) void publish_kernel(const double* __restrict__ src, int n, double* __restrict__ hdst,
+                                                      unsigned long long* __restrict__ hseq, unsigned long long seq) {
+  for (int i = threadIdx.x; i < n; i += 64) __hip_atomic_store(&hdst[i], src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(hseq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void publish_to_host(const double* d_src, int n, ReduceWork& rw, hipStream_t st) {
+  static const bool dma = getenv("DDAMG_READBACK_DMA") != nullptr;   // the copy-engine form, for comparison
+  if (dma) { DDAMG_HIP_CHECK(hipMemcpyAsync(rw.h_result, d_src, sizeof(double) * n, hipMemcpyDeviceToHost, st)); return; }
+  rw.seq++;
+  hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(64), 0, st, d_src, n, rw.h_result, rw.h_seq, rw.seq);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+__global__ __launch_bounds__(64) void upload_kernel(double* __restrict__ dst, const double* __restrict__ hsrc, int n) {
+  for (int i = threadIdx.x; i < n; i += 64) dst[i] = __hip_atomic_load(&hsrc[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+void upload_coefficients(ReduceWork& rw, int n, hipStream_t st) {
+  static const bool dma = getenv("DDAMG_READBACK_DMA") != nullptr;
+  if (dma) {
+    DDAMG_HIP_CHECK(hipMemcpyAsync(rw.d_coef, rw.h_coef, sizeof(double) * n, hipMemcpyHostToDevice, st));
+    DDAMG_HIP_CHECK(hipStreamSynchronize(st));   // h_coef is free again
+    return;
+  }
+  hipLaunchKernelGGL(upload_kernel, dim3(1), dim3(64), 0, st, rw.d_coef, rw.h_coef, n);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+void wait_published(ReduceWork& rw, hipStream_t st) {
+  static const bool dma = getenv("DDAMG_READBACK_DMA") != nullptr;
+  if (dma) { DDAMG_HIP_CHECK(hipStreamSynchronize(st)); return; }
+  volatile unsigned long long* p = rw.h_seq;
+  unsigned long long spins = 0;
+  while (__atomic_load_n(p, __ATOMIC_ACQUIRE) != rw.seq) {
+    __builtin_ia32_pause();
+    if ((++spins & 0xfffffull) == 0) {   // every ~million spins: has the stream died?
+      hipError_t e = hipStreamQuery(st);
+      if (e == hipSuccess) { if (__atomic_load_n(p, __ATOMIC_ACQUIRE) == rw.seq) break; DDAMG_REQUIRE(false, "read-back: the stream is idle but the result never arrived"); }
+      if (e != hipErrorNotReady) DDAMG_HIP_CHECK(e);
+    }
+  }
 }
 
 // ---- chunk addressing --------------------------------------------------------------------

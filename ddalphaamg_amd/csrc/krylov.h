@@ -84,8 +84,8 @@ struct Gmres {
         vec_minus<T>(r, b, w, view, st);
       }
       vec_norm<T>(r, view, *rw, rw->d_result, st);
-      DDAMG_HIP_CHECK(hipMemcpyAsync(rw->h_result, rw->d_result, sizeof(double), hipMemcpyDeviceToHost, st));
-      DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+      publish_to_host(rw->d_result, 1, *rw, st);
+      wait_published(*rw, st);
       const double gamma0 = rw->h_result[0];
       gamma[0] = gamma0;
       if (ol == 0) norm_r0 = gamma0;
@@ -120,8 +120,8 @@ struct Gmres {
     op(w, x);
     vec_minus<T>(r, b, w, view, st);
     vec_norm<T>(r, view, *rw, rw->d_result, st);
-    DDAMG_HIP_CHECK(hipMemcpyAsync(rw->h_result, rw->d_result, sizeof(double), hipMemcpyDeviceToHost, st));
-    DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+    publish_to_host(rw->d_result, 1, *rw, st);
+    wait_published(*rw, st);
     return rw->h_result[0] / norm_r0;
   }
 
@@ -145,9 +145,9 @@ struct Gmres {
       vec_multi_dot<T>(Vb, vstride, j + 2, w, view, *rw, dh, st);     // <V_0..V_j, w> and <w, w>
       arnoldi_norm_from_dots(dh, j + 1, st);
       vec_multi_axpy_dev<T>(w, Vb, vstride, j + 1, dh, -1.0, view, st);
+      publish_to_host(dh, 2 * (j + 1) + 1, *rw, st);
       vec_scale_inv_dev<T>(w, w, dh + 2 * (j + 1), view, st);
-      DDAMG_HIP_CHECK(hipMemcpyAsync(rw->h_result, dh, sizeof(double) * (2 * (j + 1) + 1), hipMemcpyDeviceToHost, st));
-      DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+      wait_published(*rw, st);
       cd* Hj = &H[(size_t)j * (restart_length + 2)];
       for (int i = 0; i <= j; i++) Hj[i] = cd(rw->h_result[2 * i], rw->h_result[2 * i + 1]);
       Hj[j + 1] = rw->h_result[2 * (j + 1)];
@@ -156,9 +156,9 @@ struct Gmres {
     vec_multi_dot<T>(Vb, vstride, j + 1, w, view, *rw, dh, st);
     vec_multi_axpy_dev<T>(w, Vb, vstride, j + 1, dh, -1.0, view, st);
     vec_norm<T>(w, view, *rw, dh + 2 * (j + 1), st);
-    vec_scale_inv_dev<T>(V(j + 1), w, dh + 2 * (j + 1), view, st);
-    DDAMG_HIP_CHECK(hipMemcpyAsync(rw->h_result, dh, sizeof(double) * (2 * (j + 1) + 1), hipMemcpyDeviceToHost, st));
-    DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+    publish_to_host(dh, 2 * (j + 1) + 1, *rw, st);     // the column is complete before the new vector is scaled:
+    vec_scale_inv_dev<T>(V(j + 1), w, dh + 2 * (j + 1), view, st);   // the host's Givens update overlaps with this kernel
+    wait_published(*rw, st);
     cd* Hj = &H[(size_t)j * (restart_length + 2)];
     for (int i = 0; i <= j; i++) Hj[i] = cd(rw->h_result[2 * i], rw->h_result[2 * i + 1]);
     Hj[j + 1] = rw->h_result[2 * (j + 1)];
@@ -187,11 +187,13 @@ struct Gmres {
       y[i] /= H[(size_t)i * ld + i];
     }
     for (int i = 0; i <= j; i++) { rw->h_coef[2 * i] = y[i].real(); rw->h_coef[2 * i + 1] = y[i].imag(); }
-    DDAMG_HIP_CHECK(hipMemcpyAsync(rw->d_coef, rw->h_coef, sizeof(double) * 2 * (j + 1), hipMemcpyHostToDevice, st));
+    // INVARIANT (h_coef): the host writes h_coef only here, and between two calls on one ReduceWork there is always a
+    // wait_published on this stream (the norm at the start of the next restart cycle or of the next solve), which cannot
+    // return before the upload kernel enqueued below has run -- the stream is in order.  So no synchronisation is needed
+    // here, and the solution update overlaps with whatever the caller enqueues next.
+    upload_coefficients(*rw, 2 * (j + 1), st);
     if (!ol) vec_zero<T>(x, view, st);
     vec_multi_axpy_dev<T>(x, basis, vstride, j + 1, rw->d_coef, 1.0, view, st);
-    // h_coef is reused by the next restart cycle: make sure the upload has been consumed
-    DDAMG_HIP_CHECK(hipStreamSynchronize(st));
   }
 };
 

@@ -717,7 +717,7 @@ void SapSmoother<T>::launch(int color, int mode, unsigned skip_mask, const T* et
       p.faces_x_out = (face_out & 2) ? faces_x_ : nullptr;
       const bool dist = op_->distributed();
       if (dist && p.mode != MODE_NONE) {
-        op_->halo_begin(p.mode == MODE_FULLRES ? pio_.res_src : latest, st);
+        op_->halo_begin(p.mode == MODE_FULLRES ? pio_.halo_src : latest, st);
         p.blocks = d_color_blocks_[color]; p.nblocks = ncol_interior_[color];
         sap_pair_launch(p, true, st);
         op_->halo_finish(st);
@@ -777,7 +777,7 @@ void SapSmoother<T>::smooth(T* phi, T* Dphi, const T* eta, int cycles, int res, 
   // production path: no copies -- the first visit of a block reads the caller's phi (or nothing) and eta, the last one writes
   // the caller's phi; every site is visited exactly once per sweep
   const bool direct = pair_ && cycles >= 1 && (schedule_ == RED_BLACK || schedule_ == TWO_COLOR);
-  pio_.x_in = x; pio_.x_out = x; pio_.r_in = r; pio_.res_src = x;
+  pio_.x_in = x; pio_.x_out = x; pio_.r_in = r; pio_.res_src = x; pio_.halo_src = x;
   if (direct) {
   } else if (res == NO_RES) {
     vec_copy<T>(r, eta, all, st);
@@ -816,6 +816,9 @@ void SapSmoother<T>::smooth(T* phi, T* Dphi, const T* eta, int cycles, int res, 
         pio_.x_out = k == cycles - 1 ? phi : x;
         pio_.r_in = (k == 0 && init_res == NO_RES) ? eta : r;
         pio_.res_src = phi;
+        // across a process boundary the full residual of the second colour couples to the first colour's UPDATED iterate,
+        // which the first launch wrote to x_out
+        pio_.halo_src = color == 0 ? phi : (cycles == 1 ? phi : x);
       }
       const T* xsrc = direct ? phi : x;
       if constexpr (sizeof(T) == 4) {

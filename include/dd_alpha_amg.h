@@ -1,4 +1,24 @@
 /*
+ * Interface declarations (struct fields, prototypes, include guards) follow the DDalphaAMG solver library:
+ * Copyright (C) 2016, Matthias Rottmann, Artur Strebel, Simon Heybrock, Simone Bacchio, Bjoern Leder, Issaku Kanamori.
+ *
+ * The DDalphaAMG solver library is free software: you can redistribute it and/or modify
+ * it under the terms of the GNU General Public License as published by
+ * the Free Software Foundation, either version 3 of the License, or
+ * (at your option) any later version.
+ *
+ * The DDalphaAMG solver library is distributed in the hope that it will be useful,
+ * but WITHOUT ANY WARRANTY; without even the implied warranty of
+ * MERCHANTABILITY or FITNESS FOR A PARTICULAR PURPOSE.  See the
+ * GNU General Public License for more details.
+ *
+ * You should have received a copy of the GNU General Public License
+ * along with the DDalphaAMG solver library. If not, see http://www.gnu.org/licenses/.
+ *
+ * This header reproduces that interface so that the MI355X implementation in this repository drops in behind it; the
+ * implementation itself is new code, distributed under the same licence (see LICENSE at the repository root).
+ */
+/*
  * dd_alpha_amg.h -- the DDalphaAMG library interface, served by the MI355X implementation.
  *
  * Same names, argument meaning, struct layout and error behaviour as the reference's
@@ -6,8 +26,10 @@
  * libddamg_hip.so instead.  All entry points are thin glue over include/ddamg_hip.h.
  *
  * Differences that a caller can observe:
- *  - one process drives one GPU; the lattice of that process is the whole lattice unless the
- *    multi-GPU layer is initialised (global == local lattice is asserted otherwise);
+ *  - one process drives one GPU.  When the global and the local lattice of the parameter block differ, the process grid is
+ *    global / local as in the reference (src/init.c:455-520) and the library builds its Cartesian communicator over
+ *    MPI_COMM_WORLD itself (libddamg_hip_mpi.so; the host application has called MPI_Init, as with the reference);
+ *    halo exchange over RCCL, or staged through MPI with DDAMG_HIP_TRANSPORT=host;
  *  - bc == 0 (open/Dirichlet boundaries, two gauge fields) is rejected with a fatal error;
  *  - the *_external_threading variants ignore core/thread ids and barriers: there is no host
  *    threading on the GPU path (every calling thread but thread 0 of core 0 returns at once).

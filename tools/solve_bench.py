@@ -59,7 +59,7 @@ def main():
         U = near_unit_gauge(V, args.eps, 20260101)
     else:
         sys.path.insert(0, REPO)
-        from bench import synth_gauge
+        from bench import synth_gauge_random as synth_gauge
         U = synth_gauge(V, 20260101)
     t1 = time.time()
     plaq = ctx.set_gauge(U, anti_pbc=True); t2 = time.time()
