@@ -143,6 +143,8 @@ def _io():
         lib.ddamg_hip_conf_info.argtypes = [cs, ctypes.c_int, ip, dp]
         lib.ddamg_hip_read_conf.argtypes = [cs, ip, ip, ip, ctypes.c_int, dp, dp]
         lib.ddamg_hip_write_conf.argtypes = [cs, ip, ip, ip, ctypes.c_int, dp, ctypes.c_double]
+        lib.ddamg_hip_read_conf_multi.argtypes = [cs, ip, ip, ip, ctypes.c_int, dp, dp]
+        lib.ddamg_hip_write_conf_multi.argtypes = [cs, ip, ip, ip, ctypes.c_int, dp, ctypes.c_double]
         lib.ddamg_hip_read_vectors.argtypes = [cs, ip, ip, ip, ctypes.c_int, ctypes.c_int, dp]
         lib.ddamg_hip_write_vectors.argtypes = [cs, ip, ip, ip, ctypes.c_int, ctypes.c_int, ctypes.POINTER(VectorHeader), dp]
         lib._io_ready = True
@@ -176,6 +178,19 @@ def read_conf(path, global_lattice, process_grid=(1, 1, 1, 1), process_coords=(0
 def write_conf(path, global_lattice, gauge_local, plaq, process_grid=(1, 1, 1, 1), process_coords=(0, 0, 0, 0), big_endian=False):
     a = np.ascontiguousarray(gauge_local, dtype=np.float64)
     _io_check(_io().ddamg_hip_write_conf(os.fsencode(path), _i4(global_lattice), _i4(process_grid), _i4(process_coords), int(big_endian), _dp(a), float(plaq)))
+
+
+def read_conf_multi(base, global_lattice, process_grid, process_coords, big_endian=False):
+    """this process's file of a multi-file configuration (read_conf_multi, src/io.c:566-668): <base>.pt<T>pz<Z>py<Y>px<X>"""
+    Vloc = int(np.prod([g // max(p, 1) for g, p in zip(global_lattice, process_grid)]))
+    out = np.zeros((Vloc, 4, 9, 2)); plaq = ctypes.c_double(0)
+    _io_check(_io().ddamg_hip_read_conf_multi(os.fsencode(base), _i4(global_lattice), _i4(process_grid), _i4(process_coords), int(big_endian), _dp(out), ctypes.byref(plaq)))
+    return out, plaq.value
+
+
+def write_conf_multi(base, global_lattice, gauge_local, plaq, process_grid, process_coords, big_endian=False):
+    a = np.ascontiguousarray(gauge_local, dtype=np.float64)
+    _io_check(_io().ddamg_hip_write_conf_multi(os.fsencode(base), _i4(global_lattice), _i4(process_grid), _i4(process_coords), int(big_endian), _dp(a), float(plaq)))
 
 
 def read_vectors(path, global_lattice, n=1, process_grid=(1, 1, 1, 1), process_coords=(0, 0, 0, 0), big_endian=False):

@@ -155,6 +155,57 @@ int ddamg_hip_read_conf(const char* path, const int G[4], const int P[4], const 
   return rc;
 }
 
+// read_conf_multi (src/io.c:566-668): one file per process of the grid, named <base>.pt<T>pz<Z>py<Y>px<X>; each file holds the
+// header of the GLOBAL lattice (extents asserted against it, :619-620; the plaquette must agree between the files, :630-632)
+// followed by that process's links in its local lexicographic order
+static std::string multi_name(const char* base, const int C[4]) {
+  char post[128];
+  snprintf(post, sizeof post, ".pt%dpz%dpy%dpx%d", C[0], C[1], C[2], C[3]);
+  return std::string(base) + post;
+}
+
+int ddamg_hip_read_conf_multi(const char* base, const int G[4], const int P[4], const int C[4], int big_endian, double* gauge_local, double* plaq_out) {
+  Part p;
+  if (!make_part(G, P, C, p)) return fail("read_conf_multi: process grid does not divide the lattice / coordinates outside the grid");
+  const std::string path = multi_name(base, C);
+  int dims[4]; double plaq;
+  if (ddamg_hip_conf_info(path.c_str(), big_endian, dims, &plaq)) return -1;
+  for (int mu = 0; mu < 4; mu++)
+    if (dims[mu] != G[mu]) return fail("configuration part '%s' belongs to a %dx%dx%dx%d lattice, expected %dx%dx%dx%d (T,Z,Y,X)", path.c_str(), dims[0], dims[1], dims[2], dims[3], G[0], G[1], G[2], G[3]);
+  int fd = open(path.c_str(), O_RDONLY);
+  if (fd < 0) return fail("cannot open configuration part '%s'", path.c_str());
+  const size_t n = p.Vloc * 72;
+  const off_t size = lseek(fd, 0, SEEK_END);
+  int rc = 0;
+  if (size != (off_t)(CONF_HEADER + n * sizeof(double))) rc = fail("configuration part '%s' has %lld bytes, a %dx%dx%dx%d part has %lld", path.c_str(), (long long)size, p.L[0], p.L[1], p.L[2], p.L[3], (long long)(CONF_HEADER + n * sizeof(double)));
+  else if (pread_all(fd, gauge_local, n * sizeof(double), (off_t)CONF_HEADER)) rc = fail("configuration part '%s' ends early", path.c_str());
+  close(fd);
+  if (rc == 0 && big_endian) swap8(gauge_local, n);
+  if (rc == 0 && plaq_out) *plaq_out = plaq;
+  return rc;
+}
+
+int ddamg_hip_write_conf_multi(const char* base, const int G[4], const int P[4], const int C[4], int big_endian, const double* gauge_local, double plaq) {
+  Part p;
+  if (!make_part(G, P, C, p)) return fail("write_conf_multi: process grid does not divide the lattice / coordinates outside the grid");
+  const std::string path = multi_name(base, C);
+  int fd = open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+  if (fd < 0) return fail("cannot create '%s'", path.c_str());
+  int32_t dims[4] = {G[0], G[1], G[2], G[3]}; double pl = plaq;
+  if (big_endian) { swap4(dims, 4); swap8(&pl, 1); }
+  const size_t n = p.Vloc * 72;
+  int rc = 0;
+  if (pwrite_all(fd, dims, sizeof dims, 0) || pwrite_all(fd, &pl, sizeof pl, sizeof dims)) rc = fail("write to '%s' failed", path.c_str());
+  if (rc == 0) {
+    std::vector<double> tmp;
+    const double* src = gauge_local;
+    if (big_endian) { tmp.assign(gauge_local, gauge_local + n); swap8(tmp.data(), n); src = tmp.data(); }
+    if (pwrite_all(fd, src, n * sizeof(double), (off_t)CONF_HEADER)) rc = fail("write to '%s' failed", path.c_str());
+  }
+  close(fd);
+  return rc;
+}
+
 int ddamg_hip_write_conf(const char* path, const int G[4], const int P[4], const int C[4], int big_endian, const double* gauge_local, double plaq) {
   Part p;
   if (!make_part(G, P, C, p)) return fail("write_conf: process grid does not divide the lattice / coordinates outside the grid");

@@ -6,7 +6,8 @@
  *   vector_io (_READ / _WRITE)      src/io.c:704-846   one spinor, optional text header, lexicographic sites
  *   vector_io_single_file           src/io.c:951-1124  n spinors behind one header (test vectors: setup persistence)
  *   write_header                    src/io.c:671-702
- * Not covered: read_conf_multi (one file per process of a former run, src/io.c:566-668), the LIME/HDF5 builds.
+ *   read_conf_multi                 src/io.c:566-668   one file per process of the grid, <base>.pt<T>pz<Z>py<Y>px<X>
+ * Not covered: the LIME/HDF5 builds.
  *
  * Layouts (all little endian unless `big_endian` is set, the reference's -DBIG_ENDIAN_CNFG / -DBIG_ENDIAN_TV builds):
  *   configuration: int32 T,Z,Y,X ; double plaquette ; then for t,z,y,x (x fastest): 4 directions (T,Z,Y,X) x 3x3 complex
@@ -33,6 +34,14 @@ int ddamg_hip_read_conf(const char* path, const int global_lattice[4], const int
 /* the same layout written out (single file; every process writes its own rows, the process at the origin the header) */
 int ddamg_hip_write_conf(const char* path, const int global_lattice[4], const int process_grid[4], const int process_coords[4],
                          int big_endian, const double* gauge_local, double plaq);
+
+/* read_conf_multi (src/io.c:566-668): the part of the process at process_coords from the file <base>.pt<T>pz<Z>py<Y>px<X>, which
+ * carries the header of the global lattice and that process's links in local lexicographic order; the writer is its inverse
+ * (every process writes its own file). */
+int ddamg_hip_read_conf_multi(const char* base, const int global_lattice[4], const int process_grid[4], const int process_coords[4],
+                              int big_endian, double* gauge_local, double* plaq_out);
+int ddamg_hip_write_conf_multi(const char* base, const int global_lattice[4], const int process_grid[4], const int process_coords[4],
+                               int big_endian, const double* gauge_local, double plaq);
 
 /* fields of write_header; strings may be NULL (written as empty) */
 typedef struct ddamg_hip_vector_header {

@@ -109,3 +109,27 @@ def test_single_spinor_with_and_without_header(tmp_path):
         api.read_vectors(tmp_path / "bare", L, 2)
     with pytest.raises(api.DDAMGError, match="fewer than 3 vectors"):
         api.read_vectors(tmp_path / "hdr", L, 3)
+
+
+@pytest.mark.parametrize("big_endian", [False, True])
+@pytest.mark.parametrize("P", GRIDS[1:])
+def test_multi_file_configuration(tmp_path, conf4, P, big_endian):
+    """read_conf_multi (src/io.c:566-668): one file per process, named <base>.pt<T>pz<Z>py<Y>px<X>, each with the header of the
+    GLOBAL lattice followed by the process's own links; byte layout checked against the single-file format"""
+    L, U, plaq = conf4
+    base = str(tmp_path / "conf")
+    Vloc = int(np.prod(L)) // int(np.prod(P))
+    for C in grid_coords(P):
+        api.write_conf_multi(base, L, ddist.local_part(U, L, list(P), C), plaq, P, C, big_endian)
+        name = base + ".pt%dpz%dpy%dpx%d" % tuple(C)
+        assert os.path.getsize(name) == 16 + 8 + Vloc * 72 * 8
+        assert api.conf_info(name, big_endian) == (L, plaq)      # header of the global lattice in every part
+        raw = np.fromfile(name, dtype=">f8" if big_endian else "<f8", offset=24)
+        assert np.array_equal(raw, ddist.local_part(U, L, list(P), C).ravel())
+    for C in grid_coords(P):
+        part, pl = api.read_conf_multi(base, L, P, C, big_endian)
+        assert pl == plaq and np.array_equal(part.reshape(len(part), -1), ddist.local_part(U, L, list(P), C))
+    with pytest.raises(api.DDAMGError):       # a part of another lattice
+        api.read_conf_multi(base, [L[0] * 2] + L[1:], P, grid_coords(P)[0], big_endian)
+    with pytest.raises(api.DDAMGError):       # a part of another decomposition (wrong size)
+        api.read_conf_multi(base, L, (1, 1, 1, 1), (0, 0, 0, 0), big_endian)
