@@ -59,9 +59,11 @@ int ddamg_hip_create(const ddamg_hip_params* p, ddamg_hip_ctx** out) {
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(p && out, "null argument");
   DDAMG_REQUIRE(p->num_levels >= 1 && p->num_levels <= DDAMG_HIP_MAX_LEVELS, "1 <= num_levels <= 4");
-  DDAMG_REQUIRE(p->method >= -1 && p->method <= 4, "method must be -1 (CGN), 0 (GMRES), 1/2/3 (additive / red-black / sixteen-colour SAP) or 4 (GMRES smoother); "
-                                                   "5 (BiCGstab) and 6 (g5D variant) of the reference are not implemented");
-  DDAMG_REQUIRE(p->method <= 0 || p->odd_even == 1, "only the odd-even preconditioned smoothers and coarsest-level solve are implemented (odd_even = 1)");
+  // the reference asserts -1 <= method <= 5 itself (src/init.c:982): its method-6 code (g5D_*) cannot be selected
+  DDAMG_REQUIRE(p->method >= -1 && p->method <= 5, "method must be -1 (CGN), 0 (GMRES), 1/2/3 (additive / red-black / sixteen-colour SAP), 4 (GMRES smoother) "
+                                                   "or 5 (FGMRES + BiCGstab, no AMG); the reference accepts no other value either (src/init.c:982)");
+  DDAMG_REQUIRE(p->method != 5 || p->mixed_precision != 2, "method 5 runs with mixed_precision 0 or 1 (ASSERT( g.mixed_precision != 2 ), src/preconditioner.c:66)");
+  DDAMG_REQUIRE(p->method != 5 || p->odd_even == 1, "method 5 is implemented on the odd-even Schur complement (odd_even = 1)");
   DDAMG_REQUIRE(p->mixed_precision >= 0 && p->mixed_precision <= 2, "mixed_precision must be 0, 1 or 2");
   int ndev = 0;
   DDAMG_HIP_CHECK(hipGetDeviceCount(&ndev));
@@ -132,6 +134,7 @@ int ddamg_hip_destroy(ddamg_hip_ctx* c) {
   if (c->outer_ready) { c->outer.release(); c->rw_outer.destroy(); }
   if (c->rw_blas_ready) c->rw_blas.destroy();
   if (c->mp_ready) { c->mp_inner.release(); c->rw_mp.destroy(); (void)hipFree(c->mp_x); (void)hipFree(c->mp_b); (void)hipFree(c->mp_r); }
+  if (c->bicg_ready) { c->bicg32.release(); c->bicg64.release(); }
   if (c->p32_in) (void)hipFree(c->p32_in);
   if (c->p32_out) (void)hipFree(c->p32_out);
   for (auto& lv : c->levels) if (lv->d_lex_of_site) (void)hipFree(lv->d_lex_of_site);

@@ -6,6 +6,7 @@
 #include "fine_op.h"
 #include "mg.h"
 #include "krylov.h"
+#include "bicgstab.h"
 #include "../../include/ddamg_hip.h"
 #include <vector>
 #include <memory>
@@ -65,6 +66,10 @@ struct ddamg_hip_ctx {
   ddamg::ReduceWork rw_mp;
   bool mp_ready = false;
   double *mp_x = nullptr, *mp_b = nullptr, *mp_r = nullptr;
+  // method 5: FGMRES preconditioned by BiCGstab on the odd-even Schur complement of the fine operator, no multigrid
+  ddamg::OddEvenBicgstab<float> bicg32;
+  ddamg::OddEvenBicgstab<double> bicg64;
+  bool bicg_ready = false;
   // results of the last solve
   int last_iter = 0, last_coarse_iter = 0;
   double last_relres = 0;

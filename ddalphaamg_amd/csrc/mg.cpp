@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <vector>
+#include <algorithm>
 
 namespace ddamg {
 
@@ -36,19 +37,19 @@ Multigrid<T>::Multigrid(const ddamg_hip_params& par, const std::vector<const Geo
       if (par.method == 4) {
         // smoother = GMRES on the odd-even Schur complement of this level (schwarz_PRECISION_alloc, src/schwarz_generic.c:78-83:
         // restart length block_iter, tolerance EPS_PRECISION, no preconditioner; the V-cycle sets the number of restarts)
-        DDAMG_REQUIRE(par.odd_even == 1, "the GMRES smoother is implemented on the odd-even preconditioned operator (odd_even = 1)");
         for (int i = 0; i < 3; i++) { DDAMG_HIP_CHECK(device_alloc(&lv.sbuf[i], sizeof(T) * lv.nel)); DDAMG_HIP_CHECK(device_zero(lv.sbuf[i], sizeof(T) * lv.nel)); }
         lv.srw.init(par.block_iter[d] + 8);
         lv.sgm.alloc(lv.nel, par.block_iter[d], false);
         lv.sgm.tol = sizeof(T) == 4 ? 1e-6 : 1e-14;
         // fine level: the Krylov vectors live on the even sites, which the site order keeps as the first half of every
         // Schwarz block -- a strided view (one row per 16-byte chunk row and block), so that no BLAS-1 pass touches the odd half
-        lv.sgm.view = (d == 0 && g.block_even_sites * 2 == g.block_sites)
+        lv.sgm.view = (par.odd_even && d == 0 && g.block_even_sites * 2 == g.block_sites)
                           ? View{(24 / Chunk<T>::CH) * g.num_blocks, (size_t)g.block_sites * Chunk<T>::CH, 0, (size_t)g.block_even_sites * Chunk<T>::CH}
                           : whole(lv.nel);
         lv.sgm.st = st_; lv.sgm.rw = &lv.srw;
-        lv.sgm.op = [this, d](T* out, const T* in) { this->smoother_schur(d, out, in); };
-        if (d > 0) {
+        if (par.odd_even) lv.sgm.op = [this, d](T* out, const T* in) { this->smoother_schur(d, out, in); };
+        else lv.sgm.op = [this, d](T* out, const T* in) { this->apply_op(d, out, in); };   // GMRES on the operator itself (src/schwarz_generic.c:81-82)
+        if (d > 0 && par.odd_even) {
           std::vector<int> ps[2];
           for (int s = 0; s < g.V; s++) ps[g.parity[s]].push_back(s);
           for (int q = 0; q < 2; q++) {
@@ -58,7 +59,7 @@ Multigrid<T>::Multigrid(const ddamg_hip_params& par, const std::vector<const Geo
           }
         }
       }
-      if (d == 0) { if (par.method != 4) lv.fsap.setup(g, fop, par.block_iter[0], par.method, st_); lv.fip.alloc(g, *geoms[1], lv.nvec); }
+      if (d == 0) { if (par.method != 4) lv.fsap.setup(g, fop, par.block_iter[0], par.method, st_, par.odd_even != 0); lv.fip.alloc(g, *geoms[1], lv.nvec); }
       else { if (par.method != 4) lv.csap.setup(g, &lv.cop, par.block_iter[d], par.method, st_); lv.cip.alloc(g, *geoms[d + 1], lv.n, lv.nvec); }
       DDAMG_HIP_CHECK(device_alloc(&lv.d_agg_face, g.V));
       DDAMG_HIP_CHECK(hipMemcpy(lv.d_agg_face, g.agg_face.data(), g.V, hipMemcpyHostToDevice));
@@ -104,6 +105,12 @@ Multigrid<T>::Multigrid(const ddamg_hip_params& par, const std::vector<const Geo
       lv.gm.num_restart = par.coarse_restart;
       lv.gm.tol = par.coarse_tol;
       lv.gm.st = st_; lv.gm.rw = &lv.rw;
+      if (!par.odd_even) {
+        // GMRES on the whole coarsest operator (fgmres_PRECISION on apply_coarse_operator, src/init_generic.c:148-154)
+        lv.gm.view = whole(lv.nel);
+        lv.gm.op = [this, d](T* out, const T* in) { this->apply_op(d, out, in); };
+        continue;
+      }
       // odd-even preconditioning needs a bipartite lattice: even global extents (the reference's check, src/init.c:1012)
       for (int mu = 0; mu < 4; mu++)
         DDAMG_REQUIRE((g.L[mu] * g.P[mu]) % 2 == 0, "the coarsest lattice must have even global extents (odd-even preconditioning)");
@@ -209,6 +216,15 @@ void Multigrid<T>::gmres_smoother(int l, T* phi, const T* eta, int cycles, int r
   MGLevel<T>& lv = *lv_[l];
   const View all = whole(lv.nel);
   Gmres<T>& gm = lv.sgm;
+  if (!par_.odd_even) {
+    // l->sp.x = phi; l->sp.b = eta; fgmres( &(l->sp) ) with initial_guess_zero = res, num_restart = n (src/vcycle_generic.c:70-75)
+    vec_copy<T>(gm.b, eta, all, st_);
+    if (res == RES) vec_copy<T>(gm.x, phi, all, st_);
+    gm.num_restart = cycles; gm.initial_guess_zero = res == NO_RES;
+    gm.solve();
+    vec_copy<T>(phi, gm.x, all, st_);
+    return;
+  }
   T *t = lv.sbuf[0], *u = lv.sbuf[1], *rhs = lv.sbuf[2];
   // right-hand side: eta, or the residual eta - D phi when phi carries an iterate
   const T* b = eta;
@@ -265,6 +281,11 @@ int Multigrid<T>::coarse_solve() {
   MGLevel<T>& lv = *lv_.back();
   const int V = lv.g->V, Ve = V / 2;
   T *x = lv.gm.x, *b = lv.gm.b;
+  if (!par_.odd_even) {
+    const int it = lv.gm.solve();
+    coarse_iter_count += it;
+    return it;
+  }
   lv.cop.self_mul(x, b, Ve, V, true, st_);          // x_o = D_oo^-1 b_o
   lv.cop.hop(b, x, 0, Ve, +1.0, true, st_);         // b_e <- b_e - D_eo x_o
   int it = lv.gm.solve();                           // S x_e = b_e  to coarse_tol
@@ -335,9 +356,21 @@ void Multigrid<T>::random_vector(int l, T* dst) {
     vec_random<T>(dst, lv.nel, par_.rng_seed + 7919ull * (unsigned long long)lv.g->rank, rng_stream_++, st_);
     return;
   }
+  if (l == 0 && !par_.odd_even && ref_order0_.empty()) {
+    // without odd-even the reference's Schwarz layout of the fine level is lexicographic inside a block
+    // (src/schwarz_generic.c:449-486); ours keeps the parity split
+    const Geometry& g = *lv.g;
+    ref_order0_.resize(V);
+    for (int b = 0; b < g.num_blocks; b++) {
+      std::vector<std::pair<int, int>> o;
+      for (int i = 0; i < g.block_sites; i++) { const int s = b * g.block_sites + i; o.emplace_back(g.lex_of_site[s], s); }
+      std::sort(o.begin(), o.end());
+      for (int i = 0; i < g.block_sites; i++) ref_order0_[(size_t)b * g.block_sites + i] = o[i].second;
+    }
+  }
   std::vector<double> h((size_t)V * n * 2);
   for (int pos = 0; pos < V; pos++) {
-    const size_t site = l == 0 ? (size_t)pos : (size_t)lv.ref_order[pos];
+    const size_t site = l == 0 ? (ref_order0_.empty() ? (size_t)pos : (size_t)ref_order0_[pos]) : (size_t)lv.ref_order[pos];
     for (int d = 0; d < n; d++) {
       const double im = (double)(T)(((double)rand() / (double)RAND_MAX)) - 0.5;
       const double re = (double)(T)(((double)rand() / (double)RAND_MAX)) - 0.5;

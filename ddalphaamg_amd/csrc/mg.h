@@ -105,6 +105,7 @@ class Multigrid {
   T* cwork_ = nullptr;    // coarse work space (5 vectors of the largest coarse level)
 
   void schur(T* out, const T* in);
+  std::vector<int> ref_order0_;   // fine-level vector-loop order of the reference when odd_even == 0
   void smoother_schur(int l, T* out, const T* in);            // (apply_schur_complement / coarse_apply_schur_complement on level l)
   void gmres_smoother(int l, T* phi, const T* eta, int cycles, int res);
   double norm_of(int l, const T* v);

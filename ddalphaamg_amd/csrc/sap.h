@@ -34,7 +34,8 @@ class SapSmoother {
  public:
   ~SapSmoother();
   // method: 1 additive, 2 red-black, 3 sixteen colours (g.method of the reference, src/vcycle_generic.c:33-39)
-  void setup(const Geometry& g, const FineOp<T>* op, int block_iter, int method, hipStream_t st);
+  // odd_even == false: MinRes on the whole block instead of its even-site Schur complement (g.odd_even == 0)
+  void setup(const Geometry& g, const FineOp<T>* op, int block_iter, int method, hipStream_t st, bool odd_even = true);
   // phi = smoothed iterate after `cycles` red-black sweeps.  res==NO_RES: start from phi=0, r=eta;
   // res==RES: start from the given phi.  (Dphi output of the reference's mixed_precision==2 path is
   // produced when Dphi != nullptr.)
@@ -54,6 +55,7 @@ class SapSmoother {
   T* latest2_ = nullptr;                           // additive method: the other generation of block updates
   // production shape (fp32, 4^4 blocks, multiplicative schedules): two blocks per workgroup, block-boundary couplings through
   // face buffers (sap_pair.h).  faces_d_: projected faces of every block's latest update; faces_x_: of the iterate x
+  bool odd_even_ = true;
   bool pair_ = false;
   float4 *faces_d_ = nullptr, *faces_x_ = nullptr;
   unsigned char* d_frank_ = nullptr;

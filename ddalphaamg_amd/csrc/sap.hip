@@ -398,6 +398,98 @@ __device__ __forceinline__ void site_allreduce3(T& a, T& b, T& c, T* red) {
   }
 }
 
+// =================================================================================================
+// Block solve WITHOUT odd-even preconditioning (g.odd_even == 0): local_minres_PRECISION on block_d_plus_clover_PRECISION
+// (src/linsolve_generic.c:985-1029 with block_op = block_d_plus_clover, src/dirac_generic.c:83-154): MinRes on the whole
+// block, inner products over all of its sites.  One thread per site, the block's residual staged in LDS for the in-block
+// couplings.  A rarely used mode of the reference (its SSE build refuses it, src/init.c:969-974): kept simple.
+template <typename T, int BS, bool DIST>
+__global__ __launch_bounds__((BS < 64 ? 64 : BS)) void sap_plain_kernel(SapArgs<T> a) {
+  constexpr int NT = BS < 64 ? 64 : BS;
+  constexpr int BPW = NT / BS;
+  __shared__ T img[BPW * 24 * BS];
+  __shared__ T red[3 * (NT / 64) + 1];
+  const FineOpDev<T>& op = a.s.op;
+  const size_t V = op.V;
+  const int bw = threadIdx.x / BS, i = threadIdx.x % BS;
+  const int bslot = blockIdx.x * BPW + bw;
+  const bool active = bslot < a.nblocks;
+  const int blk = active ? a.blocks[bslot] : a.blocks[0];
+  const size_t base = (size_t)blk * BS, s = base + i;
+  T* im = img + bw * 24 * BS;
+  int nbl[8];
+  unsigned ext = 0;
+#pragma unroll
+  for (int d = 0; d < 8; d++) {
+    nbl[d] = a.s.blk_nb[d * BS + i];
+    if (nbl[d] < 0) ext |= 1u << d;
+  }
+  int mode = a.mode;
+  if ((a.skip_mask >> a.s.block_list[blk]) & 1u) mode = MODE_NONE;
+  T r[24];
+  if (mode == MODE_FULLRES) {
+    T xs[24], e[24], et[24];
+    load_site<T, 24>(a.res_src, V, s, xs);
+    clover_apply<T>(op.clover, V, s, xs, e);
+    ext_hops<T, DIST>(a.res_src, op, s, 0xffu, e);
+    load_site<T, 24>(a.eta, V, s, et);
+#pragma unroll
+    for (int k = 0; k < 24; k++) r[k] = et[k] - e[k];
+  } else {
+    load_site<T, 24>(a.r, V, s, r);
+    if (mode == MODE_NBOUNDARY && ext) {
+      T acc[24];
+#pragma unroll
+      for (int k = 0; k < 24; k++) acc[k] = 0;
+      ext_hops<T, DIST>(a.latest, op, s, ext, acc);
+#pragma unroll
+      for (int k = 0; k < 24; k++) r[k] -= acc[k];
+    }
+  }
+  if (!a.solve) {
+    if (active) store_site<T, 24>(a.r, V, s, r);
+    return;
+  }
+  T lphi[24];
+#pragma unroll
+  for (int k = 0; k < 24; k++) lphi[k] = 0;
+  for (int it = 0; it < a.s.block_iter; it++) {
+    __syncthreads();   // the image of the previous step has been read
+#pragma unroll
+    for (int c = 0; c < 24; c++) im[c * BS + i] = r[c];
+    __syncthreads();
+    T Dr[24];
+    clover_apply<T>(op.clover, V, s, r, Dr);
+    blk_hops<T, BS>(im, nbl, op, s, base, Dr);      // Dr -= couplings inside the block
+    T nr = 0, ni = 0, dn = 0;
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      nr += Dr[2 * k] * r[2 * k] + Dr[2 * k + 1] * r[2 * k + 1];
+      ni += Dr[2 * k] * r[2 * k + 1] - Dr[2 * k + 1] * r[2 * k];
+      dn += Dr[2 * k] * Dr[2 * k] + Dr[2 * k + 1] * Dr[2 * k + 1];
+    }
+    site_allreduce3<T, BS, NT>(nr, ni, dn, red);
+    T ar = 0, ai = 0;
+    if (fabs(dn) >= Eps<T>::v) { ar = nr / dn; ai = ni / dn; }
+#pragma unroll
+    for (int k = 0; k < 12; k++) {
+      lphi[2 * k]     += ar * r[2 * k] - ai * r[2 * k + 1];
+      lphi[2 * k + 1] += ar * r[2 * k + 1] + ai * r[2 * k];
+      r[2 * k]        -= ar * Dr[2 * k] - ai * Dr[2 * k + 1];
+      r[2 * k + 1]    -= ar * Dr[2 * k + 1] + ai * Dr[2 * k];
+    }
+  }
+  if (active) {
+    T xs[24];
+    load_site<T, 24>(a.x, V, s, xs);
+#pragma unroll
+    for (int k = 0; k < 24; k++) xs[k] += lphi[k];
+    store_site<T, 24>(a.x, V, s, xs);
+    store_site<T, 24>(a.latest_out, V, s, lphi);
+    store_site<T, 24>(a.r, V, s, r);
+  }
+}
+
 // out = C in with the resident clover matrix (two Hermitian 6x6 blocks, 72 reals)
 template <typename T>
 __device__ __forceinline__ void clover_reg(const T (&C)[72], const T (&in)[24], T (&out)[24]) {
@@ -585,7 +677,8 @@ SapSmoother<T>::~SapSmoother() {
 }
 
 template <typename T>
-void SapSmoother<T>::setup(const Geometry& g, const FineOp<T>* op, int block_iter, int method, hipStream_t st) {
+void SapSmoother<T>::setup(const Geometry& g, const FineOp<T>* op, int block_iter, int method, hipStream_t st, bool odd_even) {
+  odd_even_ = odd_even;
   op_ = op; V_ = g.V; BS_ = g.block_sites; HS_ = g.block_sites / 2; nblocks_ = g.num_blocks; block_iter_ = block_iter;
   DDAMG_REQUIRE(method >= 1 && method <= 3, "Schwarz smoother: method must be 1 (additive), 2 (red-black) or 3 (sixteen colours)");
   DDAMG_REQUIRE(g.block_even_sites * 2 == g.block_sites, "Schwarz blocks need as many even as odd sites (even block extents)");
@@ -634,7 +727,7 @@ void SapSmoother<T>::setup(const Geometry& g, const FineOp<T>* op, int block_ite
   }
   // production shape: paired-block kernel with face buffers (sap_pair.hip)
   if (g_sap_variant < 0) { const char* e = getenv("DDAMG_SAP_VARIANT"); g_sap_variant = e ? atoi(e) : 3; }
-  pair_ = sizeof(T) == 4 && BS_ == 256 && schedule_ != ADDITIVE && g_sap_variant == 3;
+  pair_ = sizeof(T) == 4 && BS_ == 256 && schedule_ != ADDITIVE && g_sap_variant == 3 && odd_even_;
   for (int mu = 0; mu < 4 && pair_; mu++) if (g.B[mu] != 4) pair_ = false;
   if (pair_) {
     // rank of every block site among the sites of its parity class on its face, in transverse lexicographic order: the
@@ -678,8 +771,24 @@ void SapSmoother<T>::setup(const Geometry& g, const FineOp<T>* op, int block_ite
   DDAMG_HIP_CHECK(hipStreamSynchronize(st));
 }
 
+static bool g_sap_plain = false;   // set per launch from the smoother: g.odd_even == 0
+
 template <typename T, int HS>
 static void launch_hs(const SapArgs<T>& a, hipStream_t st) {
+  if (g_sap_plain) {
+    if constexpr (2 * HS <= 256) {
+      constexpr int BS = 2 * HS;
+      constexpr int NT = BS < 64 ? 64 : BS;
+      constexpr int BPW = NT / BS;
+      const int grid = (a.nblocks + BPW - 1) / BPW;
+      if (a.s.op.halo) hipLaunchKernelGGL((sap_plain_kernel<T, BS, true>), dim3(grid), dim3(NT), 0, st, a);
+      else hipLaunchKernelGGL((sap_plain_kernel<T, BS, false>), dim3(grid), dim3(NT), 0, st, a);
+      DDAMG_HIP_CHECK(hipGetLastError());
+      return;
+    } else {
+      DDAMG_REQUIRE(false, "Schwarz blocks of more than 256 sites need odd_even = 1");
+    }
+  }
   if (g_sap_variant < 0) { const char* e = getenv("DDAMG_SAP_VARIANT"); g_sap_variant = e ? atoi(e) : 3; }
   // the resident-operator kernel addresses the operator through buffer descriptors (32-bit offsets, 2 GiB of records):
   // the largest field (72 reals per site) must stay below that, i.e. V < 7.4e6 sites in fp32 -- beyond it (e.g. 64^4 on
@@ -730,6 +839,7 @@ void SapSmoother<T>::launch(int color, int mode, unsigned skip_mask, const T* et
       return;
     }
   }
+  g_sap_plain = !odd_even_;
   SapArgs<T> a;
   a.s.op = op_->dev(); a.s.blk_nb = d_blk_nb_; a.s.block_list = d_block_list_;
   a.s.block_sites = BS_; a.s.half_sites = HS_; a.s.block_iter = block_iter_;

@@ -51,7 +51,28 @@ static void ensure_outer(ddamg_hip_ctx* c) {
   c->outer.rw = &c->rw_outer;
   c->outer.track_history = true;
   c->outer.op = [c](double* out, const double* in) { c->fop64.apply(out, in, c->stream); };
-  if (c->par.method > 0) {
+  if (c->par.method == 5) {
+    // preconditioner(): solve_oddeven with bicgstab to the tolerance the outer iteration sets at the start of every step
+    // (src/preconditioner.c:39-55, src/linsolve_generic.c:292-296)
+    const Geometry& g0 = c->levels[0]->geom;
+    if (c->par.mixed_precision == 0) {
+      c->bicg64.init(g0, &c->fop64, c->stream); c->bicg64.set_comm(c->comm);
+      c->outer.prec = [c](double* phi, double*, const double* eta, int) { c->bicg64.solve(phi, eta, c->outer.tol); };
+    } else {
+      c->bicg32.init(g0, &c->fop32, c->stream); c->bicg32.set_comm(c->comm);
+      DDAMG_HIP_CHECK(device_alloc(&c->p32_in, sizeof(float) * n));
+      DDAMG_HIP_CHECK(device_alloc(&c->p32_out, sizeof(float) * n));
+      c->outer.prec = [c](double* phi, double*, const double* eta, int) {
+        const size_t V = c->levels[0]->geom.V;
+        const double rel = c->outer.gamma_jp1 / c->outer.norm_r0;
+        const double tol = std::max(1e-3, (c->outer.tol / rel) * 0.5);
+        vec_convert<float, double>(c->p32_in, eta, V, 24, c->stream);
+        c->bicg32.solve(c->p32_out, c->p32_in, tol);
+        vec_convert<double, float>(phi, c->p32_out, V, 24, c->stream);
+      };
+    }
+    c->bicg_ready = true;
+  } else if (c->par.method > 0) {
     if (c->par.mixed_precision == 0) {
       c->outer.prec = [c](double* phi, double* Dphi, const double* eta, int res) { c->mg64->vcycle(0, phi, Dphi, eta, res); };
     } else {
@@ -217,6 +238,11 @@ int ddamg_hip_setup(ddamg_hip_ctx* c, int setup_iterations, int* coarse_iteratio
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c, "null context");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  if (c->par.method == 5) {   // no hierarchy: the reference switches the interpolation off (src/init.c:976-979)
+    if (coarse_iterations) *coarse_iterations = 0;
+    c->setup_done = true;
+    return 0;
+  }
   ensure_mg(c);
   const int iters = setup_iterations < 0 ? c->par.setup_iter[0] : setup_iterations;
   if (c->mg32) { c->mg32->coarse_iter_count = 0; c->mg32->initial_setup(); c->mg32->iterative_setup(iters); if (coarse_iterations) *coarse_iterations = c->mg32->coarse_iter_count; }
@@ -391,9 +417,10 @@ int ddamg_hip_vcycle(ddamg_hip_ctx* c, ddamg_hip_vec* phi, const ddamg_hip_vec* 
 template <typename LoadB, typename StoreX>
 static void solve_core(ddamg_hip_ctx* c, double tol, LoadB load_b, StoreX store_x, int* iterations, int* coarse_iterations, double* relres) {
   DDAMG_REQUIRE(c->have_operator, "no operator set");
-  DDAMG_REQUIRE(c->par.method <= 0 || c->setup_done, "setup has not been run");
+  DDAMG_REQUIRE(c->par.method <= 0 || c->par.method == 5 || c->setup_done, "setup has not been run");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
   int it; double rr = 0;
+  if (c->bicg_ready) { c->bicg32.total_iter = 0; c->bicg64.total_iter = 0; }
   if (c->mg32) c->mg32->coarse_iter_count = 0;
   if (c->mg64) c->mg64->coarse_iter_count = 0;
   if (c->par.method == -1) {
@@ -420,6 +447,7 @@ static void solve_core(ddamg_hip_ctx* c, double tol, LoadB load_b, StoreX store_
   DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
   c->last_iter = it;
   c->last_coarse_iter = c->mg32 ? c->mg32->coarse_iter_count : (c->mg64 ? c->mg64->coarse_iter_count : 0);
+  if (c->par.method == 5) c->last_coarse_iter = c->bicg32.total_iter + c->bicg64.total_iter;   // inner BiCGstab iterations
   c->last_relres = rr;
   if (iterations) *iterations = it;
   if (coarse_iterations) *coarse_iterations = c->last_coarse_iter;

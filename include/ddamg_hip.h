@@ -45,7 +45,7 @@ typedef struct ddamg_hip_params {
   double kcycle_tol;
   int mixed_precision;                         /* 0: fp64 everywhere, 1: fp32 V-cycle / fp64 FGMRES, 2: fgmres_MP */
   int odd_even;
-  int method;                                  /* -1 pure CGN, 0 pure GMRES; FGMRES + AMG with smoother 1 additive / 2 red-black / 3 sixteen-colour SAP, 4 GMRES (g.method, sample.ini) */
+  int method;                                  /* -1 pure CGN, 0 pure GMRES; FGMRES + AMG with smoother 1 additive / 2 red-black / 3 sixteen-colour SAP, 4 GMRES; 5 FGMRES + BiCGstab without AMG (g.method, sample.ini) */
   double m0, csw;
   int device;                                  /* HIP device ordinal                          */
   /* domain decomposition over GPUs: one process per GPU on a Cartesian grid (reference: g.process_grid and
