@@ -31,6 +31,10 @@ inline View site_range(int nreal, size_t V, size_t s0, size_t s1) {
 struct Comm;  // halo.h: transport between the processes of a decomposed lattice
 // sum d_buf[0..n) over all processes in place (enqueued behind `st`, which then waits for the result)
 void comm_allreduce(Comm* c, double* d_buf, int n, hipStream_t st);
+// the same in two halves: kernels enqueued on st between begin and end overlap with the reduction (RCCL transport; the host
+// transport does the whole reduction in `end`)
+void comm_allreduce_begin(Comm* c, double* d_buf, int n, hipStream_t st);
+void comm_allreduce_end(Comm* c, double* d_buf, int n, hipStream_t st);
 
 struct ReduceWork {
   Comm* comm = nullptr;         // set on a process grid: every reduction below becomes a global one
@@ -75,7 +79,8 @@ template <typename T> void vec_plus(T* z, const T* x, const T* y, View v, hipStr
 // w += sign * sum_{i<m} coef[i] * (X + i*xstride)   coefficients complex fp64 in device memory
 template <typename T> void vec_multi_axpy_dev(T* w, const T* X, size_t xstride, int m, const double* d_coef, double sign, View v, hipStream_t st);
 // d_out[2i..2i+1] = < X+i*xstride , w >  for i<m  (conjugate-linear in the first argument)
-template <typename T> void vec_multi_dot(const T* X, size_t xstride, int m, const T* w, View v, ReduceWork& rw, double* d_out, hipStream_t st);
+// local_only: leave the sum over the processes to the caller (comm_allreduce_begin / _end around other work)
+template <typename T> void vec_multi_dot(const T* X, size_t xstride, int m, const T* w, View v, ReduceWork& rw, double* d_out, hipStream_t st, bool local_only = false);
 // single-allreduce Arnoldi (src/linsolve_generic.c:776-797): d_h holds m+1 inner products <V_i, w>, the last one <w,w>;
 // d_h[2m] <- sqrt( <w,w> - sum_i |h_i|^2 ), or -1 when the difference is negative (the reference restarts then)
 void arnoldi_norm_from_dots(double* d_h, int m, hipStream_t st);

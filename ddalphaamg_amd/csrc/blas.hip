@@ -311,7 +311,7 @@ __global__ __launch_bounds__(BLK) void final_sum_kernel(const double* __restrict
 __global__ void sqrt_inplace_kernel(double* x) { x[0] = sqrt(x[0]); }
 
 template <typename T>
-void vec_multi_dot(const T* X, size_t xstride, int m, const T* w, View v, ReduceWork& rw, double* d_out, hipStream_t st) {
+void vec_multi_dot(const T* X, size_t xstride, int m, const T* w, View v, ReduceWork& rw, double* d_out, hipStream_t st, bool local_only) {
   DDAMG_REQUIRE(m >= 1 && m <= rw.max_m, "multi_dot: too many vectors for the reduction workspace");
   const int gx = std::min(grid_for(v.total() / Chunk<T>::CH), 1024);
   const int gy = (m + DOT_TILE - 1) / DOT_TILE;
@@ -319,7 +319,7 @@ void vec_multi_dot(const T* X, size_t xstride, int m, const T* w, View v, Reduce
   else hipLaunchKernelGGL((multi_dot_kernel<T, false>), dim3(gx, gy), dim3(BLK), 0, st, X, xstride, m, w, v, rw.d_partial);
   hipLaunchKernelGGL(final_sum_kernel, dim3(2 * m), dim3(BLK), 0, st, rw.d_partial, gx, 2 * m, d_out, 0);
   DDAMG_HIP_CHECK(hipGetLastError());
-  if (rw.comm) comm_allreduce(rw.comm, d_out, 2 * m, st);
+  if (rw.comm && !local_only) comm_allreduce(rw.comm, d_out, 2 * m, st);
 }
 
 template <typename T>
@@ -409,7 +409,7 @@ template void vec_random<double>(double*, size_t, unsigned long long, unsigned l
   template void vec_minus<T>(T*, const T*, const T*, View, hipStream_t);                                 \
   template void vec_plus<T>(T*, const T*, const T*, View, hipStream_t);                                  \
   template void vec_multi_axpy_dev<T>(T*, const T*, size_t, int, const double*, double, View, hipStream_t); \
-  template void vec_multi_dot<T>(const T*, size_t, int, const T*, View, ReduceWork&, double*, hipStream_t); \
+  template void vec_multi_dot<T>(const T*, size_t, int, const T*, View, ReduceWork&, double*, hipStream_t, bool); \
   template void vec_norm<T>(const T*, View, ReduceWork&, double*, hipStream_t);                          \
   template void vec_dot_and_norm2<T>(const T*, const T*, View, ReduceWork&, double*, hipStream_t);
 INST(float)

@@ -52,6 +52,19 @@ void comm_allreduce(Comm* c, double* d_buf, int n, hipStream_t st) {
   }
 }
 
+void comm_allreduce_begin(Comm* c, double* d_buf, int n, hipStream_t st) {
+  if (!c || c->kind != 1) return;
+  DDAMG_HIP_CHECK(hipEventRecord(c->ev_a, st));
+  DDAMG_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_a, 0));
+  DDAMG_NCCL_CHECK(ncclAllReduce(d_buf, d_buf, (size_t)n, ncclDouble, ncclSum, c->nccl, c->stream));
+  DDAMG_HIP_CHECK(hipEventRecord(c->ev_b, c->stream));
+}
+void comm_allreduce_end(Comm* c, double* d_buf, int n, hipStream_t st) {
+  if (!c) return;
+  if (c->kind == 1) { DDAMG_HIP_CHECK(hipStreamWaitEvent(st, c->ev_b, 0)); return; }
+  comm_allreduce(c, d_buf, n, st);
+}
+
 // the transport stream gets the highest priority: its (few, small) kernels must not queue behind the operator kernels
 // they overlap with
 static void create_transport_stream(hipStream_t* st) {

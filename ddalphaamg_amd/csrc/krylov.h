@@ -39,6 +39,10 @@ struct Gmres {
   // the reference's SINGLE_ALLREDUCE_ARNOLDI build option (src/linsolve_generic.c:735-800): the new vector's norm comes out
   // of the same reduction as the Gram-Schmidt coefficients, ||w||^2 - sum |h_i|^2 -- one global sum per step instead of two
   bool single_allreduce = getenv("DDAMG_SINGLE_ALLREDUCE_ARNOLDI") != nullptr;
+  // the reference's PIPELINED_ARNOLDI build option (src/linsolve_generic.c:668-733; coarsest level only, no preconditioner):
+  // the global sum of step k travels while the operator is applied for step k+1.  Needs the Z vectors (alloc with_Z) and
+  // one more of them; set by the owner before alloc.
+  bool pipelined = false;
   // storage (owned)
   T* slab = nullptr;
   T *x = nullptr, *b = nullptr, *r = nullptr, *w = nullptr, *Vb = nullptr, *Zb = nullptr;
@@ -53,7 +57,7 @@ struct Gmres {
     vec_elems = vec_elems_;
     restart_length = restart_length_;
     vstride = (vec_elems + 63) / 64 * 64;
-    size_t nvec = 4 + (restart_length + 1) + (with_Z ? restart_length + 1 : 0);
+    size_t nvec = 4 + (restart_length + 1) + (with_Z ? restart_length + 2 : 0);
     DDAMG_HIP_CHECK(device_alloc(&slab, sizeof(T) * vstride * nvec));
     DDAMG_HIP_CHECK(device_zero(slab, sizeof(T) * vstride * nvec));
     x = slab; b = x + vstride; r = b + vstride; w = r + vstride;
@@ -96,9 +100,10 @@ struct Gmres {
       }
       vec_scale<T>(V(0), r, 1.0 / gamma0, 0.0, view, st);
       j = -1;
+      if (pipelined) arnoldi_pipelined(0);
       for (int il = 0; il < restart_length && !finish; il++) {
         j = il; iter++;
-        if (!arnoldi_step(j, right)) { j--; iter--; break; }   // negative ||w||^2 - sum |h|^2: restart from the columns completed so far
+        if (!(pipelined ? arnoldi_pipelined(j + 1) : arnoldi_step(j, right))) { j--; iter--; break; }   // negative ||w||^2 - sum |h|^2: restart from the columns completed so far
         cd* Hj = &H[(size_t)j * (restart_length + 2)];
         if (std::abs(Hj[j + 1]) > (breakdown_tol < 0 ? tol / 10 : breakdown_tol)) {
           qr_update(j);
@@ -163,6 +168,33 @@ struct Gmres {
     for (int i = 0; i <= j; i++) Hj[i] = cd(rw->h_result[2 * i], rw->h_result[2 * i + 1]);
     Hj[j + 1] = rw->h_result[2 * (j + 1)];
     return true;
+  }
+
+  // arnoldi_step_PRECISION, PIPELINED_ARNOLDI branch (src/linsolve_generic.c:670-733): Z[k] holds A V[k-1] expressed in the
+  // basis built so far; V[k] = Z[k] is orthonormalised against V[0..k-1] with the coefficients of ONE reduction (which also
+  // carries <V[k],V[k]>), and the same combination turns A Z[k] into Z[k+1] = A V[k].  The reduction over the processes
+  // runs while A Z[k] is computed.  Returns column k-1 of the Hessenberg matrix (k >= 1).
+  bool arnoldi_pipelined(int k) {
+    DDAMG_REQUIRE(Zb != nullptr && !prec, "pipelined Arnoldi needs the Z vectors and no preconditioner");
+    double* dh = rw->d_result;
+    if (k == 0) vec_copy<T>(Z(0), V(0), view, st);
+    else vec_copy<T>(V(k), Z(k), view, st);
+    vec_multi_dot<T>(Vb, vstride, k + 1, V(k), view, *rw, dh, st, true);          // <V_0..V_k, V_k>, local part
+    comm_allreduce_begin(rw->comm, dh, 2 * (k + 1), st);
+    op(Z(k + 1), Z(k));                                                           // ... overlaps with the global sum
+    comm_allreduce_end(rw->comm, dh, 2 * (k + 1), st);
+    arnoldi_norm_from_dots(dh, k, st);                                            // dh[2k] = sqrt( <V_k,V_k> - sum_{i<k} |h_i|^2 )
+    if (k > 0) publish_to_host(dh, 2 * k + 1, *rw, st);
+    if (k > 0) vec_multi_axpy_dev<T>(V(k), Vb, vstride, k, dh, -1.0, view, st);
+    vec_scale_inv_dev<T>(V(k), V(k), dh + 2 * k, view, st);
+    if (k > 0) vec_multi_axpy_dev<T>(Z(k + 1), Z(1), vstride, k, dh, -1.0, view, st);
+    vec_scale_inv_dev<T>(Z(k + 1), Z(k + 1), dh + 2 * k, view, st);
+    if (k == 0) return true;
+    wait_published(*rw, st);
+    cd* Hj = &H[(size_t)(k - 1) * (restart_length + 2)];
+    for (int i = 0; i < k; i++) Hj[i] = cd(rw->h_result[2 * i], rw->h_result[2 * i + 1]);
+    Hj[k] = rw->h_result[2 * k];
+    return rw->h_result[2 * k] >= 0;
   }
 
   void qr_update(int j) {

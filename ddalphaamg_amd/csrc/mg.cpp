@@ -101,7 +101,8 @@ Multigrid<T>::Multigrid(const ddamg_hip_params& par, const std::vector<const Geo
     if (lv.coarsest) {
       // coarsest-level GMRES on the even-site Schur complement (src/init_generic.c:148-154)
       lv.rw.init(std::max(par.coarse_iter, 8) + 4);
-      lv.gm.alloc(lv.nel, par.coarse_iter, false);
+      lv.gm.pipelined = getenv("DDAMG_PIPELINED_ARNOLDI") != nullptr;   // the reference's -DPIPELINED_ARNOLDI build, at run time
+      lv.gm.alloc(lv.nel, par.coarse_iter, lv.gm.pipelined);
       lv.gm.num_restart = par.coarse_restart;
       lv.gm.tol = par.coarse_tol;
       lv.gm.st = st_; lv.gm.rw = &lv.rw;

@@ -69,3 +69,37 @@ def test_without_odd_even_preconditioning(gold4, gold8, case, ext, method, setup
     ctx.dirac_apply(Dx, xv)
     assert abs(np.linalg.norm(b - Dx.download()) / np.linalg.norm(b) - rr) < 1e-12
     ctx.close()
+
+
+def amg_ctx(gold, ext, setup):
+    ctx = context(gold, ext, 2, 1, setup=setup)
+    ctx.setup(setup)
+    return ctx
+
+
+def test_pipelined_arnoldi_on_the_coarsest_level(gold4, monkeypatch):
+    """the reference's PIPELINED_ARNOLDI build option (src/linsolve_generic.c:668-733) as a run-time switch: on the coarsest
+    level the Gram-Schmidt coefficients of step k come from one reduction that travels while the operator is applied for
+    step k+1 (a one-step-delayed recurrence on unnormalised vectors).  Same Krylov space in exact arithmetic."""
+    V = 256
+    b = np.zeros((V, 12, 2)); b[..., 0] = 1.0
+    ctx = amg_ctx(gold4, 4, 4)
+    x0, it0, cit0, rr0 = ctx.solve(b, 1e-10)
+    ctx.close()
+    monkeypatch.setenv("DDAMG_PIPELINED_ARNOLDI", "1")
+    ctx = amg_ctx(gold4, 4, 4)
+    x1, it1, cit1, rr1 = ctx.solve(b, 1e-10)
+    ctx.close()
+    assert rr1 < 1e-10 and abs(it1 - it0) <= 1 and abs(cit1 - cit0) <= 0.15 * cit0, (it0, cit0, it1, cit1)
+    assert relerr(x1, x0) < 1e-8
+    # next to the reference's own pipelined build, whose outer FGMRES uses the single-reduction norm as well: the same
+    # residuals while that norm is still accurate (it stalls near sqrt(eps) in the reference), the same coarse-grid work
+    ref = RUNS["4x4_pipelined"]
+    monkeypatch.setenv("DDAMG_SINGLE_ALLREDUCE_ARNOLDI", "1")
+    ctx = amg_ctx(gold4, 4, 4)
+    x2, it2, cit2, rr2 = ctx.solve(b, 1e-10)
+    h = ctx.residual_history()
+    ctx.close()
+    assert rr2 < 1e-10
+    assert np.all(np.abs(h[:6] / np.array(ref["residual_history"][:6]) - 1.0) < 0.05), (h[:8], ref["residual_history"][:8])
+    assert abs(cit2 / it2 - ref["coarse_average"]) < 0.15 * ref["coarse_average"], (cit2 / it2, ref["coarse_average"])

@@ -72,6 +72,13 @@ def test_decomposed_two_level_amg(nproc, grid, mp):
 
 
 @pytest.mark.gpu
+def test_decomposed_two_level_amg_with_pipelined_arnoldi(monkeypatch):
+    """the coarsest-level recurrence whose global sum travels behind the operator application (DDAMG_PIPELINED_ARNOLDI)"""
+    monkeypatch.setenv("DDAMG_PIPELINED_ARNOLDI", "1")
+    launch(2, "--mode", "amg", "--grid", "1,2,1,1", "--prec", "1", "--tol", "1e-6", timeout=600)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nproc,grid,method,mp", [(2, "2,1,1,1", 1, 1), (2, "1,1,1,2", 1, 2), (2, "1,2,1,1", 3, 1), (4, "2,1,2,1", 3, 1), (2, "1,1,2,1", 4, 1), (4, "2,2,1,1", 4, 2)])
 def test_decomposed_two_level_amg_other_schedules(nproc, grid, method, mp):
     """additive and sixteen-colour Schwarz on a process grid: the halo of the previous generation of block updates
