@@ -37,6 +37,7 @@ class Params(ctypes.Structure):
         ("process_coords", ctypes.c_int * 4),
         ("test_vector_rng", ctypes.c_int),
         ("rng_seed", ctypes.c_ulonglong),
+        ("gather_coarsest", ctypes.c_int),
     ]
 
 

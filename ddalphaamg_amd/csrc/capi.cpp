@@ -52,7 +52,7 @@ void ddamg_hip_default_params(ddamg_hip_params* p) {
   p->mixed_precision = 2; p->odd_even = 1; p->method = 2;
   p->m0 = 0; p->csw = 0; p->device = 0;
   for (int mu = 0; mu < 4; mu++) { p->process_grid[mu] = 1; p->process_coords[mu] = 0; }
-  p->test_vector_rng = 0; p->rng_seed = 0;
+  p->test_vector_rng = 0; p->rng_seed = 0; p->gather_coarsest = 0;
 }
 
 int ddamg_hip_create(const ddamg_hip_params* p, ddamg_hip_ctx** out) {

@@ -73,6 +73,7 @@ void params_from_ini(const Ini& ini, ddamg_hip_params& hp, int* anti_pbc) {
   ddamg_hip_default_params(&hp);
   ini.geti("number of levels:", &hp.num_levels);
   int glob[DDAMG_HIP_MAX_LEVELS][4] = {};
+  int whole_level = -1;
   ini.geti("odd even preconditioning:", &hp.odd_even);
   // read_geometry_data (src/init.c:659-760): a level whose lattices are not given takes the previous level's lattice
   // divided by its block lattice; if that leaves fewer than 2 sites the method silently becomes shallower
@@ -103,8 +104,18 @@ void params_from_ini(const Ini& ini, ddamg_hip_params& hp, int* anti_pbc) {
       if (d == 0) fatal("parameter \"%s\" missing", k);
       for (int mu = 0; mu < 4; mu++) hp.local_lattice[d][mu] = glob[d][mu] / S.P[mu];   // as src/init.c:56-72
     }
-    for (int mu = 0; mu < 4; mu++)
-      if (glob[d][mu] != hp.local_lattice[d][mu] * S.P[mu]) fatal("every level must be distributed over the same process grid");
+    {
+      // a coarse level's local lattice larger than global / process grid is the reference's idle-process gathering
+      // (src/init.c:56-72).  Supported: the coarsest level given whole (local == global) -- it is then gathered on
+      // every process (ddamg_hip_params::gather_coarsest); every other level lives on the full process grid.
+      bool same = true, whole = true;
+      for (int mu = 0; mu < 4; mu++) { same = same && glob[d][mu] == hp.local_lattice[d][mu] * S.P[mu]; whole = whole && glob[d][mu] == hp.local_lattice[d][mu]; }
+      if (!same) {
+        if (!(whole && d > 0)) fatal("d%d local lattice: a level is either distributed over the whole process grid or (the coarsest one) given whole", d);
+        whole_level = d;
+        for (int mu = 0; mu < 4; mu++) hp.local_lattice[d][mu] = glob[d][mu] / S.P[mu];
+      }
+    }
     snprintf(k, sizeof k, "d%d block lattice:", d);
     if (!ini.geti(k, hp.block_lattice[d], 4)) {
       if (d == 0) fatal("parameter \"%s\" missing", k);
@@ -123,6 +134,10 @@ void params_from_ini(const Ini& ini, ddamg_hip_params& hp, int* anti_pbc) {
     snprintf(k, sizeof k, "d%d block iter:", d); ini.geti(k, &hp.block_iter[d]);
     snprintf(k, sizeof k, "d%d test vectors:", d); ini.geti(k, &hp.num_vect[d]);
     snprintf(k, sizeof k, "d%d setup iter:", d); ini.geti(k, &hp.setup_iter[d]);
+  }
+  if (whole_level >= 0) {
+    if (whole_level != hp.num_levels - 1) fatal("d%d local lattice: only the coarsest level can be gathered", whole_level);
+    hp.gather_coarsest = 1;
   }
   ini.getd("m0:", &hp.m0); ini.getd("csw:", &hp.csw);
   ini.getd("tolerance for relative residual:", &hp.tol);

@@ -31,6 +31,10 @@ void rccl_unique_id(void* id128);
 // host-buffer primitives over either transport (setup-time exchanges such as the gauge-field halo): blocking
 void comm_sendrecv_host(Comm* c, const void* send, int send_peer, void* recv, int recv_peer, size_t bytes, int tag);
 void comm_allreduce_host(Comm* c, double* buf, int n);
+// d_recv[r*bytes .. (r+1)*bytes) <- d_send of process r, for every process r (device buffers; enqueued behind st, which waits for it)
+void comm_allgather(Comm* c, const void* d_send, void* d_recv, size_t bytes, hipStream_t st);
+int comm_rank(const Comm* c);
+int comm_size(const Comm* c);
 
 // send / receive arenas of the 8 face messages of one field type and their exchange (any payload)
 class HaloArena {

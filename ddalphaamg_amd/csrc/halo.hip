@@ -27,7 +27,44 @@ struct Comm {
   hipEvent_t ev_a = nullptr, ev_b = nullptr;   // ordering between the compute stream and the transport stream
   double* h_red = nullptr;                      // pinned staging for the host transport's reductions
   int h_red_n = 0;
+  char* h_gather = nullptr;                     // pinned staging for the host transport's all-gather
+  size_t h_gather_bytes = 0;
 };
+
+int comm_rank(const Comm* c) { return c ? c->rank : 0; }
+int comm_size(const Comm* c) { return c ? c->nranks : 1; }
+
+void comm_allgather(Comm* c, const void* d_send, void* d_recv, size_t bytes, hipStream_t st) {
+  if (!c || (c->nranks == 1 && c->kind != 1)) {   // (one process on RCCL still runs the collective: the self-exchange tests)
+    DDAMG_HIP_CHECK(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, st));
+    return;
+  }
+  if (c->kind == 1) {
+    DDAMG_HIP_CHECK(hipEventRecord(c->ev_a, st));
+    DDAMG_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_a, 0));
+    DDAMG_NCCL_CHECK(ncclAllGather(d_send, d_recv, bytes, ncclChar, c->nccl, c->stream));
+    DDAMG_HIP_CHECK(hipEventRecord(c->ev_b, c->stream));
+    DDAMG_HIP_CHECK(hipStreamWaitEvent(st, c->ev_b, 0));
+    return;
+  }
+  // host transport: staged, one message to and from every other process
+  const size_t total = bytes * (size_t)c->nranks;
+  if (total > c->h_gather_bytes) {
+    if (c->h_gather) DDAMG_HIP_CHECK(hipHostFree(c->h_gather));
+    DDAMG_HIP_CHECK(hipHostMalloc(&c->h_gather, total));
+    c->h_gather_bytes = total;
+  }
+  char* mine = c->h_gather + bytes * (size_t)c->rank;
+  DDAMG_HIP_CHECK(hipMemcpyAsync(mine, d_send, bytes, hipMemcpyDeviceToHost, st));
+  DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+  for (int k = 1; k < c->nranks; k++) {
+    const int to = (c->rank + k) % c->nranks, from = (c->rank - k + c->nranks) % c->nranks;
+    ddamg_hip_halo_msg m{to, from, 64 + k, mine, c->h_gather + bytes * (size_t)from, (unsigned long long)bytes};
+    c->fn(c->user, 1, &m);
+  }
+  DDAMG_HIP_CHECK(hipMemcpyAsync(d_recv, c->h_gather, total, hipMemcpyHostToDevice, st));
+  DDAMG_HIP_CHECK(hipStreamSynchronize(st));   // the staging buffer is reused by the next call
+}
 
 void comm_allreduce(Comm* c, double* d_buf, int n, hipStream_t st) {
   if (!c) return;   // (with one process the transport still runs: a sum over one rank, used by the self-exchange tests)
@@ -144,6 +181,7 @@ void comm_destroy(Comm* c) {
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);
   if (c->ev_b) (void)hipEventDestroy(c->ev_b);
   if (c->h_red) (void)hipHostFree(c->h_red);
+  if (c->h_gather) (void)hipHostFree(c->h_gather);
   delete c;
 }
 

@@ -133,6 +133,86 @@ Multigrid<T>::Multigrid(const ddamg_hip_params& par, const std::vector<const Geo
   DDAMG_HIP_CHECK(device_alloc(&d_stage_, sizeof(double) * std::max(lv_[0]->nel, max_coarse)));
   DDAMG_HIP_CHECK(device_alloc(&W_, sizeof(T) * lv_[0]->nel * 5));
   DDAMG_HIP_CHECK(device_alloc(&cwork_, sizeof(T) * max_coarse * 5));
+  if (par.gather_coarsest && lv_.back()->g->distributed()) setup_gathered_coarsest();
+}
+
+// rows of `row` reals: dst[i] = src[perm[i]]
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(T* __restrict__ dst, const T* __restrict__ src, const int* __restrict__ perm, size_t row, size_t total) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const size_t r = i / row;
+    dst[i] = src[(size_t)perm[r] * row + (i - r * row)];
+  }
+}
+template <typename T>
+static void gather_rows(T* dst, const T* src, const int* perm, int nrows, size_t row, hipStream_t st) {
+  const size_t total = (size_t)nrows * row;
+  hipLaunchKernelGGL(gather_rows_kernel<T>, dim3((unsigned)std::min<size_t>((total + 255) / 256, 4096)), dim3(256), 0, st, dst, src, perm, row, total);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
+template <typename T>
+void Multigrid<T>::setup_gathered_coarsest() {
+  MGLevel<T>& lv = *lv_.back();
+  const Geometry& gd = *lv.g;
+  DDAMG_REQUIRE(par_.odd_even == 1, "the gathered coarsest level runs the odd-even Schur complement solve (odd_even = 1)");
+  GatheredCoarsest<T>& G = gath_;
+  int Lg[4];
+  for (int mu = 0; mu < 4; mu++) Lg[mu] = gd.L[mu] * gd.P[mu];
+  G.g.build(Lg, Lg, Lg);
+  G.V_local = gd.V;
+  const int V = G.g.V, n = lv.n, np = gd.nranks;
+  DDAMG_REQUIRE((long long)gd.V * np == V, "gathered coarsest lattice: process grid does not tile the lattice");
+  for (int mu = 0; mu < 4; mu++) DDAMG_REQUIRE(Lg[mu] % 2 == 0, "the coarsest lattice must have even global extents (odd-even preconditioning)");
+  // where every site of the whole lattice lives: each process orders its part by the parity of the GLOBAL lattice, which
+  // depends on the parity of its origin
+  std::vector<int> g2d(V, -1), d2g(gd.V, -1);
+  for (int r = 0; r < np; r++) {
+    int pc[4], rr = r;
+    for (int mu = 3; mu >= 0; mu--) { pc[mu] = rr % gd.P[mu]; rr /= gd.P[mu]; }
+    Geometry gr;
+    gr.build(gd.L, gd.B, gd.A, gd.P, pc);
+    for (int s = 0; s < gr.V; s++) {
+      int c[4];
+      for (int mu = 0; mu < 4; mu++) c[mu] = pc[mu] * gd.L[mu] + gr.coord[(size_t)s * 4 + mu];
+      const int sg = G.g.site_of_lex[G.g.lex(c)];
+      g2d[sg] = r * gd.V + s;
+      if (r == gd.rank) d2g[s] = sg;
+    }
+  }
+  for (int s = 0; s < V; s++) DDAMG_REQUIRE(g2d[s] >= 0, "gathered coarsest lattice: a site has no owner");
+  DDAMG_HIP_CHECK(device_alloc(&G.d_g2d, sizeof(int) * V));
+  DDAMG_HIP_CHECK(device_alloc(&G.d_d2g, sizeof(int) * gd.V));
+  DDAMG_HIP_CHECK(hipMemcpy(G.d_g2d, g2d.data(), sizeof(int) * V, hipMemcpyHostToDevice));
+  DDAMG_HIP_CHECK(hipMemcpy(G.d_d2g, d2g.data(), sizeof(int) * gd.V, hipMemcpyHostToDevice));
+  G.cop.alloc(G.g, n);
+  const size_t nel = (size_t)V * n * 2;
+  for (int i = 0; i < 2; i++) { DDAMG_HIP_CHECK(device_alloc(&G.buf[i], sizeof(T) * nel)); DDAMG_HIP_CHECK(device_zero(G.buf[i], sizeof(T) * nel)); }
+  // landing zone of the all-gathers: the operator is the larger payload (5 matrices per site)
+  const size_t raw_elems = std::max((size_t)V * 5 * lv.cop.msize() * 2, nel);
+  DDAMG_HIP_CHECK(device_alloc(&G.raw, sizeof(T) * raw_elems));
+  G.rw.init(std::max(par_.coarse_iter, 8) + 4);
+  G.gm.pipelined = false;     // nothing to hide: the reductions are local
+  G.gm.alloc(nel, par_.coarse_iter, false);
+  G.gm.num_restart = par_.coarse_restart;
+  G.gm.tol = par_.coarse_tol;
+  G.gm.st = st_; G.gm.rw = &G.rw;
+  int n_even = 0;
+  for (int s = 0; s < V; s++) if (G.g.parity[s] == 0) n_even++;
+  DDAMG_REQUIRE(n_even * 2 == V, "coarsest lattice needs as many even as odd sites");
+  G.gm.view = View{1, 0, 0, (size_t)n_even * n * 2};
+  G.gm.op = [this](T* out, const T* in) { this->schur_on(gath_.cop, gath_.g.V, gath_.buf[0], gath_.buf[1], out, in); };
+  G.on = true;
+}
+
+template <typename T>
+void Multigrid<T>::regather_coarsest_operator() {
+  if (!gath_.on) return;
+  MGLevel<T>& lv = *lv_.back();
+  const size_t row = 5 * lv.cop.msize() * 2;      // reals per site: five matrices
+  comm_allgather(comm_, lv.cop.matrices(), gath_.raw, sizeof(T) * row * (size_t)gath_.V_local, st_);
+  gather_rows<T>(gath_.cop.matrices(), gath_.raw, gath_.d_g2d, gath_.g.V, row, st_);
+  gath_.cop.compute_self_inverse(st_);
 }
 
 template <typename T>
@@ -158,6 +238,13 @@ Multigrid<T>::~Multigrid() {
   if (gal_C_) (void)hipFree(gal_C_);
   if (gal_cwork_) (void)hipFree(gal_cwork_);
   if (cwork_) (void)hipFree(cwork_);
+  if (gath_.on) {
+    for (int i = 0; i < 2; i++) if (gath_.buf[i]) (void)hipFree(gath_.buf[i]);
+    if (gath_.raw) (void)hipFree(gath_.raw);
+    if (gath_.d_g2d) (void)hipFree(gath_.d_g2d);
+    if (gath_.d_d2g) (void)hipFree(gath_.d_d2g);
+    gath_.gm.release(); gath_.rw.destroy();
+  }
 }
 
 // ---- level-generic pieces ---------------------------------------------------------------------------
@@ -268,13 +355,17 @@ void Multigrid<T>::gmres_smoother(int l, T* phi, const T* eta, int cycles, int r
 // ---- coarsest level: odd-even Schur complement solve ----------------------------------------------
 // S = D_ee - D_eo D_oo^-1 D_oe  on the even sites (coarse_apply_schur_complement_PRECISION)
 template <typename T>
+void Multigrid<T>::schur_on(const CoarseOp<T>& cop, int V, T* t0, T* t1, T* out, const T* in) {
+  const int Ve = V / 2;
+  cop.self_mul(out, in, 0, Ve, false, st_);        // out_e = D_ee in_e
+  cop.hop(t0, in, Ve, V, -1.0, false, st_);        // tmp0_o = -H_oe in_e   (= D_oe in_e)
+  cop.self_mul(t1, t0, Ve, V, true, st_);          // tmp1_o = D_oo^-1 tmp0_o
+  cop.hop(out, t1, 0, Ve, +1.0, true, st_);        // out_e += H_eo tmp1_o  (= -D_eo tmp1_o)
+}
+template <typename T>
 void Multigrid<T>::schur(T* out, const T* in) {
   MGLevel<T>& lv = *lv_.back();
-  const int V = lv.g->V, Ve = V / 2;
-  lv.cop.self_mul(out, in, 0, Ve, false, st_);                 // out_e = D_ee in_e
-  lv.cop.hop(lv.buf[0], in, Ve, V, -1.0, false, st_);          // tmp0_o = -H_oe in_e   (= D_oe in_e)
-  lv.cop.self_mul(lv.buf[1], lv.buf[0], Ve, V, true, st_);     // tmp1_o = D_oo^-1 tmp0_o
-  lv.cop.hop(out, lv.buf[1], 0, Ve, +1.0, true, st_);          // out_e += H_eo tmp1_o  (= -D_eo tmp1_o)
+  schur_on(lv.cop, lv.g->V, lv.buf[0], lv.buf[1], out, in);
 }
 
 template <typename T>
@@ -284,6 +375,24 @@ int Multigrid<T>::coarse_solve() {
   T *x = lv.gm.x, *b = lv.gm.b;
   if (!par_.odd_even) {
     const int it = lv.gm.solve();
+    coarse_iter_count += it;
+    return it;
+  }
+  if (gath_.on) {
+    // one all-gather of the right-hand side, the solve on the whole lattice (every process the same, bit for bit: the
+    // kernels are deterministic), my part of the solution
+    GatheredCoarsest<T>& G = gath_;
+    const size_t row = (size_t)lv.n * 2;
+    const int Vg = G.g.V, Vge = Vg / 2;
+    comm_allgather(comm_, b, G.raw, sizeof(T) * row * (size_t)G.V_local, st_);
+    T *gx = G.gm.x, *gb = G.gm.b;
+    gather_rows<T>(gb, G.raw, G.d_g2d, Vg, row, st_);
+    G.cop.self_mul(gx, gb, Vge, Vg, true, st_);
+    G.cop.hop(gb, gx, 0, Vge, +1.0, true, st_);
+    const int it = G.gm.solve();
+    G.cop.hop(gb, gx, Vge, Vg, +1.0, true, st_);
+    G.cop.self_mul(gx, gb, Vge, Vg, true, st_);
+    gather_rows<T>(x, gx, G.d_d2g, G.V_local, row, st_);
     coarse_iter_count += it;
     return it;
   }
@@ -455,6 +564,7 @@ void Multigrid<T>::build_coarse_operator(int l) {
       if (!gal_cwork_) DDAMG_HIP_CHECK(device_alloc(&gal_cwork_, sizeof(T) * coarse_galerkin_batch_work(lv_[1]->g->V, lv_[1]->n)));
       coarse_galerkin_batched(nx.cop, lv.cop, lv.cip, lv.d_agg_face, gal_cwork_, st_);
       if (nx.coarsest || par_.method == 4) nx.cop.compute_self_inverse(st_);   // D_oo^-1 of the Schur complements
+      if (nx.coarsest) regather_coarsest_operator();
       DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
       tick("Galerkin coarse operator", t_start);
       return;
@@ -478,6 +588,7 @@ void Multigrid<T>::build_coarse_operator(int l) {
       }
   }
   if (nx.coarsest || par_.method == 4) nx.cop.compute_self_inverse(st_);
+  if (nx.coarsest) regather_coarsest_operator();
   DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
   tick("Galerkin coarse operator", t_start);
 }

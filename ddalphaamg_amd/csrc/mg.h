@@ -53,6 +53,23 @@ struct MGLevel {
   std::vector<int> ref_order;   // site visited i-th by the reference's vector loops on this level
 };
 
+// The coarsest level gathered on every process (ddamg_hip_params::gather_coarsest; purpose of the reference's idle-process
+// gathering, src/gathering_generic.c:24-346): the whole coarsest lattice, its operator collected from all processes after
+// every (re)build, and the odd-even Schur GMRES on it without any communication.
+template <typename T>
+struct GatheredCoarsest {
+  bool on = false;
+  Geometry g;            // the GLOBAL coarsest lattice, not decomposed
+  CoarseOp<T> cop;
+  Gmres<T> gm;
+  ReduceWork rw;         // no transport: every process computes the same sums
+  T* buf[2] = {nullptr, nullptr};
+  T* raw = nullptr;      // all-gather landing zone: [process][local site][...]
+  int* d_g2d = nullptr;  // gathered site -> process * V_local + local site
+  int* d_d2g = nullptr;  // my local site -> gathered site
+  int V_local = 0;
+};
+
 template <typename T>
 class Multigrid {
  public:
@@ -69,6 +86,8 @@ class Multigrid {
   void set_kcycle_tol(double tol);
   void release_setup_workspace();       // large temporaries of the Galerkin construction (kept across the builds of one setup)
   void set_comm(Comm* c) { comm_ = c; for (auto& lv : lv_) { lv->rw.comm = c; lv->srw.comm = c; lv->cop.set_comm(c); } }
+  bool coarsest_gathered() const { return gath_.on; }
+  void regather_coarsest_operator();   // after every (re)build / import of the coarsest operator
 
   // ---- hot path -----------------------------------------------------------------------------
   void apply_op(int l, T* out, const T* in);
@@ -104,7 +123,10 @@ class Multigrid {
   T* W_ = nullptr;        // 5 level-0 vectors (Galerkin)
   T* cwork_ = nullptr;    // coarse work space (5 vectors of the largest coarse level)
 
+  GatheredCoarsest<T> gath_;
+  void setup_gathered_coarsest();
   void schur(T* out, const T* in);
+  void schur_on(const CoarseOp<T>& cop, int V, T* t0, T* t1, T* out, const T* in);
   std::vector<int> ref_order0_;   // fine-level vector-loop order of the reference when odd_even == 0
   void smoother_schur(int l, T* out, const T* in);            // (apply_schur_complement / coarse_apply_schur_complement on level l)
   void gmres_smoother(int l, T* phi, const T* eta, int cycles, int res);

@@ -326,6 +326,7 @@ int ddamg_hip_set_coarse_operator(ddamg_hip_ctx* c, const double* D_lex, const d
   ensure_mg(c);
   if (c->mg32) c->mg32->level(1).cop.import_reference(c->levels[1]->geom, D_lex, clover_lex, c->stream);
   else c->mg64->level(1).cop.import_reference(c->levels[1]->geom, D_lex, clover_lex, c->stream);
+  if (c->par.num_levels == 2) { if (c->mg32) c->mg32->regather_coarsest_operator(); else c->mg64->regather_coarsest_operator(); }
   DDAMG_API_END
 }
 

@@ -60,6 +60,15 @@ typedef struct ddamg_hip_params {
    * 1 = counter-based generator on the device (the role of "randomize test vectors: 1", src/init.c:870-873) */
   int test_vector_rng;
   unsigned long long rng_seed;
+  /* process grid only.  != 0: the coarsest level is not decomposed.  Every V-cycle gathers its right-hand side from all
+   * processes (one all-gather over the transport), solves the coarsest system on the WHOLE coarsest lattice without any
+   * communication, and keeps its own part of the solution.  This is the purpose of the reference's idle-process
+   * gathering -- fewer, larger processes on the coarse levels, set there by a coarse "local lattice" larger than
+   * global / process grid (src/init.c:56-72, vector_PRECISION_gather / _distribute src/gathering_generic.c:285-346) --
+   * taken to its end point of ONE coarsest lattice; on GPUs every process solves it redundantly instead of all but one
+   * idling, which also saves the distribute step.  The dd_alpha_amg_* facade sets it when the coarsest level's local lattice
+   * equals its global lattice. */
+  int gather_coarsest;
 } ddamg_hip_params;
 
 const char* ddamg_hip_last_error(void);

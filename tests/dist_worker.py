@@ -165,7 +165,7 @@ def run_gmres(rank, world, P, mp):
     return err
 
 
-def run_amg(rank, world, P, mp, levels=2, G=None, method=2):
+def run_amg(rank, world, P, mp, levels=2, G=None, method=2, gather=0):
     """two-level FGMRES+AMG on the decomposed 8^4 sample configuration (2^4 blocks and aggregates, Nvec 20):
     (1) the hierarchy of the undivided run is handed over (interpolation vectors) and the Galerkin operator,
     smoother, coarse operator and solve of the decomposed run are compared with it; (2) the decomposed run
@@ -196,6 +196,7 @@ def run_amg(rank, world, P, mp, levels=2, G=None, method=2):
         p.coarse_iter, p.coarse_restart, p.coarse_tol = 30, 10, 5e-2
         p.mixed_precision, p.method, p.odd_even = mp, method, 1
         p.m0, p.csw = m0, 1.0
+        p.gather_coarsest = gather if int(np.prod(grid)) > 1 else 0   # the coarsest level whole on every process (one all-gather per V-cycle)
         return p
 
     def rel(a, b):
@@ -256,6 +257,8 @@ def run_amg(rank, world, P, mp, levels=2, G=None, method=2):
     for k, v in errs.items():
         assert v < tol32[k], (k, v)
     assert abs(it - it1) <= (1 if levels == 2 else 2) and abs(it2 - it1) <= 2, (it1, it, it2)
+    if gather:   # the coarsest system is the undivided one: the same solver trajectory up to the rounding of the Galerkin operator
+        assert it == it1 and abs(cit - cit1) <= max(2, cit1 // 50), (it1, cit1, it, cit)
     assert rr < 1.5e-10 and rr2 < 1.5e-10
     return max(errs["solution"], errs["solution_own_setup"])
 
@@ -323,6 +326,7 @@ def main():
     ap.add_argument("--prec", type=int, default=64)
     ap.add_argument("--transport", default="host")
     ap.add_argument("--tol", type=float, default=1e-13)
+    ap.add_argument("--gather", type=int, default=0, help="amg modes: gather the coarsest level on every process")
     ap.add_argument("--method", type=int, default=2, help="Schwarz schedule of the amg modes: 1 additive, 2 red-black, 3 sixteen colours")
     a = ap.parse_args()
     dist.init_process_group("gloo")
@@ -334,11 +338,11 @@ def main():
     elif a.mode == "gauge":
         err = run_gauge(rank, world, P)
     elif a.mode == "amg":
-        err = run_amg(rank, world, P, a.prec, method=a.method)
+        err = run_amg(rank, world, P, a.prec, method=a.method, gather=a.gather)
     elif a.mode == "sample_np2":
         err = run_sample_np2(rank, world, P)
     elif a.mode == "amg3":
-        err = run_amg(rank, world, P, a.prec, levels=3, G=[int(x) for x in a.lattice.split(",")], method=a.method)
+        err = run_amg(rank, world, P, a.prec, levels=3, G=[int(x) for x in a.lattice.split(",")], method=a.method, gather=a.gather)
     elif a.mode == "gmres":
         err = run_gmres(rank, world, P, a.prec)
     else:

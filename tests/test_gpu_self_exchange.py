@@ -48,14 +48,17 @@ def test_dirac_and_gauge_through_rccl_self_exchange(gold8, grid):
     ctx.close()
 
 
-@pytest.mark.parametrize("levels,mp", [(2, 1), (3, 1), (3, 0), (3, 2)])
-def test_amg_solve_through_rccl_self_exchange(gold8, levels, mp):
+@pytest.mark.parametrize("levels,mp,gather", [(2, 1, 0), (3, 1, 0), (3, 0, 0), (3, 2, 0), (2, 1, 1), (3, 1, 1)])
+def test_amg_solve_through_rccl_self_exchange(gold8, levels, mp, gather):
     """smoother, Galerkin construction, coarse operator, K-cycle, coarsest solve and the reductions, all through RCCL;
-    mixed precision 0 (all fp64), 1 (fp64 outer / fp32 V-cycle) and 2 (fgmres_MP)"""
+    mixed precision 0 (all fp64), 1 (fp64 outer / fp32 V-cycle) and 2 (fgmres_MP); gather: the coarsest level collected
+    with ncclAllGather and solved whole (ddamg_hip_params::gather_coarsest)"""
     b = np.zeros((4096, 12, 2)); b[..., 0] = 1.0
     res = []
     for grid in ([1, 1, 1, 1], [-1, -1, -1, -1]):
-        ctx = dd.Context(params(gold8, grid, levels, mp))
+        pp = params(gold8, grid, levels, mp)
+        pp.gather_coarsest = gather
+        ctx = dd.Context(pp)
         if grid[0] == -1:
             ctx.comm_init_rccl(api.rccl_unique_id())
         ctx.set_gauge(gold8["gauge"], anti_pbc=True)

@@ -72,6 +72,16 @@ def test_decomposed_two_level_amg(nproc, grid, mp):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nproc,grid,mode,lattice", [(4, "2,2,1,1", "amg", "8,8,8,8"), (2, "1,1,2,1", "amg", "8,8,8,8"), (4, "1,2,2,1", "amg3", "8,16,16,8")])
+def test_coarsest_level_gathered_on_every_process(nproc, grid, mode, lattice):
+    """ddamg_hip_params::gather_coarsest (the purpose of the reference's idle-process gathering, src/gathering_generic.c:
+    285-346, taken to one coarsest lattice): the coarsest level is whole on every process -- operator collected after every
+    build, right-hand side by one all-gather per V-cycle, no communication inside its GMRES -- and the decomposed run has the
+    iteration count of the undivided one"""
+    launch(nproc, "--mode", mode, "--grid", grid, "--lattice", lattice, "--prec", "1", "--gather", "1", "--tol", "1e-6", timeout=900)
+
+
+@pytest.mark.gpu
 def test_decomposed_two_level_amg_with_pipelined_arnoldi(monkeypatch):
     """the coarsest-level recurrence whose global sum travels behind the operator application (DDAMG_PIPELINED_ARNOLDI)"""
     monkeypatch.setenv("DDAMG_PIPELINED_ARNOLDI", "1")
