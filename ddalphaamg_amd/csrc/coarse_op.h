@@ -95,6 +95,14 @@ class CoarseOp {
   size_t msize_ = 0;
   mutable HaloArena arena_;
   Comm* comm_ = nullptr;
+  // on a process grid: sites without / with a neighbour on another process (sorted), for the overlap of the exchange with
+  // the interior work (the reference's ghost_sendrecv ... interior hopping terms ... ghost_wait, src/coarse_oddeven_generic.c:
+  // 447-581); the sites whose FORWARD neighbour is on another process and the directions concerned
+  std::vector<int> h_interior_, h_boundary_;
+  int *d_interior_ = nullptr, *d_boundary_ = nullptr, *d_fwd_off_sites_ = nullptr;
+  unsigned char* d_fwd_off_mask_ = nullptr;
+  int n_fwd_off_ = 0;
+  void pack_and_begin(const T* in, hipStream_t st) const;
 };
 
 }  // namespace ddamg

@@ -2,6 +2,7 @@
 // n x n product (self coupling, 4 forward links, 4 backward links); every product streams its
 // matrix exactly once in 512-byte tiles: the kernel is bound by the HBM read of the couplings.
 #include "coarse_op.h"
+#include <algorithm>
 #include <complex>
 
 namespace ddamg {
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(BLOCK_MINRES_THREADS) void coarse_block_minres_kern
 // out(x) = M0 in(x) - sum_mu L_mu in(x+mu).  Phase 2: out(x) -= sum_mu bwd[mu][x].  (coarse_site_kernel computes the
 // backward terms from the neighbour's link as well, which costs a second read of every link: 9 instead of 5 matrices
 // per site.)  Across a process boundary the backward products travel in the halo as before.
-template <typename T, int NT>
+template <typename T, int NT, bool DEFER>
 __global__ __launch_bounds__(320) void coarse_apply_once_kernel(T* __restrict__ out, T* __restrict__ bwd, const T* __restrict__ in, CoarseOpDev<T> op) {
   constexpr int np = 8 * NT;
   __shared__ T res[5 * 2 * np];
@@ -282,8 +283,14 @@ __global__ __launch_bounds__(320) void coarse_apply_once_kernel(T* __restrict__ 
   } else {
     const int mu = w - 1;
     y = op.nb[(size_t)mu * V + x];
-    const T* vin = y >= 0 ? in + (size_t)y * n * 2 : op.halo + op.hoff[mu] + (size_t)(-1 - y) * n * 2;
-    wave_mv2<T, NT>(Mx + (size_t)(1 + mu) * op.msize * 2, vin, in + (size_t)x * n * 2, n, res + (size_t)w * 2 * np, tmpb + (size_t)mu * 2 * np);
+    if (DEFER && y < 0) {
+      // the forward neighbour lives on another process and its data is still travelling: this term is added after the
+      // exchange (CoarseOp::apply); the backward product of this link is the sender's business (coarse_halo_pack_kernel)
+      for (int k = threadIdx.x & 63; k < 2 * np; k += 64) res[(size_t)w * 2 * np + k] = 0;
+    } else {
+      const T* vin = y >= 0 ? in + (size_t)y * n * 2 : op.halo + op.hoff[mu] + (size_t)(-1 - y) * n * 2;
+      wave_mv2<T, NT>(Mx + (size_t)(1 + mu) * op.msize * 2, vin, in + (size_t)x * n * 2, n, res + (size_t)w * 2 * np, tmpb + (size_t)mu * 2 * np);
+    }
   }
   __syncthreads();
   if (w > 0 && y >= 0) {
@@ -395,6 +402,11 @@ __global__ void coarse_halo_pack_kernel(T* __restrict__ send, const T* __restric
 template <typename T>
 void CoarseOp<T>::halo_exchange(const T* in, hipStream_t st) const {
   if (!arena_.active()) return;
+  pack_and_begin(in, st);
+  arena_.exchange_finish(comm_, st);
+}
+template <typename T>
+void CoarseOp<T>::pack_and_begin(const T* in, hipStream_t st) const {
   const int total = arena_.total_sites();
   T* send = reinterpret_cast<T*>(arena_.send());
   const CoarseOpDev<T> op = dev();
@@ -408,7 +420,6 @@ void CoarseOp<T>::halo_exchange(const T* in, hipStream_t st) const {
   DDAMG_HIP_CHECK(hipGetLastError());
   arena_.mark_packed(st);
   arena_.exchange_begin(comm_, st);
-  arena_.exchange_finish(comm_, st);
 }
 
 template <typename T>
@@ -429,29 +440,59 @@ static void launch_site(const CoarseOpDev<T>& op, T* out, const T* in, int s0, i
 
 template <typename T> void CoarseOp<T>::apply(T* out, const T* in, hipStream_t st) const {
   DDAMG_REQUIRE(out != in, "coarse apply cannot run in place");
-  halo_exchange(in, st);
+  // On a process grid the exchange travels while everything that does not need it is computed (the reference's order of
+  // events, src/coarse_oddeven_generic.c:447-581: ghost_sendrecv, interior hopping terms, ghost_wait, the rest).
+  const bool dist = arena_.active();
+  static const bool no_overlap = getenv("DDAMG_COARSE_NO_OVERLAP") != nullptr;
+  const bool overlap = dist && !no_overlap;
+  if (dist) pack_and_begin(in, st);
+  if (dist && !overlap) arena_.exchange_finish(comm_, st);
   static const bool twice = getenv("DDAMG_COARSE_APPLY_TWICE") != nullptr;
   static const int min_sites = getenv("DDAMG_COARSE_APPLY_ONCE_MIN_SITES") ? atoi(getenv("DDAMG_COARSE_APPLY_ONCE_MIN_SITES")) : 2048;
   if (twice || V_ < min_sites) {   // small (coarsest) lattices sit in the Infinity Cache: the second read is free, the extra launch is not
-    launch_site<T>(dev(), out, in, 0, V_, MODE_FULL, 1.0, -1.0, false, st);
+    if (overlap) {
+      launch_site<T>(dev(), out, in, 0, (int)h_interior_.size(), MODE_FULL, 1.0, -1.0, false, st, d_interior_);
+      arena_.exchange_finish(comm_, st);
+      launch_site<T>(dev(), out, in, 0, (int)h_boundary_.size(), MODE_FULL, 1.0, -1.0, false, st, d_boundary_);
+    } else {
+      launch_site<T>(dev(), out, in, 0, V_, MODE_FULL, 1.0, -1.0, false, st);
+    }
     return;
   }
   if (!bwd_) DDAMG_HIP_CHECK(device_alloc(&bwd_, sizeof(T) * 4 * (size_t)V_ * n_ * 2));
   const CoarseOpDev<T> op = dev();
-#define DDAMG_CASE(NTV) case NTV: hipLaunchKernelGGL((coarse_apply_once_kernel<T, NTV>), dim3(V_), dim3(320), 0, st, out, bwd_, in, op); break;
+#define DDAMG_CASE(NTV) case NTV: if (overlap) hipLaunchKernelGGL((coarse_apply_once_kernel<T, NTV, true>), dim3(V_), dim3(320), 0, st, out, bwd_, in, op); \
+                                  else hipLaunchKernelGGL((coarse_apply_once_kernel<T, NTV, false>), dim3(V_), dim3(320), 0, st, out, bwd_, in, op); break;
   switch (nt_) {
     DDAMG_CASE(1) DDAMG_CASE(2) DDAMG_CASE(3) DDAMG_CASE(4) DDAMG_CASE(5) DDAMG_CASE(6) DDAMG_CASE(7) DDAMG_CASE(8)
     default: DDAMG_REQUIRE(false, "coarse operator: more than 64 dof per site are not supported");
   }
 #undef DDAMG_CASE
+  if (overlap) arena_.exchange_finish(comm_, st);
   const size_t total = (size_t)V_ * n_ * 2;
   hipLaunchKernelGGL(coarse_apply_once_finish_kernel<T>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, out, bwd_, op);
   DDAMG_HIP_CHECK(hipGetLastError());
+  // the forward terms across the process boundary that the first pass left out
+  if (overlap && n_fwd_off_ > 0)
+    launch_site<T>(op, out, in, 0, n_fwd_off_, MODE_HOP, 0.0, -1.0, true, st, d_fwd_off_sites_, d_fwd_off_mask_, false);
 }
 template <typename T> void CoarseOp<T>::hop(T* out, const T* in, int s0, int s1, double sign, bool accumulate, hipStream_t st) const {
   DDAMG_REQUIRE(out != in, "coarse hopping term cannot run in place");
-  halo_exchange(in, st);
-  launch_site<T>(dev(), out, in, s0, s1, MODE_HOP, 0.0, sign, accumulate, st);
+  static const bool no_overlap = getenv("DDAMG_COARSE_NO_OVERLAP") != nullptr;
+  if (!arena_.active() || no_overlap) {
+    halo_exchange(in, st);
+    launch_site<T>(dev(), out, in, s0, s1, MODE_HOP, 0.0, sign, accumulate, st);
+    return;
+  }
+  // the sites of [s0, s1) without a neighbour on another process while the exchange is in flight, the others after it
+  pack_and_begin(in, st);
+  auto sub = [&](const std::vector<int>& h, const int* d, int& n) { const int a = (int)(std::lower_bound(h.begin(), h.end(), s0) - h.begin()); n = (int)(std::lower_bound(h.begin(), h.end(), s1) - h.begin()) - a; return d + a; };
+  int ni = 0, nbd = 0;
+  const int* li = sub(h_interior_, d_interior_, ni);
+  const int* lb = sub(h_boundary_, d_boundary_, nbd);
+  launch_site<T>(dev(), out, in, 0, ni, MODE_HOP, 0.0, sign, accumulate, st, li);
+  arena_.exchange_finish(comm_, st);
+  launch_site<T>(dev(), out, in, 0, nbd, MODE_HOP, 0.0, sign, accumulate, st, lb);
 }
 template <typename T> void CoarseOp<T>::self_mul(T* out, const T* in, int s0, int s1, bool inverse, hipStream_t st) const {
   DDAMG_REQUIRE(out != in, "coarse self coupling cannot run in place");
@@ -536,6 +577,10 @@ template <typename T> CoarseOp<T>::~CoarseOp() {
   if (Minv_) (void)hipFree(Minv_);
   if (bwd_) (void)hipFree(bwd_);
   if (nb_) (void)hipFree(nb_);
+  if (d_interior_) (void)hipFree(d_interior_);
+  if (d_boundary_) (void)hipFree(d_boundary_);
+  if (d_fwd_off_sites_) (void)hipFree(d_fwd_off_sites_);
+  if (d_fwd_off_mask_) (void)hipFree(d_fwd_off_mask_);
 }
 template <typename T>
 void CoarseOp<T>::alloc(const Geometry& g, int n) {
@@ -547,7 +592,26 @@ void CoarseOp<T>::alloc(const Geometry& g, int n) {
   DDAMG_HIP_CHECK(device_zero(Minv_, sizeof(T) * 2 * msize_ * V_));
   DDAMG_HIP_CHECK(device_alloc(&nb_, sizeof(int) * 8 * V_));
   DDAMG_HIP_CHECK(hipMemcpy(nb_, g.nb.data(), sizeof(int) * 8 * V_, hipMemcpyHostToDevice));
-  if (g.distributed()) arena_.init(g, sizeof(T) * 2 * n);
+  if (g.distributed()) {
+    arena_.init(g, sizeof(T) * 2 * n);
+    std::vector<int> fwd;
+    std::vector<unsigned char> mask(V_, 0);
+    for (int s = 0; s < V_; s++) {
+      bool off = false;
+      for (int d = 0; d < 8; d++) if (g.nb[(size_t)d * V_ + s] < 0) { off = true; if (d < 4) mask[s] |= (unsigned char)(1u << d); }
+      (off ? h_boundary_ : h_interior_).push_back(s);
+      if (mask[s]) fwd.push_back(s);
+    }
+    auto up = [](int** d, const std::vector<int>& h) {
+      if (h.empty()) return;
+      DDAMG_HIP_CHECK(device_alloc(d, sizeof(int) * h.size()));
+      DDAMG_HIP_CHECK(hipMemcpy(*d, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice));
+    };
+    up(&d_interior_, h_interior_); up(&d_boundary_, h_boundary_); up(&d_fwd_off_sites_, fwd);
+    n_fwd_off_ = (int)fwd.size();
+    DDAMG_HIP_CHECK(device_alloc(&d_fwd_off_mask_, V_));
+    DDAMG_HIP_CHECK(hipMemcpy(d_fwd_off_mask_, mask.data(), V_, hipMemcpyHostToDevice));
+  }
 }
 
 static inline size_t tile_off(int nt, int i, int j) { return ((size_t)((i >> 3) * nt + (j >> 3)) * 64 + (i & 7) * 8 + (j & 7)) * 2; }

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--gauge", default="near_unit", choices=["near_unit", "random"])
     ap.add_argument("--self-exchange", default=None, help="e.g. -1,-1,-1,1: the process is its own neighbour in these directions (RCCL)")
     ap.add_argument("--rng", type=int, default=1, help="0: libc rand() in the reference's order, 1: device generator")
+    ap.add_argument("--gather", type=int, default=0, help="gather the coarsest level (ddamg_hip_params::gather_coarsest)")
     args = ap.parse_args()
     import ddalphaamg_amd as dd
     from ddalphaamg_amd import api
@@ -48,6 +49,7 @@ def main():
     p.mixed_precision, p.method, p.odd_even = args.mixed_precision, args.method, 1
     p.m0, p.csw = args.m0, args.csw
     p.test_vector_rng, p.rng_seed = args.rng, 20260101
+    p.gather_coarsest = args.gather
     if args.self_exchange:
         for mu, v in enumerate(int(x) for x in args.self_exchange.split(",")):
             p.process_grid[mu] = v
