@@ -27,7 +27,7 @@
 
 namespace ddamg {
 
-namespace {
+namespace sap_pair_detail {
 
 constexpr int HS = 128, BS = 256, FH = 32;   // sites per parity, per block, per parity class of a face (64-site faces)
 constexpr float EPS_F = 1e-6f;               // EPS_float (src/main.h:45)
@@ -432,7 +432,8 @@ __global__ __launch_bounds__(256) void sap_face_pack_kernel(FineOpDev<float> op,
 #undef DDAMG_PACK_DIR
 }
 
-}  // namespace
+}  // namespace sap_pair_detail
+using namespace sap_pair_detail;
 
 void sap_pair_launch(const SapPairArgs& a, bool dist, hipStream_t st) {
   if (a.nblocks <= 0) return;

@@ -11,7 +11,7 @@ from collections import defaultdict
 def short(name):
     if name.startswith("void "):
         name = name[5:]
-    return name.split("(")[0]
+    return name.replace("(anonymous namespace)::", "").split("(")[0]
 
 
 def stats(db, out):
