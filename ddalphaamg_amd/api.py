@@ -85,6 +85,7 @@ def load_library():
         "ddamg_hip_create": [ctypes.POINTER(Params), ctypes.POINTER(vp)],
         "ddamg_hip_destroy": [vp],
         "ddamg_hip_set_gauge": [vp, dp, ctypes.c_int, dp],
+        "ddamg_hip_set_gauge2": [vp, dp, dp, ctypes.c_int, dp],
         "ddamg_hip_set_operator": [vp, dp, dp],
         "ddamg_hip_get_operator": [vp, dp, dp],
         "ddamg_hip_vec_create": [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)],
@@ -283,6 +284,15 @@ class Context:
             raise DDAMGError("set_gauge: gauge field must hold V*4*9 complex numbers")
         plaq = ctypes.c_double(0)
         _check(self._lib.ddamg_hip_set_gauge(self._h, _dp(a), int(bool(anti_pbc)), ctypes.byref(plaq)))
+        return plaq.value
+
+    def set_gauge2(self, hopp_gauge_lex, clover_gauge_lex, anti_pbc=False):
+        """hopping term from the first field, clover term and plaquette from the second (open boundaries)"""
+        a = np.ascontiguousarray(hopp_gauge_lex, dtype=np.float64); b = np.ascontiguousarray(clover_gauge_lex, dtype=np.float64)
+        if a.size != self.volume(0) * 72 or b.size != a.size:
+            raise DDAMGError("set_gauge2: both gauge fields must hold V*4*9 complex numbers")
+        plaq = ctypes.c_double(0)
+        _check(self._lib.ddamg_hip_set_gauge2(self._h, _dp(a), _dp(b), int(bool(anti_pbc)), ctypes.byref(plaq)))
         return plaq.value
 
     def set_operator(self, D_lex, clover_lex):

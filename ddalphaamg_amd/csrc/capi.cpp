@@ -177,6 +177,18 @@ int ddamg_hip_set_gauge(ddamg_hip_ctx* c, const double* gauge_lex, int anti_pbc,
   DDAMG_API_END
 }
 
+int ddamg_hip_set_gauge2(ddamg_hip_ctx* c, const double* hopp_gauge_lex, const double* clover_gauge_lex, int anti_pbc, double* plaquette) {
+  // two passes of the one-field routine: D from the first field, clover term and plaquette from the second
+  if (hopp_gauge_lex == clover_gauge_lex) return ddamg_hip_set_gauge(c, hopp_gauge_lex, anti_pbc, plaquette);
+  if (int rc = ddamg_hip_set_gauge(c, hopp_gauge_lex, anti_pbc, nullptr)) return rc;
+  DDAMG_API_BEGIN
+  const std::vector<double> D_hopp = c->D_host;
+  if (ddamg_hip_set_gauge(c, clover_gauge_lex, anti_pbc, plaquette)) throw std::runtime_error(g_last_error);
+  c->D_host = D_hopp;
+  upload_operator(c);
+  DDAMG_API_END
+}
+
 int ddamg_hip_set_operator(ddamg_hip_ctx* c, const double* D_lex, const double* clover_lex) {
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c && D_lex && clover_lex, "null argument");

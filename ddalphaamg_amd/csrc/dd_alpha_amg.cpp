@@ -188,7 +188,7 @@ void params_from_struct(const dd_alpha_amg_parameters& a, ddamg_hip_params& hp) 
 
 void common_init(const dd_alpha_amg_par& p) {
   if (S.inited) fatal("dd_alpha_amg_init called twice (one solver instance per process, src/dd_alpha_amg.c:28-33)");
-  if (p.bc == 0) fatal("bc = 0 (Dirichlet/open boundaries) is not supported by the GPU path");
+  if (p.bc == 0 && !p.global_time) fatal("bc = 0 needs the global_time callback (src/dd_alpha_amg.c:206)");
   S.par = p;
   S.hp.csw = p.csw;           // g.csw = p.csw (src/dd_alpha_amg.c:103)
   S.hp.m0 = p.m0;             // l.real_shift = p.m0
@@ -342,6 +342,28 @@ double dd_alpha_amg_set_conf(double* gauge_field) {
       for (int k = 0; k < 18; k++, j++) U[j] = gauge_field[i + k];
     }
   double plaq = 0;
+  if (S.par.bc == 0) {
+    // open boundaries (src/dd_alpha_amg.c:205-246): on the time slices tg == 0 and tg >= T-2 the time links are dropped from
+    // the hopping term and kept for the clover term; the links leaving the last time slice must be zero in the caller's field
+    std::vector<double> H(U);
+    const int Tglob = S.P[0] * L[0];
+    int ifail = 0;
+    j = 0;
+    for (int t = 0; t < L[0]; t++) {
+      const int tg = S.par.global_time(t);
+      for (int z = 0; z < L[1]; z++) for (int y = 0; y < L[2]; y++) for (int x = 0; x < L[3]; x++, j += 72)
+        if (tg == 0 || tg >= Tglob - 2)
+          for (int k = 0; k < 18; k++) {
+            if (tg == Tglob - 1 && U[j + k] != 0.0) ifail++;
+            H[j + k] = 0.0;
+          }
+    }
+    if (ifail) fatal("Error in \"dd_alpha_amg_set_conf\": Gauge field does not fit expected boundary conditions.");
+    check(ddamg_hip_set_gauge2(S.ctx, H.data(), U.data(), 0, &plaq), "dd_alpha_amg_set_conf");
+    S.conf_set = true; S.fields_dirty = false;
+    S.current_mass = S.hp.m0;
+    return plaq;
+  }
   // as in the reference, the boundary condition is NOT applied here: the caller's links carry it
   // (src/dd_alpha_amg.c:188-252 copies the field as it is)
   check(ddamg_hip_set_gauge(S.ctx, U.data(), 0, &plaq), "dd_alpha_amg_set_conf");

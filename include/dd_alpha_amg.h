@@ -30,7 +30,8 @@
  *    global / local as in the reference (src/init.c:455-520) and the library builds its Cartesian communicator over
  *    MPI_COMM_WORLD itself (libddamg_hip_mpi.so; the host application has called MPI_Init, as with the reference);
  *    halo exchange over RCCL, or staged through MPI with DDAMG_HIP_TRANSPORT=host;
- *  - bc == 0 (open/Dirichlet boundaries, two gauge fields) is rejected with a fatal error;
+ *  - bc == 0 (open boundaries) follows src/dd_alpha_amg.c:205-246: time links dropped from the hopping term on the time
+ *    slices 0, T-2, T-1, kept for the clover term (ddamg_hip_set_gauge2);
  *  - the *_external_threading variants ignore core/thread ids and barriers: there is no host
  *    threading on the GPU path (every calling thread but thread 0 of core 0 returns at once).
  */

@@ -86,6 +86,10 @@ int ddamg_hip_destroy(ddamg_hip_ctx* ctx);
  * anti_pbc != 0 negates the T-links of the last time slice first, as read_conf does
  * (src/io.c:536-541). */
 int ddamg_hip_set_gauge(ddamg_hip_ctx* ctx, const double* gauge_lex, int anti_pbc, double* plaquette);
+/* dirac_setup( hopp, clover ) with two different fields (src/dirac.c:60-168, as dd_alpha_amg_set_conf calls it for bc == 0,
+ * src/dd_alpha_amg.c:205-246): the hopping term D = U/2 from `hopp_gauge_lex`, the clover term and the returned plaquette
+ * from `clover_gauge_lex` (open boundaries: time links dropped from the hopping term near the boundary). */
+int ddamg_hip_set_gauge2(ddamg_hip_ctx* ctx, const double* hopp_gauge_lex, const double* clover_gauge_lex, int anti_pbc, double* plaquette);
 
 /* direct upload of an operator in the reference's own storage (g.op_double.D: [V][36] complex,
  * g.op_double.clover: [V][42] complex; src/dirac.c:80,386-398) -- the path behind

@@ -129,3 +129,60 @@ randomize test vectors: 0
         assert abs(rr / 1.162251e-11 - 1.0) < 1e-3    # the scalar reference's final residual (measured: 1.162252e-11)
     finally:
         lib.dd_alpha_amg_free()
+
+
+def test_open_boundaries_bc_0(gold4):
+    """bc == 0 (src/dd_alpha_amg.c:205-246): the time links of the time slices 0, T-2 and T-1 are dropped from the hopping
+    term and kept for the clover term (dirac_setup with two fields); the links leaving the last time slice must be zero.
+    Checked against the operator assembled by hand from the one-field path, and by a solve."""
+    import ddalphaamg_amd as dd
+    from ddalphaamg_amd import api
+    lib = libiface.bind()
+    par = libiface.Par()
+    a = par.amg_params
+    a.number_of_levels = 2
+    for mu in range(4):
+        a.global_lattice[0][mu] = a.local_lattice[0][mu] = 4
+        a.block_lattice[0][mu] = 2
+        a.global_lattice[1][mu] = a.local_lattice[1][mu] = 2
+    a.mg_basis_vectors[0] = 20; a.setup_iterations[0] = 3
+    a.post_smooth_iterations[0] = 2; a.post_smooth_block_iterations[0] = 4
+    a.coarse_grid_iterations, a.coarse_grid_maximum_number_of_restarts, a.coarse_grid_tolerance = 100, 5, 5e-2
+    a.solver_mass = a.setup_mass = -0.3; a.c_sw = 1.0
+    a.discard_setup_after = 1; a.update_setup_after = 1
+    conf_idx = libiface.CONF_INDEX_FCT(lambda t, z, y, x, mu: ((((t * 4 + z) * 4 + y) * 4 + x) * 4 + mu) * 18)
+    vec_idx = libiface.VECTOR_INDEX_FCT(lambda t, z, y, x: (((t * 4 + z) * 4 + y) * 4 + x) * 24)
+    gtime = libiface.GLOBAL_TIME_FCT(lambda t: t)
+    par.conf_index_fct, par.vector_index_fct, par.global_time = conf_idx, vec_idx, gtime
+    par.bc, par.m0, par.csw, par.setup_m0 = 0, -0.3, 1.0, -0.3
+    U = gold4["gauge"].copy()
+    U[-64:, 0] = 0.0                                  # open boundary: no links leave the last time slice
+    # expectation from the one-field path: clover term of U, hopping term of U with the boundary time links removed
+    p = api.default_params(); p.num_levels = 1
+    for mu in range(4):
+        p.local_lattice[0][mu] = 4; p.block_lattice[0][mu] = 2
+    p.m0, p.csw = -0.3, 1.0
+    ctx = dd.Context(p)
+    ctx.set_gauge(U, anti_pbc=False)
+    _, cl_ref = ctx.get_operator()
+    H = U.copy(); H[:64, 0] = 0.0; H[-128:, 0] = 0.0
+    ctx.set_gauge(H, anti_pbc=False)
+    D_ref, _ = ctx.get_operator()
+    ctx.close()
+    lib.dd_alpha_amg_init_external_threading(par, 1, 1)
+    try:
+        dp = ctypes.POINTER(ctypes.c_double)
+        lib.dd_alpha_amg_set_conf(U.ctypes.data_as(dp))
+        D = np.ctypeslib.as_array(lib.dd_alpha_amg_get_gauge_pointer(), shape=(256, 36, 2))
+        cl = np.ctypeslib.as_array(lib.dd_alpha_amg_get_clover_pointer(), shape=(256, 42, 2))
+        assert np.array_equal(D, D_ref) and np.array_equal(cl, cl_ref)
+        status = (ctypes.c_int * 2)()
+        lib.dd_alpha_amg_setup(3, status)
+        b = np.zeros((256, 12, 2)); b[..., 0] = 1.0
+        x = np.zeros_like(b)
+        rr = lib.dd_alpha_amg_wilson_solve(x.ctypes.data_as(dp), b.ctypes.data_as(dp), 1e-10, 1.0, 1.0, status)
+        assert rr < 1e-10 and 0 < status[0] < 40
+        from oracle import orc
+        assert relerr(orc.dirac_apply([4, 4, 4, 4], D_ref, cl_ref, x, 64), b) < 1e-9
+    finally:
+        lib.dd_alpha_amg_free()
