@@ -290,6 +290,35 @@ def pmc_traffic(precision):
     return None, None
 
 
+def coarse_operator_report():
+    """what the north star asks to see next to the solve: the coarse operator against its roofline and the matrix-core
+    utilisation where the coarse operator is applied to many right-hand sides.  From the committed round-2 profiles
+    (profiles/r02_solve32_kernel_stats.csv, profiles/r02_pmc_mfma.json), not measured in this run."""
+    import csv
+    out = {}
+    try:
+        rows = list(csv.DictReader(open(os.path.join(REPO, "profiles", "r02_solve32_kernel_stats.csv"))))
+        r = [x for x in rows if "coarse_site_kernel<float, 6>" in x["Name"]][0]
+        us = float(r["AverageUs"]); n = 48; sites = 8 ** 4 // 2
+        byts = sites * 8 * n * n * 8        # a half hopping term reads 4 own and 4 neighbours' links per site, 8 B per complex
+        out["solve_path"] = {"kernel": "coarse_site_kernel (one right-hand side: VALU tile GEMV, arithmetic intensity ~2 flop/B)",
+                             "us_per_half_hopping_term_8^4_n48": us, "GB/s": byts / us / 1e3,
+                             "note": "302 MB of couplings per launch: above the HBM peak because the 8^4 coarse operator lives in the 256 MB Infinity Cache",
+                             "source": "profiles/r02_solve32_kernel_stats.csv"}
+    except Exception:
+        pass
+    try:
+        d = json.load(open(os.path.join(REPO, "profiles", "r02_pmc_mfma.json")))
+        k = [x for x in d if "coarse_batch_apply_kernel" in x][0]
+        busy = d[k]["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"]; cyc = d[k]["GRBM_GUI_ACTIVE"]["mean"] / 8.0   # counted per XCD
+        out["multi_rhs"] = {"kernel": "coarse_batch_apply_kernel (all 2*Nvec columns of the coarse-level Galerkin construction at once: "
+                                      "complex n x n times n x 64 on v_mfma_f32_16x16x4_f32)",
+                            "mfma_busy": busy / (cyc * 1024.0), "source": "profiles/r02_pmc_mfma.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), 48^4 three-level setup"}
+    except Exception:
+        pass
+    return out or None
+
+
 def small_lattice_leg(device):
     """BASELINE configs[1]: the reference's own 8^4 sample configuration (gauge field from tests/golden), fine operator
     only, fp32, 1000 timed applies after 50 warm-ups.  Its 3 MB working set lives in the caches, so it is reported
@@ -551,6 +580,7 @@ def main():
                     if "reference_32" in cb and L == [32, 32, 32, 32]:
                         res["iterations_reference"] = cb["reference_32"]["iterations"]
                         res["speedup_vs_reference_32"] = cb["reference_32"]["seconds"] / res["seconds_per_solve"]
+            res["coarse_operator"] = coarse_operator_report()
             out["solve"] = res
         except Exception as e:
             out["solve"] = {"error": str(e)[:300]}
