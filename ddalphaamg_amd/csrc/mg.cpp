@@ -535,16 +535,42 @@ void Multigrid<T>::build_coarse_operator(int l) {
     const size_t cs = (size_t)nx.g->V * nx.n * 2;       // one coarse vector
     // the batch workspace is allocated once per setup and kept until release_setup_workspace(): allocating and
     // freeing tens of GB for every build costs more than the build itself
+    static const bool no_slab = getenv("DDAMG_GALERKIN_NO_SLABS") != nullptr;
     if (!gal_W_) {
       size_t free_b = 0, total_b = 0;
       DDAMG_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
       gal_batch_ = 2 * N;
       while (gal_batch_ > 1 && (5 * gal_batch_ > 256 || sizeof(T) * 5 * gal_batch_ * (ws + cs) > free_b / 2)) gal_batch_ = (gal_batch_ + 1) / 2;
-      DDAMG_HIP_CHECK(device_alloc(&gal_W_, sizeof(T) * 5 * gal_batch_ * ws));
+      gal_slab_aggs_ = 0;
+      const char* force_slab = getenv("DDAMG_GALERKIN_SLAB_AGGS");   // tests: slabs of this many aggregates at any volume
+      if ((gal_batch_ < 2 * N || force_slab) && 5 * 2 * N <= 256 && !lv.fop->distributed() && !no_slab) {
+        // all columns do not fit next to each other for the whole lattice.  Fewer columns per pass starve the N dimension
+        // of the restriction GEMM (64^4: 6 of 48 columns, 30 of 240 fields, 4x the time); instead keep ALL columns and walk
+        // the lattice in slabs of whole aggregates -- D P and its restriction are local to an aggregate
+        const size_t per_agg = sizeof(T) * 5 * 2 * N * 24 * (size_t)lv.fip.agg_sites;
+        const size_t budget = free_b / 2 - sizeof(T) * 5 * 2 * N * cs;
+        gal_slab_aggs_ = (int)std::min<size_t>((size_t)lv.fip.num_aggs, std::max<size_t>(1, budget / per_agg));
+        if (force_slab) gal_slab_aggs_ = std::max(1, std::min(atoi(force_slab), lv.fip.num_aggs));
+        gal_batch_ = 2 * N;
+        DDAMG_HIP_CHECK(device_alloc(&gal_W_, per_agg * (size_t)gal_slab_aggs_));
+      } else {
+        DDAMG_HIP_CHECK(device_alloc(&gal_W_, sizeof(T) * 5 * gal_batch_ * ws));
+      }
       DDAMG_HIP_CHECK(device_alloc(&gal_C_, sizeof(T) * 5 * gal_batch_ * cs));
     }
     const int batch = gal_batch_;
     T *Wb = gal_W_, *Cb = gal_C_;
+    if (gal_slab_aggs_ > 0) {
+      const int nagg = lv.fip.num_aggs, as = lv.fip.agg_sites;
+      for (int a0 = 0; a0 < nagg; a0 += gal_slab_aggs_) {
+        const int na = std::min(gal_slab_aggs_, nagg - a0);
+        const size_t wss = (size_t)24 * na * as;        // one field of this slab
+        for (int c = 0; c < 2 * N; c++)
+          aggregate_dirac_slab<T>(Wb + (size_t)5 * c * wss, lv.fip.interp_vector(c % N), c / N, *lv.fop, lv.d_agg_face, (size_t)a0 * as, (size_t)na * as, st_);
+        lv.fip.restrict_batch_slab(Cb, cs, Wb, wss, 5 * 2 * N, a0, na, st_);
+      }
+      for (int c = 0; c < 2 * N; c++) galerkin_store_column<T>(nx.cop, Cb + (size_t)5 * c * cs, c, st_);
+    } else
     for (int c0 = 0; c0 < 2 * N; c0 += batch) {
       const int nb = std::min(batch, 2 * N - c0);
       for (int c = 0; c < nb; c++)

@@ -111,6 +111,7 @@ class Multigrid {
   T *gal_W_ = nullptr, *gal_C_ = nullptr;   // batched Galerkin workspace
   T* gal_cwork_ = nullptr;                  // the same for coarse levels (sized for level 1, the largest)
   int gal_batch_ = 0;
+  int gal_slab_aggs_ = 0;                   // > 0: all columns, the lattice in slabs of this many aggregates
  public:
   // wall-clock seconds per setup phase (stream-synchronised), filled when DDAMG_SETUP_TIMING is set
   std::vector<std::pair<std::string, double>> setup_times;

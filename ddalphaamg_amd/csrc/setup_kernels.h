@@ -16,6 +16,10 @@ namespace ddamg {
 template <typename T>
 void aggregate_dirac(T* W, const T* v, int chir, const FineOp<T>& op, const unsigned char* d_agg_face, hipStream_t st);
 
+// the same for the sites [site0, site0 + nsites) only; W then holds 5 fields of nsites sites each (stride 24*nsites)
+template <typename T>
+void aggregate_dirac_slab(T* W, const T* v, int chir, const FineOp<T>& op, const unsigned char* d_agg_face, size_t site0, size_t nsites, hipStream_t st);
+
 // column `col` of the five coarse matrices of every coarse site <- P^H W[part]
 template <typename T>
 void galerkin_column(CoarseOp<T>& cop, const Interpolation<T>& ip, const T* W, int col, T* work, hipStream_t st);

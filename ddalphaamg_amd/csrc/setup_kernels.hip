@@ -10,9 +10,10 @@ __device__ __forceinline__ void mask_chirality(T (&v)[24], int chir) {
   for (int k = 0; k < 12; k++) v[12 * (1 - chir) + k] = 0;
 }
 
+// W holds the sites [w0site, w0site + Vw) of the lattice only (Vw == V, w0site == 0: the whole lattice)
 template <typename T, int MU, bool DIST>
 __device__ __forceinline__ void agg_hop_pair(const T* __restrict__ v, int chir, const FineOpDev<T>& op, const unsigned char face,
-                                             size_t s, T (&w0)[24], T* __restrict__ W, size_t wstride) {
+                                             size_t s, T (&w0)[24], T* __restrict__ W, size_t wstride, size_t Vw, size_t w0site) {
   const size_t V = op.V;
   {
     const int j = op.nb[(size_t)MU * V + s];
@@ -33,13 +34,13 @@ __device__ __forceinline__ void agg_hop_pair(const T* __restrict__ v, int chir, 
       hop_accumulate<T, MU, true>(U, pn, acc);  // acc = -hop
 #pragma unroll
       for (int k = 0; k < 24; k++) acc[k] = -acc[k];
-      store_site<T, 24>(W + (size_t)(1 + MU) * wstride, V, s, acc);
+      store_site<T, 24>(W + (size_t)(1 + MU) * wstride, Vw, s - w0site, acc);
     } else {
       hop_accumulate<T, MU, true>(U, pn, w0);
       T z[24];
 #pragma unroll
       for (int k = 0; k < 24; k++) z[k] = 0;
-      store_site<T, 24>(W + (size_t)(1 + MU) * wstride, V, s, z);
+      store_site<T, 24>(W + (size_t)(1 + MU) * wstride, Vw, s - w0site, z);
     }
   }
   if (!(face & (1u << (4 + MU)))) {
@@ -54,11 +55,11 @@ __device__ __forceinline__ void agg_hop_pair(const T* __restrict__ v, int chir, 
 
 template <typename T, bool DIST>
 __global__ __launch_bounds__(256) void aggregate_dirac_kernel(T* __restrict__ W, const T* __restrict__ v, int chir, FineOpDev<T> op,
-                                                              const unsigned char* __restrict__ agg_face) {
-  const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+                                                              const unsigned char* __restrict__ agg_face, size_t w0site, size_t Vw) {
+  const size_t s = w0site + (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t V = op.V;
-  if (s >= V) return;
-  const size_t ws = (size_t)24 * V;
+  if (s >= w0site + Vw) return;
+  const size_t ws = (size_t)24 * Vw;
   const unsigned char face = agg_face[s];
   T w0[24];
   {
@@ -69,11 +70,11 @@ __global__ __launch_bounds__(256) void aggregate_dirac_kernel(T* __restrict__ W,
     if (chir == 0) { load_site<T, 36>(op.clover, V, s, cl); herm6_mul<T>(cl, p, w0); }
     else { load_site<T, 36>(op.clover + (size_t)36 * V, V, s, cl); herm6_mul<T>(cl, p + 12, w0 + 12); }
   }
-  agg_hop_pair<T, 0, DIST>(v, chir, op, face, s, w0, W, ws);
-  agg_hop_pair<T, 1, DIST>(v, chir, op, face, s, w0, W, ws);
-  agg_hop_pair<T, 2, DIST>(v, chir, op, face, s, w0, W, ws);
-  agg_hop_pair<T, 3, DIST>(v, chir, op, face, s, w0, W, ws);
-  store_site<T, 24>(W, V, s, w0);
+  agg_hop_pair<T, 0, DIST>(v, chir, op, face, s, w0, W, ws, Vw, w0site);
+  agg_hop_pair<T, 1, DIST>(v, chir, op, face, s, w0, W, ws, Vw, w0site);
+  agg_hop_pair<T, 2, DIST>(v, chir, op, face, s, w0, W, ws, Vw, w0site);
+  agg_hop_pair<T, 3, DIST>(v, chir, op, face, s, w0, W, ws, Vw, w0site);
+  store_site<T, 24>(W, Vw, s - w0site, w0);
 }
 
 template <typename T>
@@ -84,12 +85,21 @@ void aggregate_dirac(T* W, const T* v, int chir, const FineOp<T>& op, const unsi
     DDAMG_HIP_CHECK(hipMemcpyAsync(W + chir * half, v + chir * half, sizeof(T) * half, hipMemcpyDeviceToDevice, st));
     DDAMG_HIP_CHECK(hipMemsetAsync(W + (1 - chir) * half, 0, sizeof(T) * half, st));
     op.halo_exchange(W, st);
-    hipLaunchKernelGGL((aggregate_dirac_kernel<T, true>), dim3((op.V() + 255) / 256), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face);
+    hipLaunchKernelGGL((aggregate_dirac_kernel<T, true>), dim3((op.V() + 255) / 256), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face, (size_t)0, (size_t)op.V());
   } else {
-    hipLaunchKernelGGL((aggregate_dirac_kernel<T, false>), dim3((op.V() + 255) / 256), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face);
+    hipLaunchKernelGGL((aggregate_dirac_kernel<T, false>), dim3((op.V() + 255) / 256), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face, (size_t)0, (size_t)op.V());
   }
   DDAMG_HIP_CHECK(hipGetLastError());
 }
+
+template <typename T>
+void aggregate_dirac_slab(T* W, const T* v, int chir, const FineOp<T>& op, const unsigned char* d_agg_face, size_t site0, size_t nsites, hipStream_t st) {
+  DDAMG_REQUIRE(!op.distributed(), "the slab form of the Galerkin construction is a single-process path");
+  hipLaunchKernelGGL((aggregate_dirac_kernel<T, false>), dim3((unsigned)((nsites + 255) / 256)), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face, site0, nsites);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+template void aggregate_dirac_slab<float>(float*, const float*, int, const FineOp<float>&, const unsigned char*, size_t, size_t, hipStream_t);
+template void aggregate_dirac_slab<double>(double*, const double*, int, const FineOp<double>&, const unsigned char*, size_t, size_t, hipStream_t);
 
 // work: 5 coarse AoS vectors [part][Vc][n]; write column `col` of matrix `part` of every coarse site
 template <typename T>

@@ -38,6 +38,8 @@ struct Interpolation {
   // 256 fields instead of once per 5, and the reduction over the sites of an aggregate is the K dimension of
   // v_mfma_f32_32x32x2_f32 instead of wavefront shuffles.
   void restrict_batch(T* phi_c, size_t out_stride, const T* phi, size_t in_stride, int nw, hipStream_t st) const;
+  // the same for the aggregates [agg0, agg0 + naggs): phi holds only their sites (fields of naggs*agg_sites sites)
+  void restrict_batch_slab(T* phi_c, size_t out_stride, const T* phi, size_t in_stride, int nw, int agg0, int naggs, hipStream_t st) const;
   static bool restrict_batch_available(int agg_sites_, int nvec_) { return sizeof(T) == 4 && agg_sites_ % 16 == 0 && nvec_ <= 32; }
   // phi (+)= P phi_c
   void interpolate(T* phi, const T* phi_c, bool add, hipStream_t st) const;

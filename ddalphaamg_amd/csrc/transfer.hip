@@ -120,11 +120,12 @@ void Interpolation<T>::restrict5(T* phi_c, size_t out_stride, const T* phi, size
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(256, 2) void restrict_mfma_kernel(float* __restrict__ out, size_t out_stride, const float* __restrict__ W, size_t wstride, int nw,
                                                               const float* __restrict__ P, size_t pstride, int nvec, int V, int agg_sites,
-                                                              const int* __restrict__ agg_csite) {
+                                                              const int* __restrict__ agg_csite, int a0, size_t Vw, size_t w0site) {
   constexpr int KS = 16;            // sites per K block
   __shared__ float As[4 * KS][33];
   __shared__ float Bs[4 * KS][257];
-  const int a = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  // W holds the sites [w0site, w0site + Vw) only (the whole lattice: a0 = 0, Vw = V, w0site = 0)
+  const int a = a0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const size_t s0 = (size_t)a * agg_sites;
   const int ntile = (nw + 31) >> 5;
   for (int e = tid; e < 4 * KS * 33; e += 256) (&As[0][0])[e] = 0.f;   // rows i >= nvec stay zero
@@ -138,6 +139,7 @@ __global__ __launch_bounds__(256, 2) void restrict_mfma_kernel(float* __restrict
       for (int sb = 0; sb < agg_sites; sb += KS) {
         __syncthreads();
         const size_t row = ((size_t)kk * V + s0 + sb) * 4;
+        const size_t wrow = ((size_t)kk * Vw + (s0 - w0site) + sb) * 4;
         for (int e = tid; e < nvec * KS; e += 256) {
           const int i = e / KS, sl = e % KS;
           const float4 v = *reinterpret_cast<const float4*>(P + (size_t)i * pstride + row + sl * 4);
@@ -147,7 +149,7 @@ __global__ __launch_bounds__(256, 2) void restrict_mfma_kernel(float* __restrict
         for (int r = 0; r < 16; r++) {
           const int e = tid + 256 * r, col = e / KS, sl = e % KS;
           float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (col < nw) v = *reinterpret_cast<const float4*>(W + (size_t)col * wstride + row + sl * 4);
+          if (col < nw) v = *reinterpret_cast<const float4*>(W + (size_t)col * wstride + wrow + sl * 4);
           Bs[4 * sl][col] = v.x; Bs[4 * sl + 1][col] = v.y; Bs[4 * sl + 2][col] = v.z; Bs[4 * sl + 3][col] = v.w;
         }
         __syncthreads();
@@ -189,7 +191,19 @@ template <typename T>
 void Interpolation<T>::restrict_batch(T* phi_c, size_t out_stride, const T* phi, size_t in_stride, int nw, hipStream_t st) const {
   if constexpr (sizeof(T) == 4) {
     DDAMG_REQUIRE(restrict_batch_available(agg_sites, nvec) && nw >= 1 && nw <= 256, "batched restriction: unsupported shape");
-    hipLaunchKernelGGL(restrict_mfma_kernel, dim3(num_aggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite);
+    hipLaunchKernelGGL(restrict_mfma_kernel, dim3(num_aggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
+                       0, (size_t)V, (size_t)0);
+    DDAMG_HIP_CHECK(hipGetLastError());
+  } else {
+    DDAMG_REQUIRE(false, "batched restriction is an fp32 path");
+  }
+}
+template <typename T>
+void Interpolation<T>::restrict_batch_slab(T* phi_c, size_t out_stride, const T* phi, size_t in_stride, int nw, int agg0, int naggs, hipStream_t st) const {
+  if constexpr (sizeof(T) == 4) {
+    DDAMG_REQUIRE(restrict_batch_available(agg_sites, nvec) && nw >= 1 && nw <= 256 && agg0 >= 0 && agg0 + naggs <= num_aggs, "batched restriction: unsupported shape");
+    hipLaunchKernelGGL(restrict_mfma_kernel, dim3(naggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
+                       agg0, (size_t)naggs * agg_sites, (size_t)agg0 * agg_sites);
     DDAMG_HIP_CHECK(hipGetLastError());
   } else {
     DDAMG_REQUIRE(false, "batched restriction is an fp32 path");

@@ -391,6 +391,25 @@ def test_setup_and_solve_with_256_site_blocks_vs_reference(gold_b4, gold8):
     ctx.close()
 
 
+def test_slab_wise_galerkin_construction_is_the_same_operator(gold_b4, gold8, monkeypatch):
+    """volumes whose Galerkin workspace does not hold all columns for the whole lattice (64^4) walk the lattice in slabs of
+    whole aggregates with ALL columns; forced here with slabs of 5 of the 16 aggregates (an uneven last slab):
+    the coarse operator, and with it every number of the solve, must not change"""
+    res = []
+    for slabs in (None, "5"):
+        if slabs:
+            monkeypatch.setenv("DDAMG_GALERKIN_SLAB_AGGS", slabs)
+        ctx = make_ctx_b4(gold_b4, gold8)
+        ctx.setup(3)
+        Dc, clc = ctx.get_coarse_operator()
+        b = np.zeros((4096, 12, 2)); b[..., 0] = 1.0
+        x, it, cit, rr = ctx.solve(b, 1e-10)
+        res.append((Dc, clc, x, it, cit, rr))
+        ctx.close()
+    assert np.array_equal(res[0][0], res[1][0]) and np.array_equal(res[0][1], res[1][1])
+    assert res[0][3:] == res[1][3:] and np.array_equal(res[0][2], res[1][2])
+
+
 @pytest.mark.parametrize("fixture", ["ref_16x16_3lvl.npz", "ref_16x16_3lvl_hard.npz"], ids=["random-links", "smooth-links"])
 def test_three_level_production_block_shapes_16x16(fixture):
     """16^4 with the block shapes of the production configurations -- 4^4 Schwarz blocks and aggregates on the fine level
