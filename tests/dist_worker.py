@@ -256,6 +256,11 @@ def run_amg(rank, world, P, mp, levels=2, G=None, method=2, gather=0):
     tol32 = {"galerkin_D": 2e-5, "galerkin_self": 2e-5, "smoother": 5e-5, "coarse_apply": 2e-5, "solution": 1e-7, "solution_own_setup": 1e-7}
     for k, v in errs.items():
         assert v < tol32[k], (k, v)
+    # every rank must have taken the same stopping decisions (the Krylov control flow runs on every host from the same
+    # reduced numbers: a rank that read a stale buffer would diverge here before it hangs in a collective)
+    decisions = [None] * world
+    dist.all_gather_object(decisions, (it, cit, it2, cit2, round(rr, 18), round(rr2, 18)))
+    assert all(d == decisions[0] for d in decisions), decisions
     assert abs(it - it1) <= (1 if levels == 2 else 2) and abs(it2 - it1) <= 2, (it1, it, it2)
     if gather:   # the coarsest system is the undivided one: the same solver trajectory up to the rounding of the Galerkin operator
         assert it == it1 and abs(cit - cit1) <= max(2, cit1 // 50), (it1, cit1, it, cit)
