@@ -66,6 +66,10 @@ CASES = {
     # mixed precision 2 (fgmres_MP): AMG-preconditioned on 4^4 and pure GMRES(50) on 8^4 (383 iterations)
     "4x4_mp2": dict(conf="conf/4x4x4x4b6.0000id3n1", levels=2, L="4 4 4 4", B="2 2 2 2", nvec=20, setup=4, extra="", method=2, mp=2,
                     keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),
+    # the ragged lattice below with mixed precision 2 (fgmres_MP)
+    "ragged_mp2": dict(conf="", synthetic=4711, levels=2, L="8 4 4 8", B="4 2 2 2", nvec=12, setup=2, m0=0.3,
+                       extra="d1 global lattice: 2 2 2 2\nd1 local lattice: 2 2 2 2", method=2, mp=2,
+                       keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),
     # four different extents everywhere: lattice 8x4x4x8 (T,Z,Y,X), Schwarz blocks 4x2x2x2, aggregates 4x2x2x4
     # (coarse lattice 2x2x2x2), seeded random SU(3) links, m0 = 0.3
     "ragged": dict(conf="", synthetic=4711, levels=2, L="8 4 4 8", B="4 2 2 2", nvec=12, setup=2, m0=0.3,

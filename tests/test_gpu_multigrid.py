@@ -286,21 +286,20 @@ def test_three_level_kcycle_solve(gold8, mp, fixture):
 
 def test_mixed_precision_2_amg(gold4):
     """fgmres_MP (fp32 Krylov basis + V-cycle returning D*phi from the smoother residual, fp64 outer updates):
-    reference 4^4 run: 11 iterations, 73 coarse iterations, 3.34e-11 (tests/golden/ref_4x4_mp2.npz)"""
+    reference runs: 4^4 11 iterations, 73 coarse iterations, 3.34e-11 (tests/golden/ref_4x4_mp2.npz); ragged lattice 6 / 12 / 5.2e-12
+    (ref_ragged_mp2.npz)"""
     from conftest import load_golden
-    if volume(gold4) != 256:
-        pytest.skip("the mixed-precision-2 reference run exists for the 4^4 configuration")
-    gm = load_golden("ref_4x4_mp2.npz")
+    gm = load_golden("ref_4x4_mp2.npz" if volume(gold4) == 256 else "ref_ragged_mp2.npz")
     ctx = make_ctx(gold4, mixed_precision=2)
-    ctx.setup(4)
-    b = np.zeros((256, 12, 2)); b[..., 0] = 1.0
+    ctx.setup(setup_iterations(gold4))
+    b = np.zeros((volume(gold4), 12, 2)); b[..., 0] = 1.0
     x, it, cit, rr = ctx.solve(b, 1e-10)
     assert it == int(gm["ones_solve_iters"][0]) and abs(cit - int(gm["ones_solve_iters"][1])) <= 8
     assert rr < 1e-10 and abs(rr / float(gm["ones_solve_norm_res"][0]) - 1.0) < 0.2
     hist = ctx.residual_history(); ref = gm["ref_log_ones_history"]
     assert len(hist) == len(ref) and np.all(np.abs(hist / ref - 1.0) < 0.05)   # fp32 Krylov basis: the first iterations agree to 1e-7, the last ones to a few percent
     from oracle import orc
-    assert relerr(orc.dirac_apply([4, 4, 4, 4], gold4["D"], gold4["clover"], x, 64), b) < 1e-9
+    assert relerr(orc.dirac_apply(lattice(gold4), gold4["D"], gold4["clover"], x, 64), b) < 1e-9
     ctx.close()
 
 
