@@ -29,6 +29,11 @@ struct FineOpDev {
   const int* tile_nb;             // [8][V/256]
   const unsigned short* tnb;      // [256][8]
   const unsigned char* parity;    // [V] global parity of every site (0 even, 1 odd)
+  // two-row storage of the links (null unless every link is a real multiple +-1/2 of an SU(3) matrix, checked at upload):
+  // rows 0 and 1 as 12 reals per link in three 16-byte chunk rows, direction mu at Dc + mu*12*V; the third row is
+  // sgn * 2 conj(row0 x row1), sgn = -1 on the links that carry the anti-periodic boundary sign
+  const T* Dc;
+  const signed char* Dsgn;        // [4][V]
 };
 
 template <typename T>
@@ -44,7 +49,8 @@ class FineOp {
   void upload(const Geometry& g, const double* D_ref, const double* clover_ref, hipStream_t st);
   // eta = D_W phi; with a process grid: pack -> exchange (overlapped with the interior tiles) -> boundary tiles
   void apply(T* eta, const T* phi, hipStream_t st) const;
-  FineOpDev<T> dev() const { return FineOpDev<T>{D_, clover_, clover_inv_, nb_, V_, halo_.recv(), halo_.dev(), tile_nb_, tnb_, parity_}; }
+  FineOpDev<T> dev() const { return FineOpDev<T>{D_, clover_, clover_inv_, nb_, V_, halo_.recv(), halo_.dev(), tile_nb_, tnb_, parity_, Dc_, Dsgn_}; }
+  bool links_compressed() const { return Dc_ != nullptr; }
   int V() const { return V_; }
   void set_comm(Comm* c) { comm_ = c; }
   // fill the receive arena with the boundary half spinors of `v` (for kernels other than apply() that couple
@@ -74,6 +80,9 @@ class FineOp {
   int* lex_ = nullptr;      // lexicographic index of every device site (for the layout kernel)
   unsigned char* parity_ = nullptr;   // [V] global parity of every site
   int* tile_nb_ = nullptr;
+  T* Dc_ = nullptr;            // two-row links (operators whose links are +-1/2 SU(3) only)
+  T* Dc_store_ = nullptr;
+  signed char* Dsgn_ = nullptr;
   unsigned short* tnb_ = nullptr;
   int V_ = 0;
   mutable Halo<T> halo_;

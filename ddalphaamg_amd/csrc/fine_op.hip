@@ -93,13 +93,36 @@ __device__ __forceinline__ int tile_neighbor(const int* __restrict__ nb, size_t 
   }
 }
 
-template <typename T, int MU, bool ARITH, bool DEFER>
+// the link U_mu(s): 18 reals from the full storage, or 12 reals + the reconstruction of the third row
+//   row2 = sgn * 2 conj(row0 x row1)      (links hold U/2: |row| = 1/2, so conj(row0 x row1) = row2 / (2 sgn))
+template <typename T, int MU, bool CMP>
+__device__ __forceinline__ void load_link(const FineOpDev<T>& op, size_t V, size_t s, T (&U)[18]) {
+  if constexpr (!CMP) {
+    load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, s, U);
+  } else {
+    T r[12];
+    load_site<T, 12>(op.Dc + (size_t)MU * 12 * V, V, s, r);
+    const T sg = (T)2 * (T)op.Dsgn[(size_t)MU * V + s];
+#pragma unroll
+    for (int k = 0; k < 12; k++) U[k] = r[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+      // c = a_{k1} b_{k2} - a_{k2} b_{k1}
+      const T cr = r[2 * k1] * r[6 + 2 * k2] - r[2 * k1 + 1] * r[6 + 2 * k2 + 1] - (r[2 * k2] * r[6 + 2 * k1] - r[2 * k2 + 1] * r[6 + 2 * k1 + 1]);
+      const T ci = r[2 * k1] * r[6 + 2 * k2 + 1] + r[2 * k1 + 1] * r[6 + 2 * k2] - (r[2 * k2] * r[6 + 2 * k1 + 1] + r[2 * k2 + 1] * r[6 + 2 * k1]);
+      U[12 + 2 * k] = sg * cr; U[12 + 2 * k + 1] = -sg * ci;
+    }
+  }
+}
+
+template <typename T, int MU, bool ARITH, bool DEFER, bool CMP>
 __device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOpDev<T>& op, size_t s, bool live, int tile0, const uint4& q,
                                          const T (&p)[24], T (&e)[24], T* __restrict__ sp, T* __restrict__ hb) {
   const size_t V = op.V;
   const int t = threadIdx.x;
   T U[18];
-  if (live) load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, s, U);
+  if (live) load_link<T, MU, CMP>(op, V, s, U);
   // (a) backward product for my +mu neighbour:  U_mu(s)^dagger (1+gamma_mu) phi(s)
   {
     T h[12], g[12];
@@ -138,14 +161,14 @@ __device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOp
     } else {
       T pn[24], Un[18];
       load_site<T, 24>(phi, V, j, pn);
-      load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, j, Un);
+      load_link<T, MU, CMP>(op, V, (size_t)j, Un);
       hop_accumulate<T, MU, false>(Un, pn, e);
     }
   }
   __syncthreads();
 }
 
-template <typename T, bool ARITH, bool DEFER>
+template <typename T, bool ARITH, bool DEFER, bool CMP = false>
 __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) void dirac_apply_lds_kernel(T* __restrict__ eta, const T* __restrict__ phi, FineOpDev<T> op, int ntiles,
                                                                   const int* __restrict__ tile_list) {
   __shared__ T sp[24 * 256];
@@ -177,10 +200,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) void dirac_apply_lds
     herm6_mul<T>(cl, p + 12, e + 12);
   }
   __syncthreads();
-  tile_dir<T, 0, ARITH, DEFER>(phi, op, s, live, tile0, q, p, e, sp, hb);
-  tile_dir<T, 1, ARITH, DEFER>(phi, op, s, live, tile0, q, p, e, sp, hb);
-  tile_dir<T, 2, ARITH, DEFER>(phi, op, s, live, tile0, q, p, e, sp, hb);
-  tile_dir<T, 3, ARITH, DEFER>(phi, op, s, live, tile0, q, p, e, sp, hb);
+  tile_dir<T, 0, ARITH, DEFER, CMP>(phi, op, s, live, tile0, q, p, e, sp, hb);
+  tile_dir<T, 1, ARITH, DEFER, CMP>(phi, op, s, live, tile0, q, p, e, sp, hb);
+  tile_dir<T, 2, ARITH, DEFER, CMP>(phi, op, s, live, tile0, q, p, e, sp, hb);
+  tile_dir<T, 3, ARITH, DEFER, CMP>(phi, op, s, live, tile0, q, p, e, sp, hb);
   if (live) store_site<T, 24, DDAMG_NT_STORE>(eta, V, s, e);
 }
 
@@ -331,6 +354,7 @@ void FineOp<T>::apply(T* eta, const T* phi, hipStream_t st) const {
   auto launch = [&](int ntiles, const int* tile_list) {
     if (ntiles == 0) return;
     if (g_dirac_variant == 0) hipLaunchKernelGGL(dirac_apply_kernel<T>, dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), tile_list);
+    else if (tnb_ && g_dirac_variant != 4 && Dc_) hipLaunchKernelGGL((dirac_apply_lds_kernel<T, true, false, true>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, tile_list);
     else if (tnb_ && g_dirac_variant != 4) hipLaunchKernelGGL((dirac_apply_lds_kernel<T, true, false>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, tile_list);
     else hipLaunchKernelGGL((dirac_apply_lds_kernel<T, false, false>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, tile_list);
     DDAMG_HIP_CHECK(hipGetLastError());
@@ -408,6 +432,8 @@ FineOp<T>::~FineOp() {
   if (tnb_) (void)hipFree(tnb_);
   if (lex_) (void)hipFree(lex_);
   if (parity_) (void)hipFree(parity_);
+  if (Dc_store_) (void)hipFree(Dc_store_);
+  if (Dsgn_) (void)hipFree(Dsgn_);
 }
 
 // ---- operator data: reference storage (lexicographic fp64) -> device layouts, on the device -----------------------
@@ -494,6 +520,33 @@ __global__ __launch_bounds__(128) void operator_layout_kernel(T* __restrict__ D,
   }
 }
 
+// two-row link storage from the reference's links (lexicographic fp64, U/2): rows 0 and 1 in fp32, the sign with which
+// 2 conj(row0 x row1) gives row 2, and -- in *bad -- whether any link is not of that form (then the full storage is used)
+template <typename T>
+__global__ __launch_bounds__(128) void link_compress_kernel(T* __restrict__ Dc, signed char* __restrict__ sgn, int* __restrict__ bad,
+                                                            const double* __restrict__ D_lex, const int* __restrict__ lex_of_site, int V) {
+  const size_t s = (size_t)blockIdx.x * 128 + threadIdx.x;
+  if (s >= (size_t)V) return;
+  const size_t lx = lex_of_site[s];
+  for (int mu = 0; mu < 4; mu++) {
+    const double* u = D_lex + (lx * 36 + mu * 9) * 2;
+    double dev_p = 0, dev_m = 0, nrm = 0;
+    for (int k = 0; k < 3; k++) {
+      const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+      const double cr = u[2 * k1] * u[6 + 2 * k2] - u[2 * k1 + 1] * u[6 + 2 * k2 + 1] - (u[2 * k2] * u[6 + 2 * k1] - u[2 * k2 + 1] * u[6 + 2 * k1 + 1]);
+      const double ci = u[2 * k1] * u[6 + 2 * k2 + 1] + u[2 * k1 + 1] * u[6 + 2 * k2] - (u[2 * k2] * u[6 + 2 * k1 + 1] + u[2 * k2 + 1] * u[6 + 2 * k1]);
+      const double er = 2 * cr, ei = -2 * ci;      // 2 conj(row0 x row1)
+      dev_p += (u[12 + 2 * k] - er) * (u[12 + 2 * k] - er) + (u[12 + 2 * k + 1] - ei) * (u[12 + 2 * k + 1] - ei);
+      dev_m += (u[12 + 2 * k] + er) * (u[12 + 2 * k] + er) + (u[12 + 2 * k + 1] + ei) * (u[12 + 2 * k + 1] + ei);
+      nrm += u[12 + 2 * k] * u[12 + 2 * k] + u[12 + 2 * k + 1] * u[12 + 2 * k + 1];
+    }
+    const bool plus = dev_p <= dev_m;
+    if ((plus ? dev_p : dev_m) > 1e-24 * (nrm > 0 ? nrm : 1.0) || nrm == 0) atomicOr(bad, 1);
+    sgn[(size_t)mu * V + s] = plus ? 1 : -1;
+    for (int r = 0; r < 12; r++) Dc[(size_t)mu * 12 * V + soa_index_dev<T>(12, V, s, r)] = (T)u[r];
+  }
+}
+
 template <typename T>
 void FineOp<T>::upload(const Geometry& g, const double* D_ref, const double* clover_ref, hipStream_t st) {
   const size_t V = g.V;
@@ -517,6 +570,26 @@ void FineOp<T>::upload(const Geometry& g, const double* D_ref, const double* clo
   DDAMG_HIP_CHECK(hipMemcpyAsync(dC, clover_ref, sizeof(double) * 84 * V, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(operator_layout_kernel<T>, dim3((unsigned)((V + 127) / 128)), dim3(128), 0, st, D_, clover_, clover_inv_, dD, dC, lex_, (int)V);
   DDAMG_HIP_CHECK(hipGetLastError());
+  // two-row links (a third less link traffic in dirac_apply_lds_kernel and the Schwarz block solver) when every link allows it
+  Dc_ = nullptr;
+  {
+    const char* lc = getenv("DDAMG_LINK_COMPRESSION");
+    const bool off = lc != nullptr && atoi(lc) == 0;
+    if (!off && g.block_sites == 256) {
+      if (!Dc_store_) {
+        DDAMG_HIP_CHECK(device_alloc(&Dc_store_, sizeof(T) * 48 * V));
+        DDAMG_HIP_CHECK(device_alloc(&Dsgn_, 4 * V + sizeof(int)));
+      }
+      int* d_bad = reinterpret_cast<int*>(reinterpret_cast<char*>(Dsgn_) + 4 * V);   // one flag behind the signs
+      DDAMG_HIP_CHECK(hipMemsetAsync(d_bad, 0, sizeof(int), st));
+      hipLaunchKernelGGL(link_compress_kernel<T>, dim3((unsigned)((V + 127) / 128)), dim3(128), 0, st, Dc_store_, Dsgn_, d_bad, dD, lex_, (int)V);
+      DDAMG_HIP_CHECK(hipGetLastError());
+      int bad = 1;
+      DDAMG_HIP_CHECK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, st));
+      DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+      if (!bad) Dc_ = Dc_store_;
+    }
+  }
   DDAMG_HIP_CHECK(hipMemcpyAsync(nb_, g.nb.data(), sizeof(int) * 8 * V, hipMemcpyHostToDevice, st));
   if (g.block_sites == 256 && !tnb_) {   // one tile of the LDS kernel == one Schwarz block: arithmetic neighbours
     DDAMG_HIP_CHECK(device_alloc(&tile_nb_, sizeof(int) * 8 * g.num_blocks));

@@ -143,6 +143,21 @@ __device__ __forceinline__ void pk_load_site(const float* __restrict__ base, siz
     out[N - 1] = *p;
   }
 }
+// a link from the two-row storage: rows 0 and 1 (6 complex), row 2 = sgn * 2 conj(row0 x row1)   (links hold U/2)
+__device__ __forceinline__ void pk_load_link2(const float* __restrict__ Dc, const signed char* __restrict__ sgn, size_t V, size_t s, cf (&U)[9]) {
+  cf r[6];
+  pk_load_site<6, true>(Dc, V, s, r);
+  const float sg = 2.f * (float)sgn[s];
+#pragma unroll
+  for (int k = 0; k < 6; k++) U[k] = r[k];
+#pragma unroll
+  for (int k = 0; k < 3; k++) {
+    const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+    const cf c = cf_mul(r[k1], r[3 + k2]) - cf_mul(r[k2], r[3 + k1]);
+    U[6 + k] = cf_make(sg * c.x, -sg * c.y);
+  }
+}
+
 template <int N, bool NT = false>
 __device__ __forceinline__ void pk_store_site(float* __restrict__ base, size_t V, size_t s, const cf (&in)[N]) {
   static_assert(N % 2 == 0, "whole 16-byte chunks");

@@ -199,10 +199,18 @@ __global__ __launch_bounds__(256 * NB, 2) void sap_pair_kernel(SapPairArgs a) {
 
   // ---- the block's links: resident from here on ---------------------------------------------------
   cf U0[9], U1[9], U2[9], U3[9];
-  pk_load_site<9, true>(op.D, V, s, U0);
-  pk_load_site<9, true>(op.D + (size_t)18 * V, V, s, U1);
-  pk_load_site<9, true>(op.D + (size_t)36 * V, V, s, U2);
-  pk_load_site<9, true>(op.D + (size_t)54 * V, V, s, U3);
+  if (op.Dc) {
+    // two-row storage (fine_op.h): a third less link traffic; the third row is rebuilt once per block visit
+    pk_load_link2(op.Dc, op.Dsgn, V, s, U0);
+    pk_load_link2(op.Dc + (size_t)12 * V, op.Dsgn + V, V, s, U1);
+    pk_load_link2(op.Dc + (size_t)24 * V, op.Dsgn + 2 * V, V, s, U2);
+    pk_load_link2(op.Dc + (size_t)36 * V, op.Dsgn + 3 * V, V, s, U3);
+  } else {
+    pk_load_site<9, true>(op.D, V, s, U0);
+    pk_load_site<9, true>(op.D + (size_t)18 * V, V, s, U1);
+    pk_load_site<9, true>(op.D + (size_t)36 * V, V, s, U2);
+    pk_load_site<9, true>(op.D + (size_t)54 * V, V, s, U3);
+  }
 
   int mode = a.mode;
   if ((a.skip_mask >> a.block_list[blk]) & 1u) mode = MODE_NONE;
