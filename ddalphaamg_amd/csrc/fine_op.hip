@@ -116,7 +116,13 @@ __device__ __forceinline__ void load_link(const FineOpDev<T>& op, size_t V, size
   }
 }
 
-template <typename T, int MU, bool ARITH, bool DEFER, bool CMP>
+#ifdef DDAMG_FACE_DIAG
+// diagnostic build only (tools/gpu/facediag.sh: what the couplings that leave a tile cost, per direction):
+// bit mu = forward, bit 4+mu = backward coupling across the tile face is computed
+__device__ int g_face_mask = 0xff;
+#endif
+
+template <typename T, int MU, bool ARITH, bool DEFER, bool CMP, bool HB2>
 __device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOpDev<T>& op, size_t s, bool live, int tile0, const uint4& q,
                                          const T (&p)[24], T (&e)[24], T* __restrict__ sp, T* __restrict__ hb) {
   const size_t V = op.V;
@@ -140,9 +146,15 @@ __device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOp
 #pragma unroll
         for (int c = 0; c < 24; c++) pn[c] = sp[c * 256 + (j - tile0)];
       } else {
+#ifdef DDAMG_FACE_DIAG
+        if (!(g_face_mask >> MU & 1)) goto skip_fwd;
+#endif
         load_site<T, 24>(phi, V, j, pn);
       }
       hop_accumulate<T, MU, true>(U, pn, e);
+#ifdef DDAMG_FACE_DIAG
+    skip_fwd:;
+#endif
     } else {
       if constexpr (!DEFER) halo_forward<T, MU>(op, -1 - j, U, e);   // DEFER: added by halo_fixup_kernel after the exchange
     }
@@ -158,21 +170,29 @@ __device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOp
 #pragma unroll
       for (int c = 0; c < 12; c++) g[c] = hb[c * 256 + (j - tile0)];
       spin_reconstruct_sub<T, MU, +1>(g, e);
-    } else {
+    } else
+#ifdef DDAMG_FACE_DIAG
+    if (g_face_mask >> (4 + MU) & 1)
+#endif
+    {
       T pn[24], Un[18];
       load_site<T, 24>(phi, V, j, pn);
       load_link<T, MU, CMP>(op, V, (size_t)j, Un);
       hop_accumulate<T, MU, false>(Un, pn, e);
     }
   }
-  __syncthreads();
+  if constexpr (!HB2) __syncthreads();   // HB2: the caller alternates between two hb buffers, one barrier per direction
 }
 
 template <typename T, bool ARITH, bool DEFER, bool CMP = false>
 __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) void dirac_apply_lds_kernel(T* __restrict__ eta, const T* __restrict__ phi, FineOpDev<T> op, int ntiles,
                                                                   const int* __restrict__ tile_list) {
+  // fp32: two buffers for the backward products, used in turn, so that one barrier per direction is enough (48 KB of LDS,
+  // three workgroups per CU as before); fp64 keeps one buffer and two barriers (its tile already takes 72 KB)
+  constexpr bool HB2 = sizeof(T) == 4;
   __shared__ T sp[24 * 256];
-  __shared__ T hb[12 * 256];
+  __shared__ T hb[(HB2 ? 2 : 1) * 12 * 256];
+  T* const hb1 = hb + (HB2 ? 12 * 256 : 0);
   // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs, so give XCD k the
   // k-th contiguous eighth of the tiles (neighbouring tiles then share one L2)
   int tile = blockIdx.x;
@@ -200,10 +220,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) void dirac_apply_lds
     herm6_mul<T>(cl, p + 12, e + 12);
   }
   __syncthreads();
-  tile_dir<T, 0, ARITH, DEFER, CMP>(phi, op, s, live, tile0, q, p, e, sp, hb);
-  tile_dir<T, 1, ARITH, DEFER, CMP>(phi, op, s, live, tile0, q, p, e, sp, hb);
-  tile_dir<T, 2, ARITH, DEFER, CMP>(phi, op, s, live, tile0, q, p, e, sp, hb);
-  tile_dir<T, 3, ARITH, DEFER, CMP>(phi, op, s, live, tile0, q, p, e, sp, hb);
+  tile_dir<T, 0, ARITH, DEFER, CMP, HB2>(phi, op, s, live, tile0, q, p, e, sp, hb);
+  tile_dir<T, 1, ARITH, DEFER, CMP, HB2>(phi, op, s, live, tile0, q, p, e, sp, hb1);
+  tile_dir<T, 2, ARITH, DEFER, CMP, HB2>(phi, op, s, live, tile0, q, p, e, sp, hb);
+  tile_dir<T, 3, ARITH, DEFER, CMP, HB2>(phi, op, s, live, tile0, q, p, e, sp, hb1);
   if (live) store_site<T, 24, DDAMG_NT_STORE>(eta, V, s, e);
 }
 
@@ -351,6 +371,10 @@ void FineOp<T>::apply(T* eta, const T* phi, hipStream_t st) const {
     const char* e = getenv("DDAMG_DIRAC_VARIANT");
     g_dirac_variant = e ? atoi(e) : 1;
   }
+#ifdef DDAMG_FACE_DIAG
+  { static int once = 0; if (!once) { once = 1; const char* m = getenv("DDAMG_FACE_MASK"); int v = m ? (int)strtol(m, nullptr, 0) : 0xff;
+      DDAMG_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_face_mask), &v, sizeof(int))); } }
+#endif
   auto launch = [&](int ntiles, const int* tile_list) {
     if (ntiles == 0) return;
     if (g_dirac_variant == 0) hipLaunchKernelGGL(dirac_apply_kernel<T>, dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), tile_list);

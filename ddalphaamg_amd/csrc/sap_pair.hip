@@ -156,7 +156,7 @@ __device__ __forceinline__ void face_emit_dir(const cf (&v)[12], const cf (&U)[9
     ext_apply<3>(acc, U3, ext, fh[3], fh[7]);                            \
   } while (0)
 
-template <bool DIST, int NB>
+template <bool DIST, int NB, bool CMP>
 __global__ __launch_bounds__(256 * NB, 2) void sap_pair_kernel(SapPairArgs a) {
   __shared__ cf slots[NB][8 * 6 * HS];
   __shared__ float red[2][NB][8];        // [generation][block of the workgroup][2 even wavefronts x 3 sums]
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256 * NB, 2) void sap_pair_kernel(SapPairArgs a) {
 
   // ---- the block's links: resident from here on ---------------------------------------------------
   cf U0[9], U1[9], U2[9], U3[9];
-  if (op.Dc) {
+  if constexpr (CMP) {
     // two-row storage (fine_op.h): a third less link traffic; the third row is rebuilt once per block visit
     pk_load_link2(op.Dc, op.Dsgn, V, s, U0);
     pk_load_link2(op.Dc + (size_t)12 * V, op.Dsgn + V, V, s, U1);
@@ -450,11 +450,21 @@ void sap_pair_launch(const SapPairArgs& a, bool dist, hipStream_t st) {
   static const int nb = [] { const char* e = getenv("DDAMG_SAP_BLOCKS_PER_WG"); return e ? atoi(e) : 1; }();
   if (nb == 2) {
     const int grid = (a.nblocks + 1) / 2;
-    if (dist) hipLaunchKernelGGL((sap_pair_kernel<true, 2>), dim3(grid), dim3(512), 0, st, a);
-    else hipLaunchKernelGGL((sap_pair_kernel<false, 2>), dim3(grid), dim3(512), 0, st, a);
+    if (a.op.Dc) {
+      if (dist) hipLaunchKernelGGL((sap_pair_kernel<true, 2, true>), dim3(grid), dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((sap_pair_kernel<false, 2, true>), dim3(grid), dim3(512), 0, st, a);
+    } else {
+      if (dist) hipLaunchKernelGGL((sap_pair_kernel<true, 2, false>), dim3(grid), dim3(512), 0, st, a);
+      else hipLaunchKernelGGL((sap_pair_kernel<false, 2, false>), dim3(grid), dim3(512), 0, st, a);
+    }
   } else {
-    if (dist) hipLaunchKernelGGL((sap_pair_kernel<true, 1>), dim3(a.nblocks), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((sap_pair_kernel<false, 1>), dim3(a.nblocks), dim3(256), 0, st, a);
+    if (a.op.Dc) {
+      if (dist) hipLaunchKernelGGL((sap_pair_kernel<true, 1, true>), dim3(a.nblocks), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((sap_pair_kernel<false, 1, true>), dim3(a.nblocks), dim3(256), 0, st, a);
+    } else {
+      if (dist) hipLaunchKernelGGL((sap_pair_kernel<true, 1, false>), dim3(a.nblocks), dim3(256), 0, st, a);
+      else hipLaunchKernelGGL((sap_pair_kernel<false, 1, false>), dim3(a.nblocks), dim3(256), 0, st, a);
+    }
   }
   DDAMG_HIP_CHECK(hipGetLastError());
 }
