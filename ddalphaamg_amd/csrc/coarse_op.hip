@@ -64,8 +64,10 @@ __device__ __forceinline__ void wave_mv(const T* __restrict__ Mbase, const T* __
   }
 }
 
-template <typename T, int NT>
-__global__ void coarse_site_kernel(T* __restrict__ out, const T* __restrict__ in, CoarseOpDev<T> op, int s0, int mode,
+// MODE is a template parameter so that the hopping terms and the (8 times lighter) self-coupling products show up under
+// their own names in kernel statistics
+template <typename T, int NT, int mode>
+__global__ void coarse_site_kernel(T* __restrict__ out, const T* __restrict__ in, CoarseOpDev<T> op, int s0,
                                    T sign_self, T sign_hop, int accumulate,
                                    const int* __restrict__ site_list, const unsigned char* __restrict__ dir_mask, int mask_invert, int swizzle) {
   __shared__ T res[9 * 2 * 8 * NT];
@@ -429,12 +431,17 @@ static void launch_site(const CoarseOpDev<T>& op, T* out, const T* in, int s0, i
   const int waves = mode == MODE_FULL ? 9 : (mode == MODE_HOP ? 8 : 1);
   dim3 grid(s1 - s0), block(64 * waves);
   const int swz = (s1 - s0) >= 64 ? 1 : 0;   // measured at 48^4, three levels: 3 % on the whole solve
-#define DDAMG_CASE(NTV) case NTV: hipLaunchKernelGGL((coarse_site_kernel<T, NTV>), grid, block, 0, st, out, in, op, s0, mode, (T)ss, (T)sh, acc ? 1 : 0, site_list, dir_mask, mask_invert ? 1 : 0, swz); break;
+#define DDAMG_LAUNCH(NTV, MODEV) hipLaunchKernelGGL((coarse_site_kernel<T, NTV, MODEV>), grid, block, 0, st, out, in, op, s0, (T)ss, (T)sh, acc ? 1 : 0, site_list, dir_mask, mask_invert ? 1 : 0, swz)
+#define DDAMG_CASE(NTV) case NTV: \
+    if (mode == MODE_FULL) DDAMG_LAUNCH(NTV, MODE_FULL); else if (mode == MODE_HOP) DDAMG_LAUNCH(NTV, MODE_HOP); \
+    else if (mode == MODE_SELF) DDAMG_LAUNCH(NTV, MODE_SELF); else DDAMG_LAUNCH(NTV, MODE_SELFINV); \
+    break;
   switch (op.nt) {
     DDAMG_CASE(1) DDAMG_CASE(2) DDAMG_CASE(3) DDAMG_CASE(4) DDAMG_CASE(5) DDAMG_CASE(6) DDAMG_CASE(7) DDAMG_CASE(8)
     default: DDAMG_REQUIRE(false, "coarse operator: more than 64 dof per site are not supported");
   }
 #undef DDAMG_CASE
+#undef DDAMG_LAUNCH
   DDAMG_HIP_CHECK(hipGetLastError());
 }
 

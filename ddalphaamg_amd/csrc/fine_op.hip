@@ -394,10 +394,14 @@ void FineOp<T>::apply(T* eta, const T* phi, hipStream_t st) const {
   if (g_dirac_variant != 0 && defer) {
     // alternative (DDAMG_HALO_DEFER): the whole lattice in one launch with the off-process couplings left out -- it
     // overlaps with the complete exchange -- then a short pass over the boundary sites adds them.  Measured with the
-    // self-exchange mode at 32^4, three directions: 249 us against 237 us for the split below (the transport's copy
-    // kernel competes with the full-lattice launch for CUs and ends after it), so the split is the default.
+    // self-exchange mode at 32^4, three directions: 249 us against 237 us for the split below in round 1, 204 against 188 us
+    // with the two-row links (full launch 154 us on the 232 CUs left to the compute stream + 28 us boundary pass), so the
+    // split is the default.  Also measured: the pack kernel on a third stream so that the interior tiles start at once --
+    // 344 us, every further cross-stream dependency costs more than the 19 us it hides; the interior tiles enqueued before
+    // the transport's send/receive group -- no change (the 6 us in front of them are the event packet, not the host).
     const int ntiles = (V_ + 255) / 256;
-    if (tnb_ && g_dirac_variant != 4) hipLaunchKernelGGL((dirac_apply_lds_kernel<T, true, true>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, (const int*)nullptr);
+    if (tnb_ && g_dirac_variant != 4 && Dc_) hipLaunchKernelGGL((dirac_apply_lds_kernel<T, true, true, true>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, (const int*)nullptr);
+    else if (tnb_ && g_dirac_variant != 4) hipLaunchKernelGGL((dirac_apply_lds_kernel<T, true, true>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, (const int*)nullptr);
     else hipLaunchKernelGGL((dirac_apply_lds_kernel<T, false, true>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, (const int*)nullptr);
     DDAMG_HIP_CHECK(hipGetLastError());
     halo_.exchange_finish(comm_, st);
