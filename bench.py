@@ -77,6 +77,8 @@ def spawn_ranks(n):
             if c is None:
                 continue
             live.remove(p)
+            if c != 0:
+                print(f"bench.py: rank {procs.index(p)} ended with exit code {c}", file=sys.stderr, flush=True)
             if c != 0 and rc == 0:
                 rc = c if c > 0 else 1
         if (rc != 0 or time.time() > deadline) and live:
@@ -547,6 +549,7 @@ def main():
 
     def emit_and_die(msg):
         with die_lock:      # first caller wins; the process ends inside
+            print(f"bench.py: rank {rank}: {msg}", file=sys.stderr, flush=True)
             if rank == 0:
                 out.setdefault("strong_scaling", {})["error"] = msg
                 print(json.dumps(out), flush=True)
@@ -562,7 +565,10 @@ def main():
         signal.set_wakeup_fd(ws.fileno())
 
         def on_signal():
-            rs.recv(1)
+            while True:     # the descriptor sees every signal the interpreter handles (SIGCHLD of a helper process, ...)
+                b = rs.recv(1)
+                if b and b[0] == signal.SIGTERM:
+                    break
             emit_and_die("terminated by the launcher: another rank failed or the job overran")
         threading.Thread(target=on_signal, daemon=True).start()
 
