@@ -135,40 +135,58 @@ __global__ __launch_bounds__(256, 2) void restrict_mfma_kernel(float* __restrict
     for (int t = 0; t < 2; t++)
 #pragma unroll
       for (int r = 0; r < 16; r++) { accR[t][r] = 0.f; accI[t][r] = 0.f; }
-    for (int kk = 3 * h; kk < 3 * h + 3; kk++)
-      for (int sb = 0; sb < agg_sites; sb += KS) {
-        __syncthreads();
-        const size_t row = ((size_t)kk * V + s0 + sb) * 4;
-        const size_t wrow = ((size_t)kk * Vw + (s0 - w0site) + sb) * 4;
-        for (int e = tid; e < nvec * KS; e += 256) {
-          const int i = e / KS, sl = e % KS;
-          const float4 v = *reinterpret_cast<const float4*>(P + (size_t)i * pstride + row + sl * 4);
-          As[4 * sl][i] = v.x; As[4 * sl + 1][i] = v.y; As[4 * sl + 2][i] = v.z; As[4 * sl + 3][i] = v.w;
-        }
-#pragma unroll 4
-        for (int r = 0; r < 16; r++) {
-          const int e = tid + 256 * r, col = e / KS, sl = e % KS;
-          float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (col < nw) v = *reinterpret_cast<const float4*>(W + (size_t)col * wstride + wrow + sl * 4);
-          Bs[4 * sl][col] = v.x; Bs[4 * sl + 1][col] = v.y; Bs[4 * sl + 2][col] = v.z; Bs[4 * sl + 3][col] = v.w;
-        }
-        __syncthreads();
-#pragma unroll 4
-        for (int kp = 0; kp < 2 * KS; kp++) {
-          const int k = 2 * kp + (lane >> 5);
-          const float aR = As[k][lane & 31];
-          const float aI = (k & 1) ? As[k ^ 1][lane & 31] : -As[k ^ 1][lane & 31];
+    // K blocks of this chirality: (chunk row kk, 16 sites from sb).  The operands of block b+1 are requested from global
+    // memory before the products of block b are issued, so that the loads travel behind the matrix instructions
+    const int nsb = agg_sites / KS, nblk = 3 * nsb;
+    float4 pa[2], pb[16];
+    auto fetch = [&](int b) {
+      const int kk = 3 * h + b / nsb, sb = (b % nsb) * KS;
+      const size_t row = ((size_t)kk * V + s0 + sb) * 4;
+      const size_t wrow = ((size_t)kk * Vw + (s0 - w0site) + sb) * 4;
 #pragma unroll
-          for (int t = 0; t < 2; t++) {
-            const int tile = wv + 4 * t;
-            if (tile < ntile) {
-              const float b = Bs[k][tile * 32 + (lane & 31)];
-              accR[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aR, b, accR[t], 0, 0, 0);
-              accI[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aI, b, accI[t], 0, 0, 0);
-            }
+      for (int r = 0; r < 2; r++) {
+        const int e = tid + 256 * r, i = e / KS, sl = e % KS;
+        pa[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < nvec) pa[r] = *reinterpret_cast<const float4*>(P + (size_t)i * pstride + row + sl * 4);
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int e = tid + 256 * r, col = e / KS, sl = e % KS;
+        pb[r] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (col < nw) pb[r] = *reinterpret_cast<const float4*>(W + (size_t)col * wstride + wrow + sl * 4);
+      }
+    };
+    fetch(0);
+    for (int b = 0; b < nblk; b++) {
+      __syncthreads();
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        const int e = tid + 256 * r, i = e / KS, sl = e % KS;
+        if (i < 32) { As[4 * sl][i] = pa[r].x; As[4 * sl + 1][i] = pa[r].y; As[4 * sl + 2][i] = pa[r].z; As[4 * sl + 3][i] = pa[r].w; }
+      }
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int e = tid + 256 * r, col = e / KS, sl = e % KS;
+        Bs[4 * sl][col] = pb[r].x; Bs[4 * sl + 1][col] = pb[r].y; Bs[4 * sl + 2][col] = pb[r].z; Bs[4 * sl + 3][col] = pb[r].w;
+      }
+      __syncthreads();
+      if (b + 1 < nblk) fetch(b + 1);
+#pragma unroll 1
+      for (int kp = 0; kp < 2 * KS; kp++) {
+        const int k = 2 * kp + (lane >> 5);
+        const float aR = As[k][lane & 31];
+        const float aI = (k & 1) ? As[k ^ 1][lane & 31] : -As[k ^ 1][lane & 31];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          const int tile = wv + 4 * t;
+          if (tile < ntile) {
+            const float bv = Bs[k][tile * 32 + (lane & 31)];
+            accR[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aR, bv, accR[t], 0, 0, 0);
+            accI[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aI, bv, accI[t], 0, 0, 0);
           }
         }
       }
+    }
     const size_t cbase = ((size_t)agg_csite[a] * 2 * nvec + (size_t)h * nvec) * 2;
 #pragma unroll
     for (int t = 0; t < 2; t++) {
