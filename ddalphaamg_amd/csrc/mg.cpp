@@ -553,10 +553,13 @@ void Multigrid<T>::build_coarse_operator(int l) {
         if (force_slab) gal_slab_aggs_ = std::max(1, std::min(atoi(force_slab), lv.fip.num_aggs));
         gal_batch_ = 2 * N;
         DDAMG_HIP_CHECK(device_alloc(&gal_W_, per_agg * (size_t)gal_slab_aggs_));
+        gal_W_elems_ = per_agg / sizeof(T) * (size_t)gal_slab_aggs_;
       } else {
         DDAMG_HIP_CHECK(device_alloc(&gal_W_, sizeof(T) * 5 * gal_batch_ * ws));
+        gal_W_elems_ = (size_t)5 * gal_batch_ * ws;
       }
       DDAMG_HIP_CHECK(device_alloc(&gal_C_, sizeof(T) * 5 * gal_batch_ * cs));
+      gal_C_elems_ = (size_t)5 * gal_batch_ * cs;
     }
     const int batch = gal_batch_;
     T *Wb = gal_W_, *Cb = gal_C_;
@@ -622,8 +625,8 @@ void Multigrid<T>::build_coarse_operator(int l) {
 template <typename T>
 void Multigrid<T>::release_setup_workspace() {
   DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
-  if (gal_W_) { DDAMG_HIP_CHECK(hipFree(gal_W_)); gal_W_ = nullptr; }
-  if (gal_C_) { DDAMG_HIP_CHECK(hipFree(gal_C_)); gal_C_ = nullptr; }
+  if (gal_W_) { DDAMG_HIP_CHECK(hipFree(gal_W_)); gal_W_ = nullptr; gal_W_elems_ = 0; }
+  if (gal_C_) { DDAMG_HIP_CHECK(hipFree(gal_C_)); gal_C_ = nullptr; gal_C_elems_ = 0; }
   if (gal_cwork_) { DDAMG_HIP_CHECK(hipFree(gal_cwork_)); gal_cwork_ = nullptr; }
 }
 
@@ -658,6 +661,53 @@ void Multigrid<T>::initial_setup_from(int l0) {
   }
 }
 
+// The Nvec V-cycles of one bootstrap iteration on the fine level do not depend on each other (the interpolation operator
+// is a copy of the previous iteration's test vectors), so the two passes over the interpolation operator that every one of
+// them makes -- restriction of its right-hand side, interpolation of its coarse correction -- are done for all of them at
+// once: P is read twice per iteration instead of 2 Nvec times (32^4, Nvec 24: 2 x 2.4 GB instead of 115 GB), the
+// restriction on the matrix cores (restrict_mfma_kernel, the Galerkin construction's kernel).  The coarse solves and the
+// smoother calls stay one vector at a time.  Borrows the Galerkin workspace between two builds; single process, fp32.
+template <typename T>
+bool Multigrid<T>::bootstrap_vcycles_batched() {
+  const bool off = getenv("DDAMG_BOOTSTRAP_UNBATCHED") != nullptr;   // read at every call: tests switch it within one process
+  MGLevel<T>& lv = *lv_[0];
+  MGLevel<T>& nx = *lv_[1];
+  const int N = lv.nvec;
+  const size_t ws = (size_t)24 * lv.g->V, cs = (size_t)nx.g->V * nx.n * 2;
+  if (off || sizeof(T) != 4 || comm_ != nullptr || lv.fop->distributed() || !gal_W_ || !gal_C_) return false;
+  if (!Interpolation<T>::restrict_batch_available(lv.fip.agg_sites, N) || !Interpolation<T>::interpolate_batch_available(lv.fip.agg_sites, N, N)) return false;
+  if (gal_W_elems_ < (size_t)N * ws || gal_C_elems_ < (size_t)2 * N * cs) return false;
+  T* F = gal_W_;                 // N fine vectors: the iterates of the V-cycles
+  T* Cb = gal_C_;                // N coarse right-hand sides
+  T* Cx = gal_C_ + (size_t)N * cs;   // N coarse solutions
+  const View all = whole(lv.nel), call = whole(nx.nel);
+  lv.fip.restrict_batch(Cb, cs, tv_base(0), tv_stride(0), N, st_);
+  for (int i = 0; i < N; i++) {
+    vec_copy<T>(nx.gm.b, Cb + (size_t)i * cs, call, st_);
+    if (nx.coarsest) {
+      coarse_solve();
+    } else if (par_.kcycle) {
+      nx.gm.initial_guess_zero = true;
+      nx.gm.solve();
+    } else {
+      vcycle(1, nx.gm.x, nullptr, nx.gm.b, NO_RES);
+    }
+    // test_vector_PRECISION_update of the deeper intermediate levels, from their K-cycle iterate of THIS V-cycle
+    for (int d = num_levels() - 2; d > 0; d--) {
+      MGLevel<T>& dl = *lv_[d];
+      if (i < dl.nvec) vec_scale<T>(test_vector(d, i), dl.gm.x, 1.0 / norm_of(d, dl.gm.x), 0.0, whole(dl.nel), st_);
+    }
+    vec_copy<T>(Cx + (size_t)i * cs, nx.gm.x, call, st_);
+  }
+  lv.fip.interpolate_batch(F, ws, Cx, cs, N, st_);
+  for (int i = 0; i < N; i++) {
+    T* out = F + (size_t)i * ws;
+    smoother(0, out, nullptr, test_vector(0, i), par_.post_smooth_iter[0], RES);
+    vec_scale<T>(test_vector(0, i), out, 1.0 / norm_of(0, out), 0.0, all, st_);
+  }
+  return true;
+}
+
 template <typename T>
 void Multigrid<T>::bootstrap(int l, int iters) {
   MGLevel<T>& lv = *lv_[l];
@@ -675,6 +725,13 @@ void Multigrid<T>::bootstrap(int l, int iters) {
       vec_scale<T>(vi, vi, 1.0 / norm_of(l, vi), 0.0, all, st_);
     }
     tb = tick("test-vector Gram-Schmidt", tb);
+    if (l == 0 && bootstrap_vcycles_batched()) {
+      tick("bootstrap V-cycles", tb);
+      re_setup(l);
+      if (!lv_[1]->coarsest)
+        bootstrap(1, std::max(1, (int)std::lround((double)((j + 1) * par_.setup_iter[1]) / (double)iters)));
+      continue;
+    }
     for (int i = 0; i < lv.nvec; i++) {
       T* out = l == 0 ? lv.buf[2] : lv.gm.x;   // the reference writes into l->p_PRECISION.x
       vcycle(l, out, nullptr, test_vector(l, i), NO_RES);

@@ -111,6 +111,7 @@ class Multigrid {
   T *gal_W_ = nullptr, *gal_C_ = nullptr;   // batched Galerkin workspace
   T* gal_cwork_ = nullptr;                  // the same for coarse levels (sized for level 1, the largest)
   int gal_batch_ = 0;
+  size_t gal_W_elems_ = 0, gal_C_elems_ = 0;   // sizes of the two (the bootstrap borrows them between the builds)
   int gal_slab_aggs_ = 0;                   // > 0: all columns, the lattice in slabs of this many aggregates
  public:
   // wall-clock seconds per setup phase (stream-synchronised), filled when DDAMG_SETUP_TIMING is set
@@ -138,6 +139,7 @@ class Multigrid {
   void build_coarse_operator(int l);    // D_{l+1} = P_l^H D_l P_l
   void orthonormalize(int l);
   void bootstrap(int l, int iters);     // inv_iter_inv_fcycle_PRECISION
+  bool bootstrap_vcycles_batched();     // the fine level's Nvec V-cycles with ONE restriction and ONE interpolation for all of them
   T* test_vector(int l, int j) { return l == 0 ? lv_[0]->fip.test_vector(j) : lv_[l]->cip.test_vector(j); }
   T* interp_vector(int l, int j) { return l == 0 ? lv_[0]->fip.interp_vector(j) : lv_[l]->cip.interp_vector(j); }
   T* tv_base(int l) { return l == 0 ? lv_[0]->fip.tv : lv_[l]->cip.tv; }

@@ -43,6 +43,10 @@ struct Interpolation {
   static bool restrict_batch_available(int agg_sites_, int nvec_) { return sizeof(T) == 4 && agg_sites_ % 16 == 0 && nvec_ <= 32; }
   // phi (+)= P phi_c
   void interpolate(T* phi, const T* phi_c, bool add, hipStream_t st) const;
+  // many coarse vectors at once (fp32, nrhs <= 32): out[w] = P phi_c[w].  P is read once for all of them -- the setup's
+  // bootstrap interpolates the coarse corrections of all Nvec test vectors with it (interpolate3 of the reference, batched)
+  void interpolate_batch(T* out, size_t out_stride, const T* phi_c, size_t c_stride, int nrhs, hipStream_t st) const;
+  static bool interpolate_batch_available(int agg_sites_, int nvec_, int nrhs) { return sizeof(T) == 4 && agg_sites_ % 64 == 0 && nvec_ <= 32 && nrhs >= 1 && nrhs <= 32; }
 };
 
 }  // namespace ddamg

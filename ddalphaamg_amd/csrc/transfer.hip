@@ -270,6 +270,62 @@ void Interpolation<T>::interpolate(T* phi, const T* phi_c, bool add, hipStream_t
   DDAMG_HIP_CHECK(hipGetLastError());
 }
 
+// ---- batched interpolation: out_w(x,d) = sum_j P_j(x,d) c_w[a][h(d)*N + j] for NR coarse vectors at once ------------
+// One workgroup per aggregate; a work item is (site, 16-byte chunk = two complex dof of one chirality) and keeps the two
+// dof of ALL right-hand sides in registers, so every element of P is read exactly once; the coarse coefficients of the
+// aggregate sit in LDS and are read as broadcasts.
+template <int NR>
+__global__ __launch_bounds__(256) void interpolate_batch_kernel(float* __restrict__ out, size_t out_stride, const float* __restrict__ cvec, size_t c_stride, int nrhs,
+                                                                const float* __restrict__ P, size_t pstride, int nvec, int V, int agg_sites,
+                                                                const int* __restrict__ agg_csite) {
+  extern __shared__ float2 cf_lds[];   // [2*nvec][NR]
+  const int a = blockIdx.x;
+  const size_t s0 = (size_t)a * agg_sites;
+  for (int e = threadIdx.x; e < 2 * nvec * NR; e += 256) {
+    const int w = e % NR, k = e / NR;
+    float2 c = make_float2(0.f, 0.f);
+    if (w < nrhs) c = *reinterpret_cast<const float2*>(cvec + (size_t)w * c_stride + ((size_t)agg_csite[a] * 2 * nvec + k) * 2);
+    cf_lds[k * NR + w] = c;
+  }
+  __syncthreads();
+  for (int item = threadIdx.x; item < 6 * agg_sites; item += 256) {
+    const int chunk = item / agg_sites, i = item - chunk * agg_sites, h = chunk / 3;
+    const size_t off = ((size_t)chunk * V + s0 + i) * 4;
+    float4 acc[NR];
+#pragma unroll
+    for (int w = 0; w < NR; w++) acc[w] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int j = 0; j < nvec; j++) {
+      typedef float f4v __attribute__((ext_vector_type(4)));
+      const f4v pv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(P + (size_t)j * pstride + off));
+      const float4 p = make_float4(pv[0], pv[1], pv[2], pv[3]);
+      const float2* cj = cf_lds + (size_t)(h * nvec + j) * NR;
+#pragma unroll
+      for (int w = 0; w < NR; w++) {
+        const float2 c = cj[w];
+        acc[w].x += c.x * p.x - c.y * p.y; acc[w].y += c.x * p.y + c.y * p.x;
+        acc[w].z += c.x * p.z - c.y * p.w; acc[w].w += c.x * p.w + c.y * p.z;
+      }
+    }
+#pragma unroll
+    for (int w = 0; w < NR; w++)
+      if (w < nrhs) *reinterpret_cast<float4*>(out + (size_t)w * out_stride + off) = acc[w];
+  }
+}
+
+template <typename T>
+void Interpolation<T>::interpolate_batch(T* out, size_t out_stride, const T* phi_c, size_t c_stride, int nrhs, hipStream_t st) const {
+  if constexpr (sizeof(T) == 4) {
+    DDAMG_REQUIRE(interpolate_batch_available(agg_sites, nvec, nrhs), "batched interpolation: unsupported shape");
+    if (nrhs <= 24) hipLaunchKernelGGL(interpolate_batch_kernel<24>, dim3(num_aggs), dim3(256), sizeof(float2) * 2 * nvec * 24, st, out, out_stride, phi_c, c_stride, nrhs,
+                                       P, pstride, nvec, V, agg_sites, agg_csite);
+    else hipLaunchKernelGGL(interpolate_batch_kernel<32>, dim3(num_aggs), dim3(256), sizeof(float2) * 2 * nvec * 32, st, out, out_stride, phi_c, c_stride, nrhs,
+                            P, pstride, nvec, V, agg_sites, agg_csite);
+    DDAMG_HIP_CHECK(hipGetLastError());
+  } else {
+    DDAMG_REQUIRE(false, "batched interpolation is an fp32 path");
+  }
+}
+
 // ---- modified Gram-Schmidt per aggregate and chirality --------------------------------------------
 // all threads receive the sum of NV values over the workgroup
 template <int NV>

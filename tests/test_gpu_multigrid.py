@@ -409,6 +409,26 @@ def test_slab_wise_galerkin_construction_is_the_same_operator(gold_b4, gold8, mo
     assert res[0][3:] == res[1][3:] and np.array_equal(res[0][2], res[1][2])
 
 
+def test_bootstrap_with_one_restriction_and_one_interpolation_for_all_test_vectors(gold_b4, gold8, monkeypatch):
+    """the setup's bootstrap V-cycles of the fine level share their two passes over the interpolation operator (restriction
+    on the matrix cores, batched interpolation).  Against the vector-by-vector form (DDAMG_BOOTSTRAP_UNBATCHED):
+    the same test vectors up to the rounding of a different summation order, the same solve"""
+    res = []
+    for unbatched in (None, "1"):
+        if unbatched:
+            monkeypatch.setenv("DDAMG_BOOTSTRAP_UNBATCHED", unbatched)
+        ctx = make_ctx_b4(gold_b4, gold8)
+        ctx.setup(3)
+        tv = ctx.get_test_vectors()
+        b = np.zeros((4096, 12, 2)); b[..., 0] = 1.0
+        x, it, cit, rr = ctx.solve(b, 1e-10)
+        res.append((tv, x, it, rr))
+        ctx.close()
+    assert relerr(res[0][0], res[1][0]) < 2e-4 and not np.array_equal(res[0][0], res[1][0])   # two code paths did run
+    assert abs(res[0][2] - res[1][2]) <= 1 and res[0][3] < 1e-10 and res[1][3] < 1e-10
+    assert relerr(res[0][1], res[1][1]) < 1e-8
+
+
 @pytest.mark.parametrize("fixture", ["ref_16x16_3lvl.npz", "ref_16x16_3lvl_hard.npz"], ids=["random-links", "smooth-links"])
 def test_three_level_production_block_shapes_16x16(fixture):
     """16^4 with the block shapes of the production configurations -- 4^4 Schwarz blocks and aggregates on the fine level
