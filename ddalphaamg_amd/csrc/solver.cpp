@@ -1,6 +1,7 @@
 // solver.cpp -- setup / solve entry points of the C-ABI (include/ddamg_hip.h) on top of mg.h and krylov.h.
 // Reference: method_setup / method_update src/init.c:134-374, wilson_driver src/top_level.c:64-104,
 // fgmres_double + preconditioner (mixed precision 1) src/linsolve_generic.c:219-413, src/preconditioner.c:25-69.
+#include <chrono>
 #include "context.h"
 #include <cstring>
 #include <cstdio>
@@ -243,14 +244,23 @@ int ddamg_hip_setup(ddamg_hip_ctx* c, int setup_iterations, int* coarse_iteratio
     c->setup_done = true;
     return 0;
   }
+  const auto wall = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double t_h0 = wall();
   ensure_mg(c);
+  DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
+  const double t_hier = wall() - t_h0;
   const int iters = setup_iterations < 0 ? c->par.setup_iter[0] : setup_iterations;
   if (c->mg32) { c->mg32->coarse_iter_count = 0; c->mg32->initial_setup(); c->mg32->iterative_setup(iters); if (coarse_iterations) *coarse_iterations = c->mg32->coarse_iter_count; }
   else { c->mg64->coarse_iter_count = 0; c->mg64->initial_setup(); c->mg64->iterative_setup(iters); if (coarse_iterations) *coarse_iterations = c->mg64->coarse_iter_count; }
   c->setup_done = true;
+  const double t_r0 = wall();
   if (c->mg32) c->mg32->release_setup_workspace(); else c->mg64->release_setup_workspace();
-  auto report = [](const std::vector<std::pair<std::string, double>>& t) {
+  const double t_rel = wall() - t_r0;
+  auto report = [&](const std::vector<std::pair<std::string, double>>& t) {
+    if (t.empty()) return;      // DDAMG_SETUP_TIMING not set
+    fprintf(stderr, "[ddamg setup] %-28s %8.3f s\n", "hierarchy: tables, buffers", t_hier);
     for (auto& e : t) fprintf(stderr, "[ddamg setup] %-28s %8.3f s\n", e.first.c_str(), e.second);
+    fprintf(stderr, "[ddamg setup] %-28s %8.3f s\n", "workspace released", t_rel);
   };
   if (c->mg32) report(c->mg32->setup_times); else report(c->mg64->setup_times);
   DDAMG_API_END
