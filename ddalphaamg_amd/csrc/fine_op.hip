@@ -142,19 +142,18 @@ __device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOp
     const int j = tile_neighbor<ARITH>(op.nb, V, s, MU, tile0, q, op.tile_nb, (int)(V >> 8));
     if (j >= 0) {
       T pn[24];
+      bool take = true;
       if (j - tile0 >= 0 && j - tile0 < 256) {
 #pragma unroll
         for (int c = 0; c < 24; c++) pn[c] = sp[c * 256 + (j - tile0)];
       } else {
 #ifdef DDAMG_FACE_DIAG
-        if (!(g_face_mask >> MU & 1)) goto skip_fwd;
+        take = (g_face_mask >> MU & 1) != 0;
+        if (take)
 #endif
         load_site<T, 24>(phi, V, j, pn);
       }
-      hop_accumulate<T, MU, true>(U, pn, e);
-#ifdef DDAMG_FACE_DIAG
-    skip_fwd:;
-#endif
+      if (take) hop_accumulate<T, MU, true>(U, pn, e);
     } else {
       if constexpr (!DEFER) halo_forward<T, MU>(op, -1 - j, U, e);   // DEFER: added by halo_fixup_kernel after the exchange
     }
