@@ -106,19 +106,29 @@ __global__ __launch_bounds__(256) void coarse_batch_restrict_store_kernel(float*
   const int half = n >> 1, nc = 2 * N;
   const float2* Yp = Y + (size_t)part * y_stride + (size_t)X * agg_sites * n * NB;
   float2* Mp = reinterpret_cast<float2*>(Mnext) + ((size_t)agg_csite[X] * 5 + part) * msize2;
-  for (int ip = q; ip < nc; ip += 4) {
-    const int h = ip >= N, jj = ip - h * N;
-    const float* p = P + (size_t)jj * pstride + (size_t)X * agg_sites * n * 2;
-    float sr = 0.f, si = 0.f;
+  // wavefront q owns the rows jj = q, q+4, ... of each chirality and runs ONCE over the aggregate's Y block for all of
+  // them (up to 8 rows: N <= 32): the block used to be streamed again for every row (14 times for N = 28)
+  for (int h = 0; h < 2; h++) {
+    float sr[8], si[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) { sr[r] = 0.f; si[r] = 0.f; }
+    const float* p0 = P + (size_t)q * pstride + (size_t)X * agg_sites * n * 2;
     for (int xs = 0; xs < agg_sites; xs++)
       for (int kk = 0; kk < half; kk++) {
         const int k = h * half + kk;
-        const float pr = p[((size_t)xs * n + k) * 2], pi = p[((size_t)xs * n + k) * 2 + 1];
+        const size_t e = ((size_t)xs * n + k) * 2;
         const float2 y = Yp[((size_t)xs * n + k) * NB + j];
-        sr += pr * y.x + pi * y.y;
-        si += pr * y.y - pi * y.x;
+#pragma unroll
+        for (int r = 0; r < 8; r++)
+          if (q + 4 * r < N) {     // wave-uniform
+            const float pr = p0[(size_t)4 * r * pstride + e], pi = p0[(size_t)4 * r * pstride + e + 1];
+            sr[r] += pr * y.x + pi * y.y;
+            si[r] += pr * y.y - pi * y.x;
+          }
       }
-    if (j < nc) Mp[tile_off_c(nt2, ip, j)] = make_float2(sr, si);
+#pragma unroll
+    for (int r = 0; r < 8; r++)
+      if (q + 4 * r < N && j < nc) Mp[tile_off_c(nt2, h * N + q + 4 * r, j)] = make_float2(sr[r], si[r]);
   }
 }
 
