@@ -140,6 +140,9 @@ void Interpolation<T>::restrict5(T* phi_c, size_t out_stride, const T* phi, size
 // v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; result register r of
 // lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// KSPLIT (at most 32 fields: one column tile, the bootstrap's 24 right-hand sides): the four wavefronts share that tile and
+// split the K range of every block instead of owning column tiles; their partial tiles are added through LDS at the end
+template <bool KSPLIT>
 __global__ __launch_bounds__(256, 2) void restrict_mfma_kernel(float* __restrict__ out, size_t out_stride, const float* __restrict__ W, size_t wstride, int nw,
                                                               const float* __restrict__ P, size_t pstride, int nvec, int V, int agg_sites,
                                                               const int* __restrict__ agg_csite, int a0, size_t Vw, size_t w0site) {
@@ -160,7 +163,8 @@ __global__ __launch_bounds__(256, 2) void restrict_mfma_kernel(float* __restrict
     // K blocks of this chirality: (chunk row kk, 16 sites from sb).  The operands of block b+1 are requested from global
     // memory before the products of block b are issued, so that the loads travel behind the matrix instructions
     const int nsb = agg_sites / KS, nblk = 3 * nsb;
-    float4 pa[2], pb[16];
+    constexpr int RB = KSPLIT ? 2 : 16;   // float4 of B per thread and block: 32 or 256 columns x 16 sites
+    float4 pa[2], pb[RB];
     auto fetch = [&](int b) {
       const int kk = 3 * h + b / nsb, sb = (b % nsb) * KS;
       const size_t row = ((size_t)kk * V + s0 + sb) * 4;
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void restrict_mfma_kernel(float* __restrict
         if (i < nvec) pa[r] = *reinterpret_cast<const float4*>(P + (size_t)i * pstride + row + sl * 4);
       }
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
+      for (int r = 0; r < RB; r++) {
         const int e = tid + 256 * r, col = e / KS, sl = e % KS;
         pb[r] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (col < nw) pb[r] = *reinterpret_cast<const float4*>(W + (size_t)col * wstride + wrow + sl * 4);
@@ -187,20 +191,20 @@ __global__ __launch_bounds__(256, 2) void restrict_mfma_kernel(float* __restrict
         if (i < 32) { As[4 * sl][i] = pa[r].x; As[4 * sl + 1][i] = pa[r].y; As[4 * sl + 2][i] = pa[r].z; As[4 * sl + 3][i] = pa[r].w; }
       }
 #pragma unroll
-      for (int r = 0; r < 16; r++) {
+      for (int r = 0; r < RB; r++) {
         const int e = tid + 256 * r, col = e / KS, sl = e % KS;
         Bs[4 * sl][col] = pb[r].x; Bs[4 * sl + 1][col] = pb[r].y; Bs[4 * sl + 2][col] = pb[r].z; Bs[4 * sl + 3][col] = pb[r].w;
       }
       __syncthreads();
       if (b + 1 < nblk) fetch(b + 1);
 #pragma unroll 1
-      for (int kp = 0; kp < 2 * KS; kp++) {
+      for (int kp = KSPLIT ? (KS / 2) * wv : 0; kp < (KSPLIT ? (KS / 2) * (wv + 1) : 2 * KS); kp++) {
         const int k = 2 * kp + (lane >> 5);
         const float aR = As[k][lane & 31];
         const float aI = (k & 1) ? As[k ^ 1][lane & 31] : -As[k ^ 1][lane & 31];
 #pragma unroll
-        for (int t = 0; t < 2; t++) {
-          const int tile = wv + 4 * t;
+        for (int t = 0; t < (KSPLIT ? 1 : 2); t++) {
+          const int tile = KSPLIT ? 0 : wv + 4 * t;
           if (tile < ntile) {
             const float bv = Bs[k][tile * 32 + (lane & 31)];
             accR[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aR, bv, accR[t], 0, 0, 0);
@@ -210,10 +214,32 @@ __global__ __launch_bounds__(256, 2) void restrict_mfma_kernel(float* __restrict
       }
     }
     const size_t cbase = ((size_t)agg_csite[a] * 2 * nvec + (size_t)h * nvec) * 2;
+    if constexpr (KSPLIT) {
+      // the four partial tiles: through LDS (the B stage is free now), wavefront 0 adds them in a fixed order
+      float* scratch = &Bs[0][0];
+      __syncthreads();
+      if (wv > 0) {
 #pragma unroll
-    for (int t = 0; t < 2; t++) {
-      const int col = (wv + 4 * t) * 32 + (lane & 31);
-      if (col < nw) {
+        for (int r = 0; r < 16; r++) {
+          scratch[((wv - 1) * 32 + r) * 64 + lane] = accR[0][r];
+          scratch[((wv - 1) * 32 + 16 + r) * 64 + lane] = accI[0][r];
+        }
+      }
+      __syncthreads();
+      if (wv == 0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+#pragma unroll
+          for (int w = 0; w < 3; w++) {
+            accR[0][r] += scratch[(w * 32 + r) * 64 + lane];
+            accI[0][r] += scratch[(w * 32 + 16 + r) * 64 + lane];
+          }
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < (KSPLIT ? 1 : 2); t++) {
+      const int col = KSPLIT ? (lane & 31) : (wv + 4 * t) * 32 + (lane & 31);
+      if (col < nw && (!KSPLIT || wv == 0)) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -231,8 +257,10 @@ template <typename T>
 void Interpolation<T>::restrict_batch(T* phi_c, size_t out_stride, const T* phi, size_t in_stride, int nw, hipStream_t st) const {
   if constexpr (sizeof(T) == 4) {
     DDAMG_REQUIRE(restrict_batch_available(agg_sites, nvec) && nw >= 1 && nw <= 256, "batched restriction: unsupported shape");
-    hipLaunchKernelGGL(restrict_mfma_kernel, dim3(num_aggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
-                       0, (size_t)V, (size_t)0);
+    if (nw <= 32) hipLaunchKernelGGL(restrict_mfma_kernel<true>, dim3(num_aggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
+                                     0, (size_t)V, (size_t)0);
+    else hipLaunchKernelGGL(restrict_mfma_kernel<false>, dim3(num_aggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
+                            0, (size_t)V, (size_t)0);
     DDAMG_HIP_CHECK(hipGetLastError());
   } else {
     DDAMG_REQUIRE(false, "batched restriction is an fp32 path");
@@ -242,7 +270,7 @@ template <typename T>
 void Interpolation<T>::restrict_batch_slab(T* phi_c, size_t out_stride, const T* phi, size_t in_stride, int nw, int agg0, int naggs, hipStream_t st) const {
   if constexpr (sizeof(T) == 4) {
     DDAMG_REQUIRE(restrict_batch_available(agg_sites, nvec) && nw >= 1 && nw <= 256 && agg0 >= 0 && agg0 + naggs <= num_aggs, "batched restriction: unsupported shape");
-    hipLaunchKernelGGL(restrict_mfma_kernel, dim3(naggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
+    hipLaunchKernelGGL(restrict_mfma_kernel<false>, dim3(naggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
                        agg0, (size_t)naggs * agg_sites, (size_t)agg0 * agg_sites);
     DDAMG_HIP_CHECK(hipGetLastError());
   } else {
