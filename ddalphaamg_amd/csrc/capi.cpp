@@ -155,6 +155,19 @@ static void upload_operator(ddamg_hip_ctx* c) {
   if (c->mg64 && c->setup_done) { c->mg64->operator_changed(); c->mg64->release_setup_workspace(); }
 }
 
+// gauge field -> operator fields in the reference's storage (dirac_setup, src/dirac.c:60-168), no upload
+static double gauge_fields(ddamg_hip_ctx* c, const double* gauge_lex, int anti_pbc, double* D_out, double* clover_out) {
+  const Geometry& g = c->levels[0]->geom;
+  if (g.distributed()) {
+    DDAMG_REQUIRE(c->comm != nullptr, "set_gauge on a process grid fetches the neighbours' links: install a transport first "
+                                      "(ddamg_hip_comm_init_rccl / ddamg_hip_comm_init_host / ddamg_hip_comm_init_mpi)");
+    return gauge_to_operator_dist(g, c->comm, gauge_lex, anti_pbc, c->par.m0, c->par.csw, D_out, clover_out, c->stream);
+  }
+  static const bool host_clover = getenv("DDAMG_HOST_CLOVER") != nullptr;
+  if (host_clover) return gauge_to_operator(g.L, gauge_lex, anti_pbc, c->par.m0, c->par.csw, D_out, clover_out);
+  return gauge_to_operator_device(g.L, gauge_lex, anti_pbc, c->par.m0, c->par.csw, D_out, clover_out, c->stream);
+}
+
 int ddamg_hip_set_gauge(ddamg_hip_ctx* c, const double* gauge_lex, int anti_pbc, double* plaquette) {
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c && gauge_lex, "null argument");
@@ -162,30 +175,50 @@ int ddamg_hip_set_gauge(ddamg_hip_ctx* c, const double* gauge_lex, int anti_pbc,
   const Geometry& g = c->levels[0]->geom;
   c->D_host.resize((size_t)g.V * 72);
   c->clover_host.resize((size_t)g.V * 84);
-  double pl;
-  if (g.distributed()) {
-    DDAMG_REQUIRE(c->comm != nullptr, "set_gauge on a process grid fetches the neighbours' links: install a transport first "
-                                      "(ddamg_hip_comm_init_rccl / ddamg_hip_comm_init_host / ddamg_hip_comm_init_mpi)");
-    pl = gauge_to_operator_dist(g, c->comm, gauge_lex, anti_pbc, c->par.m0, c->par.csw, c->D_host.data(), c->clover_host.data(), c->stream);
-  } else {
-    static const bool host_clover = getenv("DDAMG_HOST_CLOVER") != nullptr;
-    if (host_clover) pl = gauge_to_operator(g.L, gauge_lex, anti_pbc, c->par.m0, c->par.csw, c->D_host.data(), c->clover_host.data());
-    else pl = gauge_to_operator_device(g.L, gauge_lex, anti_pbc, c->par.m0, c->par.csw, c->D_host.data(), c->clover_host.data(), c->stream);
-  }
+  const double pl = gauge_fields(c, gauge_lex, anti_pbc, c->D_host.data(), c->clover_host.data());
   if (plaquette) *plaquette = pl;
   upload_operator(c);
   DDAMG_API_END
 }
 
 int ddamg_hip_set_gauge2(ddamg_hip_ctx* c, const double* hopp_gauge_lex, const double* clover_gauge_lex, int anti_pbc, double* plaquette) {
-  // two passes of the one-field routine: D from the first field, clover term and plaquette from the second
+  // D from the first field, clover term and plaquette from the second, ONE upload (and one rebuild of the hierarchy)
   if (hopp_gauge_lex == clover_gauge_lex) return ddamg_hip_set_gauge(c, hopp_gauge_lex, anti_pbc, plaquette);
-  if (int rc = ddamg_hip_set_gauge(c, hopp_gauge_lex, anti_pbc, nullptr)) return rc;
   DDAMG_API_BEGIN
-  const std::vector<double> D_hopp = c->D_host;
-  if (ddamg_hip_set_gauge(c, clover_gauge_lex, anti_pbc, plaquette)) throw std::runtime_error(g_last_error);
-  c->D_host = D_hopp;
+  DDAMG_REQUIRE(c && hopp_gauge_lex && clover_gauge_lex, "null argument");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  const Geometry& g = c->levels[0]->geom;
+  c->D_host.resize((size_t)g.V * 72);
+  c->clover_host.resize((size_t)g.V * 84);
+  std::vector<double> D_unused((size_t)g.V * 72), cl_unused((size_t)g.V * 84);
+  gauge_fields(c, hopp_gauge_lex, anti_pbc, c->D_host.data(), cl_unused.data());
+  const double pl = gauge_fields(c, clover_gauge_lex, anti_pbc, D_unused.data(), c->clover_host.data());
+  if (plaquette) *plaquette = pl;
   upload_operator(c);
+  DDAMG_API_END
+}
+
+// shift_update (src/dirac.c:646-668): m0 -> new_m0 on the operator that is set, on the device: the clover diagonals of both
+// precisions, the 6x6 inverses of the odd-even kernels, and the self couplings of every coarse level (+ their inverses).
+// No upload, no Galerkin construction; the host copy handed out by dd_alpha_amg_get_clover_pointer follows.
+int ddamg_hip_shift_mass(ddamg_hip_ctx* c, double new_m0) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && c->have_operator, "no operator set");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  const double diff = new_m0 - c->par.m0;
+  if (diff != 0.0) {
+    const size_t V = c->levels[0]->geom.V;
+    c->fop64.shift_diagonal(c->fop64.clover_field(), diff, c->stream);
+    c->fop32.shift_diagonal(c->fop64.clover_field(), 0.0, c->stream);
+    if (c->setup_done) {
+      if (c->mg32) c->mg32->mass_shifted(diff);
+      if (c->mg64) c->mg64->mass_shifted(diff);
+    }
+    for (size_t s = 0; s < V; s++)
+      for (int k = 0; k < 12; k++) c->clover_host[(s * 42 + k) * 2] += diff;
+    c->par.m0 = new_m0;
+    DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
+  }
   DDAMG_API_END
 }
 

@@ -48,6 +48,7 @@ class CoarseOp {
   void import_reference(const Geometry& g, const double* D_ref, const double* clover_ref, hipStream_t st);
   void export_reference(const Geometry& g, double* D_ref, double* clover_ref, hipStream_t st) const;
   void compute_self_inverse(hipStream_t st);  // Minv = M[0]^-1 on every site
+  void shift_diagonal(double diff, hipStream_t st);   // M[0] += diff * 1 on every site (mass shift; the caller redoes the inverse)
   CoarseOpDev<T> dev() const {
     CoarseOpDev<T> d{M_, Minv_, nb_, V_, n_, nt_, msize_, reinterpret_cast<const T*>(arena_.recv()), {0, 0, 0, 0, 0, 0, 0, 0}};
     for (int k = 0; k < 8; k++) d.hoff[k] = arena_.site_offset(k) * n_ * 2;

@@ -585,6 +585,22 @@ void CoarseOp<T>::compute_self_inverse(hipStream_t st) {
   DDAMG_HIP_CHECK(hipGetLastError());
 }
 
+// mass shift on a coarse level: P^H P = 1 on every aggregate and chirality, so P^H (D + d) P = D_c + d -- the self coupling
+// of every site gets d on its diagonal (shift_update_PRECISION, depth > 0 branch, src/dirac_generic.c:528-546)
+template <typename T>
+__global__ void shift_self_diagonal_kernel(T* __restrict__ M, int V, int n, int nt, size_t msize, T diff) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)V * n) return;
+  const size_t s = i / n; const int d = (int)(i % n);
+  M[(s * 5 * msize + (size_t)((d >> 3) * nt + (d >> 3)) * 64 + (d & 7) * 9) * 2] += diff;
+}
+template <typename T>
+void CoarseOp<T>::shift_diagonal(double diff, hipStream_t st) {
+  const size_t tot = (size_t)V_ * n_;
+  hipLaunchKernelGGL(shift_self_diagonal_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, M_, V_, n_, nt_, msize_, (T)diff);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
 // ---- allocation / import / export ---------------------------------------------------------------
 template <typename T> CoarseOp<T>::~CoarseOp() {
   if (M_) (void)hipFree(M_);

@@ -24,7 +24,9 @@ struct State {
   ddamg_hip_params hp;
   dd_alpha_amg_setup_status status{0, 0};
   int discard_setup_after = 0, update_setup_after = 0;
-  double mass_for_next_solve = 0, current_mass = 0;
+  double mass_for_next_solve = 0;
+  double setup_m0 = 0;       // g.setup_m0: mass of the operator during the iterative setup (src/init.c:326-357)
+  int print = 0;             // g.print
   bool setup_done = false, conf_set = false, fields_dirty = false;
   int V = 0;
   int P[4] = {1, 1, 1, 1};     // process grid = global / local lattice (T,Z,Y,X)
@@ -139,7 +141,11 @@ void params_from_ini(const Ini& ini, ddamg_hip_params& hp, int* anti_pbc) {
     if (whole_level != hp.num_levels - 1) fatal("d%d local lattice: only the coarsest level can be gathered", whole_level);
     hp.gather_coarsest = 1;
   }
-  ini.getd("m0:", &hp.m0); ini.getd("csw:", &hp.csw);
+  ini.getd("m0:", &hp.m0); ini.getd("solver m0:", &hp.m0); ini.getd("csw:", &hp.csw);
+  // "setup m0:" is read like the reference does (src/init.c:856-857) and, like there, replaced by dd_alpha_amg_par::setup_m0
+  // right after the file has been read (src/dd_alpha_amg.c:106; already src/init.c:1105 resets it to the solver mass)
+  S.setup_m0 = hp.m0; ini.getd("setup m0:", &S.setup_m0);
+  ini.geti("print mode:", &S.print);
   ini.getd("tolerance for relative residual:", &hp.tol);
   ini.geti("iterations between restarts:", &hp.restart);
   ini.geti("maximum of restarts:", &hp.max_restart);
@@ -184,6 +190,8 @@ void params_from_struct(const dd_alpha_amg_parameters& a, ddamg_hip_params& hp) 
   hp.m0 = a.solver_mass; hp.csw = a.c_sw;
   hp.restart = 50; hp.max_restart = 100; hp.tol = 1e-10;
   hp.kcycle = 1; hp.kcycle_restart = 5; hp.kcycle_max_restart = 2; hp.kcycle_tol = 1e-1;
+  S.setup_m0 = a.setup_mass;   // g.setup_m0 = amg_params->setup_mass (src/init.c:887); dd_alpha_amg_par::setup_m0 replaces it, see common_init
+  S.print = 1;                 // src/init.c:896
 }
 
 void common_init(const dd_alpha_amg_par& p) {
@@ -192,7 +200,8 @@ void common_init(const dd_alpha_amg_par& p) {
   S.par = p;
   S.hp.csw = p.csw;           // g.csw = p.csw (src/dd_alpha_amg.c:103)
   S.hp.m0 = p.m0;             // l.real_shift = p.m0
-  S.current_mass = S.mass_for_next_solve = p.m0;
+  S.setup_m0 = p.setup_m0;    // g.setup_m0 = p.setup_m0 in BOTH init paths (src/dd_alpha_amg.c:106,146), after the file / the struct
+  S.mass_for_next_solve = p.m0;
   const int nproc = S.P[0] * S.P[1] * S.P[2] * S.P[3];
   void* comm = nullptr;
   int (*comm_init_mpi)(ddamg_hip_ctx*, void*, int) = nullptr;
@@ -232,21 +241,31 @@ void reupload_if_dirty() {
   S.fields_dirty = false;
 }
 
-void shift_mass_if_needed() {
-  if (S.mass_for_next_solve == S.current_mass) return;
-  // shift_update (src/dirac.c:646-668): only the 12 diagonal clover entries change
-  const double diff = S.mass_for_next_solve - S.current_mass;
-  std::vector<double> D = S.ctx->D_host, cl = S.ctx->clover_host;
-  for (int s = 0; s < S.V; s++) for (int k = 0; k < 12; k++) cl[((size_t)s * 42 + k) * 2] += diff;
-  check(ddamg_hip_set_operator(S.ctx, D.data(), cl.data()), "shift update");
-  S.current_mass = S.mass_for_next_solve;
+// shift_update (src/dirac.c:646-668) on the device: diagonals of every level, no upload, no Galerkin construction
+void shift_mass(double m0) {
+  if (m0 == S.ctx->par.m0) return;
+  check(ddamg_hip_shift_mass(S.ctx, m0), "shift update");
+}
+void shift_mass_if_needed() { shift_mass(S.mass_for_next_solve); }   // run_dd_alpha_amg_setup_if_necessary, src/dd_alpha_amg.c:91-92
+
+// method_update (src/init.c:326-357): the iterative setup runs on the operator with mass g.setup_m0, then the solver mass
+// comes back.  The initial setup before it (method_setup) runs at the solver mass, as in the reference.
+int iterative_setup_at_setup_mass(int iterations) {
+  int ci = 0;
+  if (iterations <= 0 || S.hp.method <= 0 || S.hp.method == 5 || S.hp.num_levels < 2) return 0;
+  const double shift = S.ctx->par.m0;
+  shift_mass(S.setup_m0);
+  check(ddamg_hip_setup_update(S.ctx, iterations, &ci), "dd_alpha_amg_setup");
+  shift_mass(shift);
+  return ci;
 }
 
 void run_setup(int iterations, int* status) {
   if (!S.conf_set) fatal("dd_alpha_amg_setup: no configuration set");
   reupload_if_dirty();
   int ci = 0;
-  check(ddamg_hip_setup(S.ctx, iterations, &ci), "dd_alpha_amg_setup");
+  check(ddamg_hip_setup(S.ctx, 0, &ci), "dd_alpha_amg_setup");            // method_setup
+  ci += iterative_setup_at_setup_mass(iterations);                         // method_update
   S.setup_done = true;
   S.status.gauge_updates_since_last_setup = 0;
   S.status.gauge_updates_since_last_setup_update = 0;
@@ -256,8 +275,7 @@ void run_setup(int iterations, int* status) {
 void run_setup_update(int iterations, int* status) {
   if (!S.setup_done) fatal("dd_alpha_amg_setup_update: setup has not been run");
   reupload_if_dirty();
-  int ci = 0;
-  check(ddamg_hip_setup_update(S.ctx, iterations, &ci), "dd_alpha_amg_setup_update");
+  const int ci = iterative_setup_at_setup_mass(iterations);
   S.status.gauge_updates_since_last_setup_update = 0;
   status[0] = 1; status[1] = ci;
 }
@@ -361,14 +379,12 @@ double dd_alpha_amg_set_conf(double* gauge_field) {
     if (ifail) fatal("Error in \"dd_alpha_amg_set_conf\": Gauge field does not fit expected boundary conditions.");
     check(ddamg_hip_set_gauge2(S.ctx, H.data(), U.data(), 0, &plaq), "dd_alpha_amg_set_conf");
     S.conf_set = true; S.fields_dirty = false;
-    S.current_mass = S.hp.m0;
     return plaq;
   }
   // as in the reference, the boundary condition is NOT applied here: the caller's links carry it
   // (src/dd_alpha_amg.c:188-252 copies the field as it is)
   check(ddamg_hip_set_gauge(S.ctx, U.data(), 0, &plaq), "dd_alpha_amg_set_conf");
   S.conf_set = true; S.fields_dirty = false;
-  S.current_mass = S.hp.m0;
   return plaq;
 }
 
@@ -410,6 +426,14 @@ double dd_alpha_amg_wilson_solve(double* vector_out, double* vector_in, double t
   check(ddamg_hip_solve(S.ctx, sol.data(), src.data(), tol, &it, &cit, &rr), "dd_alpha_amg_wilson_solve");
   if (scaled) check(ddamg_hip_set_operator(S.ctx, D_keep.data(), cl_keep.data()), "restore clover");
   scatter_vector(vector_out, sol);
+  if (S.print > 0 && S.ctx->levels[0]->geom.rank == 0) {
+    // what the reference prints per outer iteration with g.print > 0 (src/linsolve_generic.c:322-329) and at the end (:363-374)
+    for (size_t i = 0; i < S.ctx->last_history.size(); i++)
+      printf("| approx. rel. res. after  %-6d iterations: %e |\n", (int)i + 1, S.ctx->last_history[i]);
+    printf("|       FGMRES iterations: %-6d coarse average: %-6.2lf   |\n", it, it > 0 ? (double)cit / it : 0.0);
+    printf("| exact relative residual: ||r||/||b|| = %e      |\n", rr);
+    fflush(stdout);
+  }
   status[0] = it; status[1] = cit;
   if (rr > tol) status[0] = -1;   // src/dd_alpha_amg.c:391-392
   return rr;

@@ -47,6 +47,12 @@ class FineOp {
   // D_ref: [V][4][9] complex (lexicographic sites), clover_ref: [V][42] complex, both fp64 as the
   // reference holds them in g.op_double (src/dirac.c:60-168)
   void upload(const Geometry& g, const double* D_ref, const double* clover_ref, hipStream_t st);
+  // mass shift without a new upload (shift_update_PRECISION src/dirac_generic.c:504-551): the 12 real diagonal clover entries
+  // of every site become those of `clover64` plus `diff`, and the 6x6 inverses the odd-even kernels read are rebuilt from the
+  // same fp64 values.  clover64: the fp64 operator's clover field (its own one for T = double, where diff is applied in
+  // place; the fp32 operator then follows with diff = 0), so both precisions stay what an upload of the shifted field gives.
+  void shift_diagonal(const double* clover64, double diff, hipStream_t st);
+  const T* clover_field() const { return clover_; }
   // eta = D_W phi; with a process grid: pack -> exchange (overlapped with the interior tiles) -> boundary tiles
   void apply(T* eta, const T* phi, hipStream_t st) const;
   FineOpDev<T> dev() const { return FineOpDev<T>{D_, clover_, clover_inv_, nb_, V_, halo_.recv(), halo_.dev(), tile_nb_, tnb_, parity_, Dc_, Dsgn_}; }

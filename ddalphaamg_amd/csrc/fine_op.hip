@@ -477,6 +477,37 @@ __device__ __forceinline__ size_t soa_index_dev(int NR, size_t V, size_t s, int 
   return (size_t)NF * V * CH + s * TL + (r - NF * CH);
 }
 
+// [A | 1] -> [1 | A^-1] for a complex 6x6 matrix, Gauss-Jordan with partial pivoting in fp64
+__device__ __forceinline__ void gauss_jordan6(double (&mr)[6][12], double (&mi)[6][12]) {
+  for (int col = 0; col < 6; col++) {
+    int piv = col;
+    double best = mr[col][col] * mr[col][col] + mi[col][col] * mi[col][col];
+    for (int r = col + 1; r < 6; r++) {
+      const double a2 = mr[r][col] * mr[r][col] + mi[r][col] * mi[r][col];
+      if (a2 > best) { best = a2; piv = r; }
+    }
+    if (piv != col)
+      for (int j = 0; j < 12; j++) {
+        double t = mr[col][j]; mr[col][j] = mr[piv][j]; mr[piv][j] = t;
+        t = mi[col][j]; mi[col][j] = mi[piv][j]; mi[piv][j] = t;
+      }
+    const double dr = mr[col][col] / best, di = -mi[col][col] / best;   // 1 / pivot
+    for (int j = 0; j < 12; j++) {
+      const double xr = mr[col][j], xi = mi[col][j];
+      mr[col][j] = xr * dr - xi * di; mi[col][j] = xr * di + xi * dr;
+    }
+    for (int r = 0; r < 6; r++) {
+      if (r == col) continue;
+      const double fr = mr[r][col], fi = mi[r][col];
+      if (fr == 0.0 && fi == 0.0) continue;
+      for (int j = 0; j < 12; j++) {
+        mr[r][j] -= fr * mr[col][j] - fi * mi[col][j];
+        mi[r][j] -= fr * mi[col][j] + fi * mr[col][j];
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(128) void operator_layout_kernel(T* __restrict__ D, T* __restrict__ clover, T* __restrict__ clover_inv,
                                                               const double* __restrict__ D_lex, const double* __restrict__ clover_lex,
@@ -508,33 +539,7 @@ __global__ __launch_bounds__(128) void operator_layout_kernel(T* __restrict__ D,
         clover[soa_index_dev<T>(72, V, s, r0 + 1)] = (T)mi[i][j];
         r0 += 2;
       }
-    for (int col = 0; col < 6; col++) {
-      int piv = col;
-      double best = mr[col][col] * mr[col][col] + mi[col][col] * mi[col][col];
-      for (int r = col + 1; r < 6; r++) {
-        const double a2 = mr[r][col] * mr[r][col] + mi[r][col] * mi[r][col];
-        if (a2 > best) { best = a2; piv = r; }
-      }
-      if (piv != col)
-        for (int j = 0; j < 12; j++) {
-          double t = mr[col][j]; mr[col][j] = mr[piv][j]; mr[piv][j] = t;
-          t = mi[col][j]; mi[col][j] = mi[piv][j]; mi[piv][j] = t;
-        }
-      const double dr = mr[col][col] / best, di = -mi[col][col] / best;   // 1 / pivot
-      for (int j = 0; j < 12; j++) {
-        const double xr = mr[col][j], xi = mi[col][j];
-        mr[col][j] = xr * dr - xi * di; mi[col][j] = xr * di + xi * dr;
-      }
-      for (int r = 0; r < 6; r++) {
-        if (r == col) continue;
-        const double fr = mr[r][col], fi = mi[r][col];
-        if (fr == 0.0 && fi == 0.0) continue;
-        for (int j = 0; j < 12; j++) {
-          mr[r][j] -= fr * mr[col][j] - fi * mi[col][j];
-          mi[r][j] -= fr * mi[col][j] + fi * mr[col][j];
-        }
-      }
-    }
+    gauss_jordan6(mr, mi);
     r0 = 36 * b;
     for (int i = 0; i < 6; i++) clover_inv[soa_index_dev<T>(72, V, s, r0 + i)] = (T)mr[i][6 + i];
     r0 += 6;
@@ -545,6 +550,42 @@ __global__ __launch_bounds__(128) void operator_layout_kernel(T* __restrict__ D,
         r0 += 2;
       }
   }
+}
+
+// mass shift: new diagonal = fp64 diagonal + diff, inverses of both 6x6 blocks rebuilt in fp64 (FineOp::shift_diagonal)
+template <typename T>
+__global__ __launch_bounds__(128) void clover_shift_kernel(T* clover, T* __restrict__ clover_inv, const double* clover64, double diff, int V) {
+  const size_t s = (size_t)blockIdx.x * 128 + threadIdx.x;
+  if (s >= (size_t)V) return;
+  for (int b = 0; b < 2; b++) {
+    double mr[6][12], mi[6][12];
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 12; j++) { mr[i][j] = (j == 6 + i) ? 1.0 : 0.0; mi[i][j] = 0.0; }
+    int r0 = 36 * b;
+    for (int i = 0; i < 6; i++) mr[i][i] = clover64[soa_index_dev<double>(72, V, s, r0 + i)] + diff;
+    for (int i = 0; i < 6; i++) clover[soa_index_dev<T>(72, V, s, r0 + i)] = (T)mr[i][i];
+    r0 += 6;
+    for (int i = 0; i < 6; i++)
+      for (int j = i + 1; j < 6; j++, r0 += 2) {
+        const double re = clover64[soa_index_dev<double>(72, V, s, r0)], im = clover64[soa_index_dev<double>(72, V, s, r0 + 1)];
+        mr[i][j] = re; mi[i][j] = im; mr[j][i] = re; mi[j][i] = -im;
+      }
+    gauss_jordan6(mr, mi);
+    r0 = 36 * b;
+    for (int i = 0; i < 6; i++) clover_inv[soa_index_dev<T>(72, V, s, r0 + i)] = (T)mr[i][6 + i];
+    r0 += 6;
+    for (int i = 0; i < 6; i++)
+      for (int j = i + 1; j < 6; j++, r0 += 2) {
+        clover_inv[soa_index_dev<T>(72, V, s, r0)] = (T)mr[i][6 + j];
+        clover_inv[soa_index_dev<T>(72, V, s, r0 + 1)] = (T)mi[i][6 + j];
+      }
+  }
+}
+template <typename T>
+void FineOp<T>::shift_diagonal(const double* clover64, double diff, hipStream_t st) {
+  DDAMG_REQUIRE(clover_ != nullptr && clover64 != nullptr, "shift_diagonal: no operator uploaded");
+  hipLaunchKernelGGL(clover_shift_kernel<T>, dim3((unsigned)((V_ + 127) / 128)), dim3(128), 0, st, clover_, clover_inv_, clover64, diff, (int)V_);
+  DDAMG_HIP_CHECK(hipGetLastError());
 }
 
 // two-row link storage from the reference's links (lexicographic fp64, U/2): rows 0 and 1 in fp32, the sign with which

@@ -764,6 +764,19 @@ void Multigrid<T>::operator_changed() {
   for (int l = 0; l + 1 < num_levels(); l++) build_coarse_operator(l);
 }
 
+// shift_update (src/dirac.c:646-668) on the hierarchy.  The reference re-runs its Galerkin construction on every level
+// (operator_updates_PRECISION, src/dirac_generic.c:465-501); with P^H P = 1 that is D_c + diff on every level, which is what
+// is done here without touching P: diagonal kernels and the inverses of the self couplings where a solver reads them.
+template <typename T>
+void Multigrid<T>::mass_shifted(double diff) {
+  for (int l = 1; l < num_levels(); l++) {
+    MGLevel<T>& lv = *lv_[l];
+    lv.cop.shift_diagonal(diff, st_);
+    if (lv.coarsest || par_.method == 4) lv.cop.compute_self_inverse(st_);
+    if (lv.coarsest && gath_.on) { gath_.cop.shift_diagonal(diff, st_); gath_.cop.compute_self_inverse(st_); }
+  }
+}
+
 template <typename T>
 void Multigrid<T>::import_test_vectors(const double* tv_lex_host) {
   MGLevel<T>& lv = *lv_[0];

@@ -83,6 +83,7 @@ class Multigrid {
   void import_test_vectors(const double* tv_lex_host);   // level-0 test vectors, then re_setup(0)
   void import_interpolation(const double* P_lex_host);   // level-0 interpolation vectors as they are
   void operator_changed();              // fine operator re-uploaded: rebuild the coarse operators
+  void mass_shifted(double diff);       // fine operator's mass changed by diff: the same shift on every coarse self coupling
   void set_kcycle_tol(double tol);
   void release_setup_workspace();       // large temporaries of the Galerkin construction (kept across the builds of one setup)
   void set_comm(Comm* c) { comm_ = c; for (auto& lv : lv_) { lv->rw.comm = c; lv->srw.comm = c; lv->cop.set_comm(c); } }

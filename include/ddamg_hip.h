@@ -95,6 +95,10 @@ int ddamg_hip_set_gauge2(ddamg_hip_ctx* ctx, const double* hopp_gauge_lex, const
  * g.op_double.clover: [V][42] complex; src/dirac.c:80,386-398) -- the path behind
  * dd_alpha_amg_get_gauge_pointer / dd_alpha_amg_get_clover_pointer (src/dirac.c:171-176). */
 int ddamg_hip_set_operator(ddamg_hip_ctx* ctx, const double* D_lex, const double* clover_lex);
+/* shift_update (src/dirac.c:646-668): change the mass of the operator that is set, m0 -> new_m0, without a new upload and
+ * without rebuilding the hierarchy: diagonal updates on the device on every level (shift_update_PRECISION
+ * src/dirac_generic.c:504-551) and the inverses the odd-even kernels read.  ddamg_hip_get_operator shows the new clover field. */
+int ddamg_hip_shift_mass(ddamg_hip_ctx* ctx, double new_m0);
 /* read back the fp64 operator in the reference's storage (for parity tests) */
 int ddamg_hip_get_operator(ddamg_hip_ctx* ctx, double* D_lex, double* clover_lex);
 
