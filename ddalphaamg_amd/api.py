@@ -87,6 +87,7 @@ def load_library():
         "ddamg_hip_set_gauge": [vp, dp, ctypes.c_int, dp],
         "ddamg_hip_set_gauge2": [vp, dp, dp, ctypes.c_int, dp],
         "ddamg_hip_set_operator": [vp, dp, dp],
+        "ddamg_hip_shift_mass": [vp, ctypes.c_double],
         "ddamg_hip_get_operator": [vp, dp, dp],
         "ddamg_hip_vec_create": [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)],
         "ddamg_hip_vec_destroy": [vp, vp],
@@ -302,6 +303,10 @@ class Context:
         if D.size != V * 72 or cl.size != V * 84:
             raise DDAMGError("set_operator: D must be [V][36] complex and clover [V][42] complex")
         _check(self._lib.ddamg_hip_set_operator(self._h, _dp(D), _dp(cl)))
+
+    def shift_mass(self, m0):
+        """shift_update of the reference: change the mass of the operator that is set, on the device, on every level"""
+        _check(self._lib.ddamg_hip_shift_mass(self._h, float(m0)))
 
     def get_operator(self):
         V = self.volume(0)

@@ -402,12 +402,14 @@ void dd_alpha_amg_update_parameters(const struct dd_alpha_amg_parameters* a) {
 void dd_alpha_amg_setup(int iterations, int* status) { run_setup(iterations, status); }
 void dd_alpha_amg_setup_external_threading(int iterations, int* status, int core, int thread, void*, void (*)(void*, int)) {
   if (core != 0 || thread != 0) { status[0] = 1; status[1] = 0; return; }
-  run_setup(iterations, status);
+  (void)iterations;
+  run_setup(S.hp.setup_iter[0], status);   // run_setup() of the reference takes g.setup_iter[0], not the argument (src/dd_alpha_amg.c:48-65)
 }
 void dd_alpha_amg_setup_update(int iterations, int* status) { run_setup_update(iterations, status); }
 void dd_alpha_amg_setup_update_external_threading(int iterations, int* status, int core, int thread, void*, void (*)(void*, int)) {
   if (core != 0 || thread != 0) { status[0] = 1; status[1] = 0; return; }
-  run_setup_update(iterations, status);
+  (void)iterations;
+  run_setup_update(S.hp.setup_iter[0], status);   // src/dd_alpha_amg.c:67-83
 }
 
 double dd_alpha_amg_wilson_solve(double* vector_out, double* vector_in, double tol, double scale_even, double scale_odd, int* status) {

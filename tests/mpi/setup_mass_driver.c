@@ -11,8 +11,12 @@
  * 4^4 lattice; gauge.bin: 256 x 4 x 18 doubles, lexicographic (t,z,y,x; mu = T,Z,Y,X), boundary sign already applied.
  * init: parameter-file path, setup + solve of b = 1 (the file asks for "print mode: 1", so the library prints the residual
  *   curve); with m0_second_solve a second solve at another mass through dd_alpha_amg_update_parameters (mass_for_next_solve).
- * struct: parameter-struct path; the reference keeps no outer solver there (g.restart = -1, src/init.c:893), so only the
- *   setup is run and its coarse-grid iteration count (status[1]) is printed. */
+ * struct: the same through the parameter struct (dd_alpha_amg_init_external_threading and the _external_threading setup).
+ *   Against the reference itself this mode cannot run: its struct path never sets g.ncycle[] (set_dd_alpha_amg_parameters,
+ *   src/init.c:1163-1177), so l->n_cy is read from uninitialised memory (src/init.c:1084) and validate_parameters aborts on
+ *   "IMPLIES( g.method > 0, l->n_cy > 0 )" (src/init.c:1034) -- observed here; it also keeps no outer solver there
+ *   (g.restart = -1, src/init.c:893).  The struct path of libddamg_hip.so is therefore compared with the reference's
+ *   init-path run on the same parameters (the struct path hard-wires exactly those, src/init.c:876-901). */
 #include <mpi.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -22,6 +26,7 @@
 static int conf_index(int t, int z, int y, int x, int mu) { return ((((t * 4 + z) * 4 + y) * 4 + x) * 4 + mu) * 18; }
 static int vector_index(int t, int z, int y, int x) { return (((t * 4 + z) * 4 + y) * 4 + x) * 24; }
 static int global_time(int t) { return t; }
+static void no_barrier(void* data, int id) { (void)data; (void)id; }   /* one core, one thread: nothing to wait for */
 
 int main(int argc, char** argv) {
   MPI_Init(&argc, &argv);
@@ -57,9 +62,12 @@ int main(int argc, char** argv) {
   }
   const double plaq = dd_alpha_amg_set_conf(U);
   int status[2] = {0, 0};
-  dd_alpha_amg_setup(setup_iter, status);
+  /* the struct path belongs to callers that bring their own threads: its entry points are the _external_threading ones
+   * (the reference's plain dd_alpha_amg_setup waits for barriers that only they install) */
+  if (by_struct) dd_alpha_amg_setup_external_threading(setup_iter, status, 0, 0, NULL, no_barrier);
+  else dd_alpha_amg_setup(setup_iter, status);
   printf("RESULT plaquette %.12f\nRESULT setup_coarse_iterations %d\n", plaq, status[1]);
-  if (!by_struct) {
+  {
     double *b = malloc(sizeof(double) * V * 24), *x = calloc(V * 24, sizeof(double));
     for (size_t i = 0; i < V * 12; i++) { b[2 * i] = 1.0; b[2 * i + 1] = 0.0; }
     double rr = dd_alpha_amg_wilson_solve(x, b, 1e-10, 1.0, 1.0, status);

@@ -1,0 +1,110 @@
+"""GPU tests (-m gpu) of the two masses of the library interface.
+
+1. Setup at a mass different from the solver mass (dd_alpha_amg_par::setup_m0, src/dd_alpha_amg.c:106,146; method_update shifts
+   the operator to it for the iterative setup and back, src/init.c:326-357): the host program tests/mpi/setup_mass_driver.c,
+   which knows only include/dd_alpha_amg.h, was run against the REFERENCE library (oracle/make_setup_mass_golden.py ->
+   tests/golden/ref_setup_mass.json); here the same program runs against libddamg_hip.so, through dd_alpha_amg_init and through
+   the parameter struct.  (The reference's own struct path aborts in validate_parameters on an uninitialised g.ncycle[], see the
+   driver's header; it hard-wires the parameters the file of the init-path run spells out, so that run is the fixture for both.)
+2. The mass shift itself (shift_update, src/dirac.c:646-668) as diagonal updates on the device on every level
+   (ddamg_hip_shift_mass): the operator, the hierarchy and the solve afterwards against a context that got the shifted
+   operator through a full upload + Galerkin rebuild."""
+import json, os, subprocess, sys
+import numpy as np
+import pytest
+from conftest import GOLDEN, REPO, relerr, splitmix_uniform
+from ddalphaamg_amd import api
+import ddalphaamg_amd as dd
+
+sys.path.insert(0, os.path.join(REPO, "oracle"))
+pytestmark = pytest.mark.gpu
+DRIVER = os.path.join(REPO, "tests", "mpi", "setup_mass_driver")
+
+
+@pytest.fixture(scope="module")
+def golden():
+    return {(c["mode"], c["setup_m0"]): c for c in json.load(open(os.path.join(GOLDEN, "ref_setup_mass.json")))["cases"]}
+
+
+@pytest.mark.parametrize("mode", ["init", "struct"])
+@pytest.mark.parametrize("setup_m0", [-0.35, -0.5])
+def test_setup_mass_apart_from_solver_mass_against_the_reference_library(golden, tmp_path, mode, setup_m0):
+    import make_setup_mass_golden as mk      # checker side: writes the same inputs the reference run got, parses the same output
+    if not os.path.exists(DRIVER):
+        pytest.fail("tests/mpi/setup_mass_driver not built (make -C ddalphaamg_amd/csrc mpi)")
+    ref = golden[("init", setup_m0)]
+    gauge, ini = mk.write_inputs(str(tmp_path), ref["m0"], setup_m0, ref["setup_iter"])
+    cmd = [DRIVER, mode, repr(ref["m0"]), repr(setup_m0), gauge, str(ref["setup_iter"])] + ([ini] if mode == "init" else [])
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = mk.parse(r.stdout)
+    assert abs(got["plaquette"] - ref["plaquette"]) < 1e-11
+    assert got["iterations"] == ref["iterations"], (got, ref)
+    assert got["relres"] < 1e-10
+    # same Krylov trajectory as the reference: the residual curve, digit by digit at the start, to a few per cent at the end
+    # (fp32 V-cycle; the two setup masses differ by 3 % in the FIRST entry, 0.0821 against 0.0851, so this tells them apart)
+    h, hr = np.array(got["residual_history"]), np.array(ref["residual_history"])
+    assert len(h) == len(hr)
+    assert abs(h[0] / hr[0] - 1.0) < 2e-5 and np.max(np.abs(h / hr - 1.0)) < 3e-2, (h, hr)
+    assert abs(got["coarse_iterations"] - ref["coarse_iterations"]) <= 3
+    assert abs(got["setup_coarse_iterations"] - ref["setup_coarse_iterations"]) <= 0.03 * ref["setup_coarse_iterations"]
+
+
+def hierarchy_params(L, levels, m0):
+    p = api.default_params(); p.num_levels = levels
+    for mu in range(4):
+        p.local_lattice[0][mu] = L[mu]; p.block_lattice[0][mu] = 2; p.local_lattice[1][mu] = L[mu] // 2
+        if levels == 3:
+            p.block_lattice[1][mu] = 2; p.local_lattice[2][mu] = L[mu] // 4
+    p.num_vect[0] = 12; p.num_vect[1] = 14; p.setup_iter[0] = 2; p.setup_iter[1] = 2
+    p.post_smooth_iter[0] = p.post_smooth_iter[1] = 2; p.block_iter[0] = p.block_iter[1] = 4
+    p.restart, p.max_restart, p.tol = 30, 20, 1e-10
+    p.coarse_iter, p.coarse_restart, p.coarse_tol = 100, 5, 5e-2
+    p.mixed_precision, p.method, p.odd_even = 1, 2, 1
+    p.m0, p.csw = m0, 1.0
+    return p
+
+
+@pytest.mark.parametrize("levels", [2, 3])
+def test_mass_shift_on_the_device_equals_upload_and_rebuild(gold8, levels):
+    L = [8, 8, 8, 8]; V = 4096
+    U = gold8["gauge"]
+    m_a, m_b = -0.5, -0.42
+    b = splitmix_uniform(V * 24, 3).reshape(V, 12, 2)
+
+    A = dd.Context(hierarchy_params(L, levels, m_a))
+    A.set_gauge(U, anti_pbc=True)
+    A.setup(2)
+    D0, cl0 = A.get_operator()
+    A.shift_mass(m_b)                      # device: diagonals of every level
+    DA, clA = A.get_operator()
+    cl_expect = cl0.copy(); cl_expect[:, :12, 0] += m_b - m_a
+    assert np.array_equal(DA, D0) and np.array_equal(clA, cl_expect)
+    xa, ita, cita, rra = A.solve(b, 1e-10)
+    hist_a = np.array(A.residual_history())
+    phi = splitmix_uniform(V * 24, 4).reshape(V, 12, 2)
+    ya = {}
+    for prec in (32, 64):
+        v = A.vector(0, prec).upload(phi); w = A.vector(0, prec); A.dirac_apply(w, v); ya[prec] = w.download()
+    DcA, clcA = A.get_coarse_operator()
+
+    B = dd.Context(hierarchy_params(L, levels, m_a))
+    B.set_gauge(U, anti_pbc=True)
+    B.setup(2)                             # same rand() stream as A (seeded at create): same test vectors
+    B.set_operator(D0, cl_expect)          # the long way: upload of the shifted field, Galerkin construction on every level
+    xb, itb, citb, rrb = B.solve(b, 1e-10)
+    hist_b = np.array(B.residual_history())
+    for prec in (32, 64):
+        v = B.vector(0, prec).upload(phi); w = B.vector(0, prec); B.dirac_apply(w, v)
+        assert np.array_equal(w.download(), ya[prec])          # fine operator: bit for bit, both precisions
+    DcB, clcB = B.get_coarse_operator()
+    assert np.array_equal(DcA, DcB)                            # links untouched
+    assert relerr(clcA, clcB) < 2e-6                           # P^H (D + d) P = D_c + d up to the rounding of P^H P = 1 in fp32
+    assert ita == itb and abs(cita - citb) <= 2 and max(rra, rrb) < 1e-10
+    assert np.max(np.abs(hist_a / hist_b - 1.0)) < 2e-2
+    assert relerr(xa, xb) < 1e-8
+    # and back: the original operator again, bit for bit on the fine level
+    A.shift_mass(m_a)
+    _, cl_back = A.get_operator()
+    assert np.max(np.abs(cl_back - cl0)) < 1e-15
+    A.close(); B.close()
