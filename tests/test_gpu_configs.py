@@ -54,7 +54,10 @@ def test_solve_true_residual_iteration_band_and_repeatability(big):
     x1 = ctx.vector(0, 64); x2 = ctx.vector(0, 64)
     it, cit, rr = ctx.solve_vec(x1, bv, 1e-10)
     assert rr < 1e-10, rr
-    assert 9 <= it <= 18, it                      # the reference needs 11-12 on this kind of field (golden fixtures)
+    # the reference itself on this field and this hierarchy shape: 12 iterations at 32^4 and at 64 x 32^3, the largest volumes
+    # it fits into the build container (tests/golden/ref_32x32_3lvl.json, ref_64x32_3lvl.json; 48^4 needs about 87 GB there)
+    print(f"{ext}^4 three-level:", it, cit, rr)
+    assert abs(it - 12) <= 1, it
     # the true residual, recomputed here with the fp64 operator on the device
     Dx = ctx.vector(0, 64)
     ctx.dirac_apply(Dx, x1)

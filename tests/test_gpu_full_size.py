@@ -10,28 +10,36 @@ from conftest import relerr, splitmix_uniform
 from ddalphaamg_amd import api
 import ddalphaamg_amd as dd
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+REPO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tools"))
 pytestmark = pytest.mark.gpu
+# the seeded field the reference itself was run on at this volume (oracle/run_reference_big.py, tests/golden/ref_32x32_2lvl.json)
+GAUGE_EPS, GAUGE_SEED = 0.35, 20260101
 
 L = [32, 32, 32, 32]
 V = 32 ** 4
+# measured with this library on the fields of these tests (gpurun, round 3); a change of more than one iteration is a regression
+# or an algorithmic change that has to be looked at.  The reference's own numbers at small volumes are in tests/golden/ref_runs.json
+# and the method dumps (test_gpu_schwarz_methods.py); it is too slow to run these smoothers at 32^4 in the build container.
+OTHER_SMOOTHER_ITERATIONS = {1: 18, 3: 13, 4: 9}
+FOUR_LEVEL_ITERATIONS = 11
 
 
 @pytest.fixture(scope="module")
 def ctx32():
-    from bench import near_unit_gauge
+    import synth
     p = api.default_params(); p.num_levels = 2
     for mu in range(4):
         p.local_lattice[0][mu] = 32; p.block_lattice[0][mu] = 4; p.local_lattice[1][mu] = 8
-    p.num_vect[0] = 24; p.post_smooth_iter[0] = 2; p.block_iter[0] = 4; p.setup_iter[0] = 3
-    p.restart, p.max_restart, p.tol = 50, 20, 1e-10
+    p.num_vect[0] = 24; p.post_smooth_iter[0] = 2; p.block_iter[0] = 4; p.setup_iter[0] = 4
+    p.restart, p.max_restart, p.tol = 20, 20, 1e-10
     p.coarse_iter, p.coarse_restart, p.coarse_tol = 100, 5, 5e-2
     p.mixed_precision, p.method, p.odd_even = 1, 2, 1
     p.m0, p.csw = -0.3, 1.0
     p.test_vector_rng, p.rng_seed = 1, 7
     ctx = dd.Context(p)
-    ctx.set_gauge(near_unit_gauge(V, 0.35, 11), anti_pbc=True)
-    ctx.setup(3)
+    ctx.set_gauge(synth.synth_gauge(L, GAUGE_EPS, GAUGE_SEED), anti_pbc=True)
+    ctx.setup(4)
     yield ctx
     ctx.close()
 
@@ -88,7 +96,15 @@ def test_smoother_converges(ctx32):
 def test_solve_host_and_device_vectors(ctx32):
     b = np.zeros((V, 12, 2)); b[..., 0] = 1.0
     x, it, cit, rr = ctx32.solve(b, 1e-10)
-    assert rr < 1e-10 and 8 <= it <= 16
+    # the reference on this field with these parameters: 12 iterations (tests/golden/ref_32x32_2lvl.json); +-1 for the other
+    # random test vectors (device generator here, rand() there)
+    import json
+    ref = json.load(open(os.path.join(REPO, "tests", "golden", "ref_32x32_2lvl.json")))
+    print("32^4 two-level:", it, cit, rr, "reference", ref["iterations"])
+    assert rr < 1e-10 and abs(it - ref["iterations"]) <= 1, (it, ref["iterations"])
+    hist = np.array(ctx32.residual_history()); href = np.array(ref["residual_history"])
+    n = min(len(hist), len(href)) - 1
+    assert np.max(np.abs(np.log10(hist[:n] / href[:n]))) < 0.35      # the same convergence rate: within a factor 2.2 at every step
     # the returned relative residual is the true one: recompute it with the fp64 operator
     xv = ctx32.vector(0, 64).upload(x); Dx = ctx32.vector(0, 64)
     ctx32.dirac_apply(Dx, xv)
@@ -121,7 +137,8 @@ def test_four_level_hierarchy():
     ctx.setup(3)
     b = np.zeros((Vl, 12, 2)); b[..., 0] = 1.0
     x, it, cit, rr = ctx.solve(b, 1e-10)
-    assert rr < 1e-10 and it <= 16
+    print("16^4 four-level:", it, cit, rr)
+    assert rr < 1e-10 and abs(it - FOUR_LEVEL_ITERATIONS) <= 1, it
     ctx.close()
 
 
@@ -130,7 +147,7 @@ def test_other_smoothers_at_full_size(method):
     """additive / sixteen-colour Schwarz and the GMRES smoother at 32^4: every cycle lowers the residual, and the solve with
     the smoother inside the V-cycle reaches the target with the true residual it reports (the device-side generator makes
     the setup cheap enough to run it per smoother)"""
-    from bench import near_unit_gauge
+    import synth
     p = api.default_params(); p.num_levels = 2
     for mu in range(4):
         p.local_lattice[0][mu] = 32; p.block_lattice[0][mu] = 4; p.local_lattice[1][mu] = 8
@@ -141,7 +158,7 @@ def test_other_smoothers_at_full_size(method):
     p.m0, p.csw = -0.3, 1.0
     p.test_vector_rng, p.rng_seed = 1, 7
     ctx = dd.Context(p)
-    ctx.set_gauge(near_unit_gauge(V, 0.35, 11), anti_pbc=True)
+    ctx.set_gauge(synth.synth_gauge(L, GAUGE_EPS, GAUGE_SEED), anti_pbc=True)
     ctx.setup(2)
     eta = splitmix_uniform(V * 24, 9).reshape(V, 12, 2)
     e = ctx.vector(0, 32).upload(eta); phi = ctx.vector(0, 32); Dphi = ctx.vector(0, 32)
@@ -155,7 +172,8 @@ def test_other_smoothers_at_full_size(method):
         v.free()
     b = np.zeros((V, 12, 2)); b[..., 0] = 1.0
     x, it, cit, rr = ctx.solve(b, 1e-10)
-    assert rr < 1e-10 and it <= 30, (it, rr)
+    print("32^4 method", method, ":", it, cit, rr)
+    assert rr < 1e-10 and abs(it - OTHER_SMOOTHER_ITERATIONS[method]) <= 1, (it, rr)
     xv = ctx.vector(0, 64).upload(x); Dx = ctx.vector(0, 64)
     ctx.dirac_apply(Dx, xv)
     assert abs(np.linalg.norm(b - Dx.download()) / np.linalg.norm(b) - rr) < 1e-12

@@ -1,0 +1,55 @@
+"""GPU test: the three-level production hierarchy (BASELINE configs[3]/[4] shape, the `strong_scaling` algorithm of bench.py)
+against runs of the REFERENCE ITSELF at the same volume on the same seeded field.  A file of its own: the 64^4 context of
+test_gpu_configs.py has to be gone before these contexts are built."""
+import os, sys
+import numpy as np
+import pytest
+from ddalphaamg_amd import api
+import ddalphaamg_amd as dd
+
+REPO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tools"))
+pytestmark = pytest.mark.gpu
+
+
+def device_norm_of_difference(ctx, a, b):
+    z = ctx.vector(a.level, a.precision)
+    ctx.vec_axpy(z, a, b, -1.0)
+    _, n = ctx.vec_dot(z, z)
+    z.free()
+    return n
+
+
+@pytest.mark.parametrize("name,lat", [("32x32_3lvl", [32, 32, 32, 32]), ("64x32_3lvl", [64, 32, 32, 32])])
+def test_three_level_production_shape_against_the_reference_at_the_same_volume(name, lat):
+    """The `strong_scaling` algorithm of bench.py (3 levels, 4^4 then 2^4 aggregates, Nvec 24 / 28, K-cycle, FGMRES(10) x 100)
+    on the field the REFERENCE was run on at the same volume (oracle/run_reference_big.py -> tests/golden/ref_<name>.json):
+    iteration count within +-1 (north_star), the same convergence rate step by step, the reported residual the true one.
+    64 x 32^3 is the local volume of the 8-GPU decomposition of 64^4 and the largest case the reference fits into the build
+    container's memory."""
+    import json
+    import bench, synth
+    ref = json.load(open(os.path.join(REPO, "tests", "golden", f"ref_{name}.json")))
+    assert ref["lattice"] == lat and ref["gauge"]["seed"] == 20260101
+    p = bench.amg_params(api, lat, 3, 0)
+    p.restart, p.max_restart = 10, 100
+    ctx = dd.Context(p)
+    U = synth.synth_gauge(lat, ref["gauge"]["eps"], ref["gauge"]["seed"])
+    ctx.set_gauge(U, anti_pbc=True)
+    del U
+    ctx.setup(p.setup_iter[0])
+    V = int(np.prod(lat))
+    b = np.zeros((V, 12, 2)); b[..., 0] = 1.0
+    bv = ctx.vector(0, 64).upload(b); del b
+    xv = ctx.vector(0, 64)
+    it, cit, rr = ctx.solve_vec(xv, bv, 1e-10)
+    print(name, "iterations", it, "reference", ref["iterations"], "coarse average", cit / it, "reference", ref["coarse_average_iterations"])
+    assert rr < 1e-10 and abs(it - ref["iterations"]) <= 1, (it, ref["iterations"])
+    hist = np.array(ctx.residual_history()); href = np.array(ref["residual_history"])
+    n = min(len(hist), len(href)) - 1
+    assert np.max(np.abs(np.log10(hist[:n] / href[:n]))) < 0.35
+    Dx = ctx.vector(0, 64)
+    ctx.dirac_apply(Dx, xv)
+    _, nb = ctx.vec_dot(bv, bv)
+    assert abs(device_norm_of_difference(ctx, bv, Dx) / nb - rr) < 1e-3 * rr + 1e-14
+    ctx.close()
