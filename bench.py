@@ -59,12 +59,14 @@ def parse_args():
 # ---- N > 1 without a launcher: the parent only starts and reaps the ranks ------------------------------------------
 def spawn_ranks(n):
     """one child process per GPU; the parent imports neither torch nor the library and never touches a GPU"""
-    import socket
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    import tempfile
+    # rendezvous through a file the parent owns (torch's file:// store): no port is probed and then bound by somebody else
+    rdzv_dir = tempfile.mkdtemp(prefix="ddamg_bench_rdzv_")
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+                   DDAMG_BENCH_RDZV="file://" + os.path.join(rdzv_dir, "store"))
+        env.pop("MASTER_PORT", None)
         env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // n)))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
@@ -94,6 +96,8 @@ def spawn_ranks(n):
             if rc == 0:
                 rc = 3
             break
+    import shutil
+    shutil.rmtree(rdzv_dir, ignore_errors=True)
     return rc
 
 
@@ -430,13 +434,17 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # self-spawned ranks meet through the parent's file store; under torchrun the launcher's env:// rendezvous is used
+        rdzv = {}
+        if os.environ.get("DDAMG_BENCH_RDZV"):
+            rdzv = dict(init_method=os.environ["DDAMG_BENCH_RDZV"], rank=rank, world_size=world)
         if args.transport == "rccl":
             if torch.cuda.device_count() < world:
                 raise SystemExit(f"bench.py: {world} ranks over RCCL need {world} GPUs, {torch.cuda.device_count()} visible "
                                  "(use --transport host to rehearse on fewer)")
-            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank), **rdzv)
         else:
-            dist.init_process_group(backend="gloo")
+            dist.init_process_group(backend="gloo", **rdzv)
             local_rank = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
 

@@ -25,6 +25,12 @@ struct Comm {
   void* user = nullptr;
   int rank = 0, nranks = 1;
   hipEvent_t ev_a = nullptr, ev_b = nullptr;   // ordering between the compute stream and the transport stream
+  // split-phase reductions (pipelined Arnoldi): a communicator, stream and event pair of their own, so that a global sum in
+  // flight does not queue in front of the halo exchange of the operator application it is meant to hide behind
+  ncclComm_t nccl_red = nullptr;
+  hipStream_t stream_red = nullptr;
+  hipEvent_t ev_ra = nullptr, ev_rb = nullptr;
+  bool red_tried = false;
   double* h_red = nullptr;                      // pinned staging for the host transport's reductions
   int h_red_n = 0;
   char* h_gather = nullptr;                     // pinned staging for the host transport's all-gather
@@ -89,16 +95,33 @@ void comm_allreduce(Comm* c, double* d_buf, int n, hipStream_t st) {
   }
 }
 
+static void create_transport_stream(hipStream_t* st);
 void comm_allreduce_begin(Comm* c, double* d_buf, int n, hipStream_t st) {
   if (!c || c->kind != 1) return;
-  DDAMG_HIP_CHECK(hipEventRecord(c->ev_a, st));
-  DDAMG_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_a, 0));
-  DDAMG_NCCL_CHECK(ncclAllReduce(d_buf, d_buf, (size_t)n, ncclDouble, ncclSum, c->nccl, c->stream));
-  DDAMG_HIP_CHECK(hipEventRecord(c->ev_b, c->stream));
+  if (!c->red_tried) {
+    // first split-phase reduction (every process reaches it at the same point of the same algorithm): split off a second
+    // communicator.  If the library refuses, the reductions share the halo stream as before (correct, not overlapped).
+    c->red_tried = true;
+    ncclComm_t sub = nullptr;
+    if (ncclCommSplit(c->nccl, 0, c->rank, &sub, nullptr) == ncclSuccess && sub) {
+      c->nccl_red = sub;
+      create_transport_stream(&c->stream_red);
+      DDAMG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_ra, hipEventDisableTiming));
+      DDAMG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_rb, hipEventDisableTiming));
+    } else {
+      (void)hipGetLastError();
+    }
+  }
+  const bool own = c->nccl_red != nullptr;
+  hipStream_t rs = own ? c->stream_red : c->stream;
+  DDAMG_HIP_CHECK(hipEventRecord(own ? c->ev_ra : c->ev_a, st));
+  DDAMG_HIP_CHECK(hipStreamWaitEvent(rs, own ? c->ev_ra : c->ev_a, 0));
+  DDAMG_NCCL_CHECK(ncclAllReduce(d_buf, d_buf, (size_t)n, ncclDouble, ncclSum, own ? c->nccl_red : c->nccl, rs));
+  DDAMG_HIP_CHECK(hipEventRecord(own ? c->ev_rb : c->ev_b, rs));
 }
 void comm_allreduce_end(Comm* c, double* d_buf, int n, hipStream_t st) {
   if (!c) return;
-  if (c->kind == 1) { DDAMG_HIP_CHECK(hipStreamWaitEvent(st, c->ev_b, 0)); return; }
+  if (c->kind == 1) { DDAMG_HIP_CHECK(hipStreamWaitEvent(st, c->nccl_red ? c->ev_rb : c->ev_b, 0)); return; }
   comm_allreduce(c, d_buf, n, st);
 }
 
@@ -176,6 +199,11 @@ Comm* comm_create_host(const Geometry& g, ddamg_hip_exchange_fn fn, ddamg_hip_al
 void comm_destroy(Comm* c) {
   if (!c) return;
   if (c->stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream_red) (void)hipStreamSynchronize(c->stream_red);
+  if (c->nccl_red) (void)ncclCommDestroy(c->nccl_red);
+  if (c->stream_red) (void)hipStreamDestroy(c->stream_red);
+  if (c->ev_ra) (void)hipEventDestroy(c->ev_ra);
+  if (c->ev_rb) (void)hipEventDestroy(c->ev_rb);
   if (c->nccl) (void)ncclCommDestroy(c->nccl);
   if (c->stream) (void)hipStreamDestroy(c->stream);
   if (c->ev_a) (void)hipEventDestroy(c->ev_a);

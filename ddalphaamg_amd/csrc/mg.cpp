@@ -548,9 +548,14 @@ void Multigrid<T>::build_coarse_operator(int l) {
         // of the restriction GEMM (64^4: 6 of 48 columns, 30 of 240 fields, 4x the time); instead keep ALL columns and walk
         // the lattice in slabs of whole aggregates -- D P and its restriction are local to an aggregate
         const size_t per_agg = sizeof(T) * 5 * 2 * N * 24 * (size_t)lv.fip.agg_sites;
-        const size_t budget = free_b / 2 - sizeof(T) * 5 * 2 * N * cs;
+        const size_t coarse_b = sizeof(T) * 5 * 2 * N * cs;           // gal_C_: all columns on the coarse lattice
+        DDAMG_REQUIRE(coarse_b + per_agg < free_b, "Galerkin construction: not enough device memory for the coarse columns and one aggregate of fields");
+        // half of the free memory for the two buffers where that leaves room for at least one aggregate, else what is left
+        // after the coarse columns (unsigned arithmetic: never subtract past zero)
+        const size_t budget = free_b / 2 > coarse_b + per_agg ? free_b / 2 - coarse_b : free_b - coarse_b - (free_b - coarse_b) / 8;
         gal_slab_aggs_ = (int)std::min<size_t>((size_t)lv.fip.num_aggs, std::max<size_t>(1, budget / per_agg));
         if (force_slab) gal_slab_aggs_ = std::max(1, std::min(atoi(force_slab), lv.fip.num_aggs));
+        DDAMG_REQUIRE(per_agg * (size_t)gal_slab_aggs_ + coarse_b < free_b, "Galerkin construction: slab workspace does not fit the free device memory");
         gal_batch_ = 2 * N;
         DDAMG_HIP_CHECK(device_alloc(&gal_W_, per_agg * (size_t)gal_slab_aggs_));
         gal_W_elems_ = per_agg / sizeof(T) * (size_t)gal_slab_aggs_;

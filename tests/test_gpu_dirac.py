@@ -196,3 +196,32 @@ def test_two_row_link_storage_and_its_fall_back(monkeypatch):
                 assert np.array_equal(outs[0], outs[1])       # compression refused: the same kernel ran twice
             else:
                 assert relerr(outs[0], outs[1]) < close and not np.array_equal(outs[0], outs[1])
+
+
+def test_two_row_links_are_not_taken_for_an_fp64_operator_that_is_unitary_to_1e_13_only(monkeypatch):
+    """links whose third row deviates from 2 conj(row0 x row1) by 1e-13: the fp64 operator (outer solver, reported residual) must
+    be the caller's matrix, not a reconstruction that differs from it by more than its own 1e-13 parity tolerance -> it keeps
+    the full storage (bit-identical to the run with compression switched off); the fp32 operator still compresses (its own
+    rounding is 6e-8)"""
+    from ddalphaamg_amd import api
+    L = [8, 4, 8, 4]; V = int(np.prod(L))
+    p = api.default_params(); p.num_levels = 1
+    for mu in range(4):
+        p.local_lattice[0][mu] = L[mu]; p.block_lattice[0][mu] = 4
+    p.m0, p.csw = -0.1, 1.0
+    phi = splitmix_uniform(V * 24, 78).reshape(V, 12, 2)
+    U = random_su3(V * 4, 4).reshape(V, 4, 9, 2)
+    U[:, :, 6:9, :] *= 1.0 + 1e-13 * splitmix_uniform(V * 4 * 6, 5).reshape(V, 4, 3, 2)     # third rows off by ~1e-13 relative
+    outs = {}
+    for comp in ("1", "0"):
+        monkeypatch.setenv("DDAMG_LINK_COMPRESSION", comp)
+        ctx = dd.Context(p)
+        ctx.set_gauge(U, anti_pbc=True)
+        for prec in (32, 64):
+            x = ctx.vector(0, prec).upload(phi); y = ctx.vector(0, prec)
+            ctx.dirac_apply(y, x)
+            outs[(comp, prec)] = y.download()
+        ctx.close()
+    assert np.array_equal(outs[("1", 64)], outs[("0", 64)])                    # fp64: full storage either way
+    assert not np.array_equal(outs[("1", 32)], outs[("0", 32)])                # fp32: two-row storage taken
+    assert relerr(outs[("1", 32)], outs[("0", 32)]) < 5e-7
