@@ -3,7 +3,8 @@ import ctypes, os, re
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIBNAME = os.path.join(_HERE, "libddamg_hip.so")
+# DDAMG_HIP_LIBRARY: another build of the same library (A/B measurements of a kernel change on one GPU box); never a fallback
+_LIBNAME = os.environ.get("DDAMG_HIP_LIBRARY") or os.path.join(_HERE, "libddamg_hip.so")
 _HEADER = os.path.join(os.path.dirname(_HERE), "include", "ddamg_hip.h")
 MAX_LEVELS = 4
 

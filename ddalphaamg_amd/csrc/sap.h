@@ -66,7 +66,8 @@ class SapSmoother {
   int* d_all_blocks_ = nullptr;
   // face_in: 0 none, 1 faces_d_, 2 faces_x_;  face_out bit 0: write faces_d_, bit 1: write faces_x_
   // production path: where a visit reads / writes the iterate and the residual (see SapPairArgs)
-  struct PairIO { const T* x_in = nullptr; T* x_out = nullptr; const T* r_in = nullptr; const T* res_src = nullptr; const T* halo_src = nullptr; };
+  struct PairIO { const T* x_in = nullptr; T* x_out = nullptr; const T* r_in = nullptr; const T* res_src = nullptr; const T* halo_src = nullptr;
+                  bool odd_r_store = true; };
   PairIO pio_;
   void launch(int color, int mode_default, unsigned skip_mask, const T* eta, hipStream_t st, int face_out = 1);
 };

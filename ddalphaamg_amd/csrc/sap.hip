@@ -821,6 +821,7 @@ void SapSmoother<T>::launch(int color, int mode, unsigned skip_mask, const T* et
       p.x_in = (const float*)pio_.x_in; p.x_out = (float*)pio_.x_out; p.r_in = (const float*)pio_.r_in; p.res_src = (const float*)pio_.res_src;
       p.latest_out = op_->distributed() ? latest : nullptr;   // only the halo pack reads the full-vector copy
       p.mode = mode < 0 ? MODE_NBOUNDARY : mode; p.skip_mask = skip_mask; p.solve = mode < 0 ? 0 : 1; p.block_iter = block_iter_;
+      p.odd_r_store = pio_.odd_r_store ? 1 : 0;
       p.faces_in = p.mode == MODE_FULLRES ? faces_x_ : faces_d_;
       p.faces_d_out = (face_out & 1) ? faces_d_ : nullptr;
       p.faces_x_out = (face_out & 2) ? faces_x_ : nullptr;
@@ -888,6 +889,7 @@ void SapSmoother<T>::smooth(T* phi, T* Dphi, const T* eta, int cycles, int res, 
   // the caller's phi; every site is visited exactly once per sweep
   const bool direct = pair_ && cycles >= 1 && (schedule_ == RED_BLACK || schedule_ == TWO_COLOR);
   pio_.x_in = x; pio_.x_out = x; pio_.r_in = r; pio_.res_src = x; pio_.halo_src = x;
+  pio_.odd_r_store = true;
   if (direct) {
   } else if (res == NO_RES) {
     vec_copy<T>(r, eta, all, st);
@@ -925,6 +927,9 @@ void SapSmoother<T>::smooth(T* phi, T* Dphi, const T* eta, int cycles, int res, 
         pio_.x_in = k == 0 ? (init_res == RES ? phi : nullptr) : x;
         pio_.x_out = k == cycles - 1 ? phi : x;
         pio_.r_in = (k == 0 && init_res == NO_RES) ? eta : r;
+        // the residual of the odd sites is zero after every visit of a block: the first sweep writes the zeros, the later ones
+        // of this call leave them where they are
+        pio_.odd_r_store = k == 0;
         pio_.res_src = phi;
         // across a process boundary the full residual of the second colour couples to the first colour's UPDATED iterate,
         // which the first launch wrote to x_out

@@ -27,6 +27,12 @@ struct SapPairArgs {
   float4* faces_x_out;           // where the new iterate x leaves its faces (or null)
   const int* blocks; int nblocks;
   int mode; unsigned skip_mask; int solve; int block_iter;
+  // A block visit leaves r = 0 on its odd sites (block_solve_oddeven, src/oddeven_generic.c:1356-1357): written once (the first
+  // visit of a smoother call, odd_r_store = 1) the zeros need not be written again by the later visits of that call -- 48 of the
+  // ~1056 bytes per site of a visit.  (Not READING them either was measured and withdrawn: every form of it -- a branch, a
+  // pointer to a block of zeros, a cached row + select -- took the kernel from 42 to 120-145 spilled registers and from 1020 to
+  // 1245 us per smoother call.)
+  int odd_r_store;
 };
 
 // faces: [num_blocks][8][3][64] float4

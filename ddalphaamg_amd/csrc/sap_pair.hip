@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256 * NB, 2) void sap_pair_kernel(SapPairArgs a) {
   }
   if (active) {
     // x += delta ; r_e = MinRes residual, r_o = 0 ; the faces of delta (and of the new x) for the neighbouring blocks
-    pk_store_site<12>(a.r, V, s, v0);
+    if (!odd || a.odd_r_store) pk_store_site<12>(a.r, V, s, v0);
     if (a.latest_out) pk_store_site<12>(a.latest_out, V, s, v1);
     if (a.faces_d_out && ext) {
       face_emit_dir<0>(v1, U0, ext, a.faces_d_out, blk, pidx[0]);
