@@ -52,6 +52,9 @@ def parse_args():
     ap.add_argument("--self-exchange", default=None,
                     help="single GPU only, e.g. -1,-1,-1,1: run the fine operator through the multi-GPU machinery with the process "
                          "as its own neighbour in the directions marked -1 (RCCL transport); not a reported configuration")
+    ap.add_argument("--rehearse", type=int, default=8, choices=[0, 2, 4, 8],
+                    help="N = 1 only: also run the PER-GPU problem of the N-GPU strong-scaling decomposition on this one GPU, every split "
+                         "direction through the RCCL self-exchange (0: skip); printed as `rehearsal` next to `strong_scaling`")
     ap.add_argument("--leg-timeout", type=float, default=900.0, help="watchdog for the solve legs on N > 1 (seconds)")
     return ap.parse_args()
 
@@ -377,14 +380,17 @@ def run_solve(q, G, grid, coords, world, rank, transport, group):
     import ddalphaamg_amd as dd
     for mu in range(4):
         q.process_grid[mu] = grid[mu]; q.process_coords[mu] = coords[mu]
-    V = int(np.prod([G[mu] // grid[mu] for mu in range(4)]))
+    V = int(np.prod([G[mu] // max(1, grid[mu]) for mu in range(4)]))
     t0 = time.perf_counter()
-    U = synth.synth_gauge(G, GAUGE_EPS, GAUGE_SEED, grid, coords)
+    U = synth.synth_gauge(G, GAUGE_EPS, GAUGE_SEED, [max(1, g) for g in grid], coords)
     t_gauge = time.perf_counter() - t0
     ctx = dd.Context(q)
     if world > 1:
         from ddalphaamg_amd import dist as ddist
         ddist.attach_host(ctx, group)
+    elif any(g == -1 for g in grid):
+        from ddalphaamg_amd import api as _api
+        ctx.comm_init_rccl(_api.rccl_unique_id())     # one GPU, the process its own neighbour: everything through RCCL
     ctx.set_gauge(U, anti_pbc=True)     # global clover term: on a process grid the neighbours' links travel over the host transport
     del U
     if world > 1 and transport == "rccl":
@@ -396,9 +402,22 @@ def run_solve(q, G, grid, coords, world, rank, transport, group):
     t0 = time.perf_counter(); it, cit, rr = ctx.solve_vec(xv, bv, 1e-10); t_solve = time.perf_counter() - t0
     res = {"seconds_per_solve": t_solve, "setup_seconds": t_setup, "iterations": it, "coarse_iterations": cit, "true_relres": rr,
            "gauge_generation_seconds": t_gauge}
-    if world == 1:
+    if world == 1 and not any(g == -1 for g in grid):
         x, it2, _, _ = ctx.solve(b, 1e-10)
         t0 = time.perf_counter(); ctx.solve(b, 1e-10, out=x); res["seconds_per_solve_host_vectors"] = time.perf_counter() - t0
+    if world == 1:
+        # seconds per GMRES iteration of the coarsest-level solve (for the rehearsal's correction: on N GPUs the gathered
+        # coarsest level is the GLOBAL one, the rehearsal's is 1/N of it)
+        try:
+            lc = q.num_levels - 1
+            n = ctx.ndof(lc); Vc = ctx.volume(lc)
+            bc = np.zeros((Vc, n, 2)); bc[..., 0] = 1.0
+            bcv = ctx.vector(lc, 32).upload(bc); xcv = ctx.vector(lc, 32)
+            ctx.coarse_solve(xcv, bcv); ctx.sync()
+            t0 = time.perf_counter(); cits = sum(ctx.coarse_solve(xcv, bcv) for _ in range(5)); ctx.sync()
+            res["coarsest"] = {"sites": Vc, "dof_per_site": n, "seconds_per_iteration": (time.perf_counter() - t0) / max(1, cits)}
+        except Exception as e:
+            res["coarsest"] = {"error": str(e)[:200]}
     ctx.close()
     return res
 
@@ -654,6 +673,49 @@ def main():
             out["strong_scaling"] = {"error": str(e)[:300]}
         if dog:
             dog.cancel()
+    if world == 1 and args.rehearse > 1 and not args.no_strong and not args.self_exchange:
+        # ---- rehearsal of the N-GPU point of the strong-scaling curve on ONE GPU (no multi-GPU node is available to the build):
+        # the per-GPU problem of the decomposition -- local lattice G / grid_N, the same three-level method, the coarsest level
+        # gathered -- with the process as its own neighbour in every split direction, so that every boundary coupling runs
+        # pack -> ncclSend/ncclRecv -> halo kernels and every reduction ncclAllReduce, as on N GPUs.  What it cannot show: xGMI
+        # instead of on-device copies, and the global coarsest level (gathered on N GPUs it is N times the rehearsal's; the
+        # correction below uses the measured seconds per coarsest GMRES iteration at both sizes).
+        try:
+            N = args.rehearse
+            grid_n = ddist.process_grid_for(N)
+            Lloc = [G[mu] // grid_n[mu] for mu in range(4)]
+            q = amg_params(api, Lloc, 3, local_rank)
+            q.restart, q.max_restart = 10, 100
+            q.gather_coarsest = 1
+            sx = [-1 if grid_n[mu] > 1 else 1 for mu in range(4)]
+            r8 = run_solve(q, Lloc, sx, [0, 0, 0, 0], 1, 0, "rccl", None)
+            q1 = amg_params(api, Lloc, 3, local_rank)
+            q1.restart, q1.max_restart = 10, 100
+            r1 = run_solve(q1, Lloc, [1, 1, 1, 1], [0, 0, 0, 0], 1, 0, "rccl", None)     # the same lattice, plain periodic wrap
+            reh = {"n_gpus_rehearsed": N, "process_grid": grid_n, "local_lattice": Lloc, "self_exchange": sx, "transport": "rccl (self-exchange on one device)",
+                   "seconds_per_solve_per_gpu": r8["seconds_per_solve"], "setup_seconds": r8["setup_seconds"], "iterations": r8["iterations"],
+                   "coarse_iterations": r8["coarse_iterations"], "true_relres": r8["true_relres"],
+                   "same_lattice_without_the_machinery": {"seconds_per_solve": r1["seconds_per_solve"], "iterations": r1["iterations"],
+                                                          "setup_seconds": r1["setup_seconds"]},
+                   "cost_of_the_machinery": r8["seconds_per_solve"] / r1["seconds_per_solve"]}
+            ss = out.get("strong_scaling", {})
+            corr = 0.0
+            c_n1, c_r = ss.get("coarsest", {}), r8.get("coarsest", {})
+            if "seconds_per_iteration" in c_n1 and "seconds_per_iteration" in c_r:
+                corr = r8["coarse_iterations"] * max(0.0, c_n1["seconds_per_iteration"] - c_r["seconds_per_iteration"])
+                reh["coarsest_level"] = {"rehearsed_sites": c_r["sites"], "gathered_sites_on_n_gpus": c_n1["sites"],
+                                         "seconds_per_iteration_rehearsed": c_r["seconds_per_iteration"],
+                                         "seconds_per_iteration_gathered": c_n1["seconds_per_iteration"], "correction_seconds": corr}
+            reh["predicted_seconds_per_solve_per_gpu"] = r8["seconds_per_solve"] + corr
+            if "seconds_per_solve" in ss:
+                reh["n1_seconds_per_solve"] = ss["seconds_per_solve"]; reh["n1_iterations"] = ss["iterations"]
+                reh["predicted_speedup_vs_n1"] = ss["seconds_per_solve"] / reh["predicted_seconds_per_solve_per_gpu"]
+                # per outer iteration, in case the smaller torus of the rehearsal needs another count than the 64^4 lattice
+                reh["predicted_speedup_vs_n1_per_iteration"] = (ss["seconds_per_solve"] / ss["iterations"]) / (reh["predicted_seconds_per_solve_per_gpu"] / r8["iterations"])
+            reh["not_covered"] = "xGMI latency and bandwidth (messages are on-device copies here); load imbalance between ranks"
+            out["rehearsal"] = reh
+        except Exception as e:
+            out["rehearsal"] = {"error": str(e)[:300]}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

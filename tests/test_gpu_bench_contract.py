@@ -86,3 +86,21 @@ def test_failed_or_hung_rank_gives_nonzero_exit_and_keeps_the_headline(fault, ex
     d = last_json_line(r.stdout)
     check_common(d, 2, 5, 2, 16 ** 4)
     assert "error" in d["strong_scaling"]
+
+
+def test_rehearsal_of_the_eight_gpu_point_on_one_gpu():
+    """`--rehearse 8` (the default at N = 1): the per-GPU problem of the 8-GPU decomposition -- here of a 32^4 lattice, local
+    16x16x16x32 -- with three split directions through the RCCL self-exchange and the coarsest level gathered; the `rehearsal`
+    object carries the predicted seconds per solve per GPU next to the N = 1 time of the same run"""
+    r = subprocess.run([sys.executable, BENCH, "--steps", "5", "--warmup", "2", "--no-solve", "--no-cpu-baseline", "--rehearse", "8",
+                        "--strong-lattice", "32", "32", "32", "32"], capture_output=True, text=True, timeout=900, cwd=REPO)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = last_json_line(r.stdout)
+    s, h = d["strong_scaling"], d["rehearsal"]
+    assert "error" not in h, h
+    assert h["n_gpus_rehearsed"] == 8 and h["process_grid"] == [2, 2, 2, 1] and h["local_lattice"] == [16, 16, 16, 32]
+    assert h["self_exchange"] == [-1, -1, -1, 1] and h["true_relres"] < 1e-10
+    assert abs(h["iterations"] - h["same_lattice_without_the_machinery"]["iterations"]) <= 1      # the machinery changes no result
+    assert h["predicted_seconds_per_solve_per_gpu"] >= h["seconds_per_solve_per_gpu"] > 0
+    assert abs(h["predicted_speedup_vs_n1"] - s["seconds_per_solve"] / h["predicted_seconds_per_solve_per_gpu"]) < 1e-9
+    assert h["coarsest_level"]["gathered_sites_on_n_gpus"] == 8 * h["coarsest_level"]["rehearsed_sites"]
