@@ -110,6 +110,7 @@ def load_library():
         "ddamg_hip_interpolate": [vp, vp, vp, ctypes.c_int],
         "ddamg_hip_coarse_apply": [vp, vp, vp],
         "ddamg_hip_coarse_solve": [vp, vp, vp, ctypes.POINTER(ctypes.c_int)],
+        "ddamg_hip_coarse_solve_many": [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int)],
         "ddamg_hip_vcycle": [vp, vp, vp],
         "ddamg_hip_solve": [vp, dp, dp, ctypes.c_double, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), dp],
         "ddamg_hip_solve_vec": [vp, vp, vp, ctypes.c_double, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), dp],
@@ -394,6 +395,15 @@ class Context:
         it = ctypes.c_int(0)
         _check(self._lib.ddamg_hip_coarse_solve(self._h, x._h, b._h, ctypes.byref(it)))
         return it.value
+
+    def coarse_solve_many(self, xs, bs):
+        """the coarsest-level solve for up to 32 right-hand sides in lockstep (matrix-core coarse operator); returns the list of
+        iteration counts (-1: the column needs the one-at-a-time solver)"""
+        n = len(bs)
+        VP = ctypes.c_void_p * n
+        its = (ctypes.c_int * n)()
+        _check(self._lib.ddamg_hip_coarse_solve_many(self._h, n, VP(*[v._h for v in xs]), VP(*[v._h for v in bs]), its))
+        return list(its)
 
     def vcycle(self, phi, eta):
         _check(self._lib.ddamg_hip_vcycle(self._h, phi._h, eta._h))

@@ -1,0 +1,366 @@
+// coarse_lockstep.hip -- see coarse_lockstep.h
+#include "coarse_lockstep.h"
+#include <complex>
+#include <cmath>
+
+namespace ddamg {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int NC = LOCKSTEP_COLS;
+constexpr int DOT_BLOCKS = 128, DOT_CHUNK = 8;
+
+namespace {
+
+__device__ __forceinline__ size_t tile_at(int nt, int i, int j) { return ((size_t)((i >> 3) * nt + (j >> 3)) * 64 + (i & 7) * 8 + (j & 7)); }
+
+// acc += sign * A B,  A = the n x n coupling matrix M (tile layout of coarse_op.h) or G5 M^H G5 (DAG: the backward coupling
+// from the neighbour's forward matrix), B = the batch of one site ([k][c], NC columns).  One wavefront: 16 columns
+// (col0 .. col0+15) and NRT row tiles of 16; a complex product is four real v_mfma_f32_16x16x4_f32.
+template <int NRT, bool DAG>
+__device__ __forceinline__ void mfma_product(const float2* __restrict__ M, int nt, int n, const float2* __restrict__ By, int col0, float sign,
+                                             f32x4 (&accR)[NRT], f32x4 (&accI)[NRT]) {
+  const int l = threadIdx.x & 63, r16 = l & 15, kq = l >> 4;
+  const int half = n >> 1;
+  for (int ks = 0; ks < n; ks += 4) {
+    const int k = ks + kq;                       // k < n because n % 4 == 0
+    const float2 b = By[(size_t)k * NC + col0 + r16];
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) {
+      const int i = rt * 16 + r16;
+      float2 a = make_float2(0.f, 0.f);
+      if (i < n) {
+        if constexpr (!DAG) a = M[tile_at(nt, i, k)];
+        else {
+          const float2 m = M[tile_at(nt, k, i)];
+          const float s = ((i >= half) != (k >= half)) ? -1.f : 1.f;   // G5 M^H G5
+          a = make_float2(s * m.x, -s * m.y);
+        }
+      }
+      a.x *= sign; a.y *= sign;
+      accR[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, accR[rt], 0, 0, 0);
+      accR[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-a.y, b.y, accR[rt], 0, 0, 0);
+      accI[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.y, accI[rt], 0, 0, 0);
+      accI[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.x, accI[rt], 0, 0, 0);
+    }
+  }
+}
+
+template <int NRT>
+__device__ __forceinline__ void store_rows(float2* __restrict__ out, int n, int col0, const f32x4 (&accR)[NRT], const f32x4 (&accI)[NRT], bool accumulate) {
+  const int l = threadIdx.x & 63, r16 = l & 15, kq = l >> 4;
+#pragma unroll
+  for (int rt = 0; rt < NRT; rt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int i = rt * 16 + 4 * kq + r;      // result row held in register r
+      if (i < n) {
+        float2* p = out + (size_t)i * NC + col0 + r16;
+        float2 v = make_float2(accR[rt][r], accI[rt][r]);
+        if (accumulate) { const float2 o = *p; v.x += o.x; v.y += o.y; }
+        *p = v;
+      }
+    }
+}
+
+// out(x) = M0(x) in(x)  or  M0(x)^-1 in(x)  on the sites s0 + blockIdx.x   (coarse_diag_ee / coarse_diag_oo_inv, all columns)
+template <int NRT>
+__global__ __launch_bounds__(128) void ls_self_kernel(float2* __restrict__ out, const float2* __restrict__ in, CoarseOpDev<float> op, int s0, int inverse) {
+  const int x = s0 + blockIdx.x, n = op.n;
+  const int col0 = (threadIdx.x >> 6) * 16;
+  const float2* M = inverse ? reinterpret_cast<const float2*>(op.Minv) + (size_t)x * op.msize
+                            : reinterpret_cast<const float2*>(op.M) + (size_t)x * 5 * op.msize;
+  f32x4 aR[NRT], aI[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; rt++) { aR[rt] = f32x4{0, 0, 0, 0}; aI[rt] = f32x4{0, 0, 0, 0}; }
+  mfma_product<NRT, false>(M, op.nt, n, in + (size_t)x * n * NC, col0, 1.f, aR, aI);
+  store_rows<NRT>(out + (size_t)x * n * NC, n, col0, aR, aI, false);
+}
+
+// out(x) (+)= sign * sum_mu [ U_mu(x) in(x+mu) + G5 U_mu(x-mu)^H G5 in(x-mu) ]   (coarse_hopping_term, all columns)
+template <int NRT>
+__global__ __launch_bounds__(128) void ls_hop_kernel(float2* __restrict__ out, const float2* __restrict__ in, CoarseOpDev<float> op, int s0, float sign,
+                                                     int accumulate) {
+  const int x = s0 + blockIdx.x, n = op.n, nt = op.nt;
+  const int col0 = (threadIdx.x >> 6) * 16;
+  const float2* Mall = reinterpret_cast<const float2*>(op.M);
+  f32x4 aR[NRT], aI[NRT];
+#pragma unroll
+  for (int rt = 0; rt < NRT; rt++) { aR[rt] = f32x4{0, 0, 0, 0}; aI[rt] = f32x4{0, 0, 0, 0}; }
+  for (int mu = 0; mu < 4; mu++) {
+    const int yf = op.nb[(size_t)mu * op.V + x], yb = op.nb[(size_t)(4 + mu) * op.V + x];
+    mfma_product<NRT, false>(Mall + ((size_t)x * 5 + 1 + mu) * op.msize, nt, n, in + (size_t)yf * n * NC, col0, sign, aR, aI);
+    mfma_product<NRT, true>(Mall + ((size_t)yb * 5 + 1 + mu) * op.msize, nt, n, in + (size_t)yb * n * NC, col0, sign, aR, aI);
+  }
+  store_rows<NRT>(out + (size_t)x * n * NC, n, col0, aR, aI, accumulate != 0);
+}
+
+// ordinary coarse vectors (AoS [x][k], column c at src + c*sstride) <-> the batch layout [x][k][c]
+__global__ void ls_gather_kernel(float2* __restrict__ Wb, const float* __restrict__ src, size_t sstride, int ncols, size_t rows) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= rows * NC) return;
+  const int c = (int)(e % NC);
+  const size_t row = e / NC;
+  float2 v = make_float2(0.f, 0.f);
+  if (c < ncols) { const float* p = src + (size_t)c * sstride + row * 2; v = make_float2(p[0], p[1]); }
+  Wb[e] = v;
+}
+__global__ void ls_scatter_kernel(float* __restrict__ dst, size_t dstride, const float2* __restrict__ Wb, int ncols, size_t rows) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // (c, row): coalesced on the destination
+  if (e >= rows * ncols) return;
+  const size_t row = e % rows;
+  const int c = (int)(e / rows);
+  const float2 v = Wb[row * NC + c];
+  float* p = dst + (size_t)c * dstride + row * 2;
+  p[0] = v.x; p[1] = v.y;
+}
+
+// partial[blk][i][c] = sum over the block's rows of conj(V_i[row][c]) w[row][c], i < m <= DOT_CHUNK; fp64 accumulation,
+// fixed order (deterministic)
+__global__ __launch_bounds__(256) void ls_dot_kernel(double* __restrict__ partial, const float2* __restrict__ basis, size_t vstride, int m,
+                                                     const float2* __restrict__ w, size_t rows) {
+  __shared__ double sh[2][DOT_CHUNK][8][NC];
+  const int c = threadIdx.x & 31, r = threadIdx.x >> 5;
+  const size_t rpb = (rows + gridDim.x - 1) / gridDim.x;
+  const size_t r0 = (size_t)blockIdx.x * rpb, r1 = r0 + rpb < rows ? r0 + rpb : rows;
+  double ar[DOT_CHUNK], ai[DOT_CHUNK];
+#pragma unroll
+  for (int i = 0; i < DOT_CHUNK; i++) { ar[i] = 0; ai[i] = 0; }
+  for (size_t row = r0 + r; row < r1; row += 8) {
+    const float2 wv = w[row * NC + c];
+#pragma unroll
+    for (int i = 0; i < DOT_CHUNK; i++)
+      if (i < m) {
+        const float2 v = basis[(size_t)i * vstride + row * NC + c];
+        ar[i] += (double)v.x * wv.x + (double)v.y * wv.y;
+        ai[i] += (double)v.x * wv.y - (double)v.y * wv.x;
+      }
+  }
+#pragma unroll
+  for (int i = 0; i < DOT_CHUNK; i++) { sh[0][i][r][c] = ar[i]; sh[1][i][r][c] = ai[i]; }
+  __syncthreads();
+  // thread (i, c): i = threadIdx.x / 32 < DOT_CHUNK
+  const int i = threadIdx.x >> 5;
+  if (i < m) {
+    double sr = 0, si = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) { sr += sh[0][i][q][c]; si += sh[1][i][q][c]; }
+    double* p = partial + (((size_t)blockIdx.x * DOT_CHUNK + i) * NC + c) * 2;
+    p[0] = sr; p[1] = si;
+  }
+}
+__global__ void ls_dot_final_kernel(double* __restrict__ out, const double* __restrict__ partial, int nblocks, int m) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;     // (i, c)
+  if (t >= m * NC) return;
+  const int i = t / NC, c = t % NC;
+  double sr = 0, si = 0;
+  for (int b = 0; b < nblocks; b++) {
+    const double* p = partial + (((size_t)b * DOT_CHUNK + i) * NC + c) * 2;
+    sr += p[0]; si += p[1];
+  }
+  out[(size_t)t * 2] = sr; out[(size_t)t * 2 + 1] = si;
+}
+// w[row][c] += sign * sum_{i<m} coef[i][c] V_i[row][c]
+__global__ void ls_axpy_kernel(float2* __restrict__ w, const float2* __restrict__ basis, size_t vstride, int m, const double* __restrict__ coef, double sign,
+                               size_t elems) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= elems) return;
+  const int c = (int)(e % NC);
+  double sr = 0, si = 0;
+  for (int i = 0; i < m; i++) {
+    const float2 v = basis[(size_t)i * vstride + e];
+    const double cr = coef[((size_t)i * NC + c) * 2], ci = coef[((size_t)i * NC + c) * 2 + 1];
+    sr += cr * v.x - ci * v.y;
+    si += cr * v.y + ci * v.x;
+  }
+  float2 o = w[e];
+  o.x = (float)((double)o.x + sign * sr); o.y = (float)((double)o.y + sign * si);
+  w[e] = o;
+}
+// out[row][c] = w[row][c] / sqrt(n2[c])   (n2: complex pairs, real part = ||w_c||^2; a column of norm <= 1e-15 is copied, as
+// vec_scale_inv_dev does, cf. src/linsolve_generic.c:889)
+__global__ void ls_scale_inv_kernel(float2* __restrict__ out, const float2* __restrict__ w, const double* __restrict__ n2, size_t elems) {
+  const size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= elems) return;
+  const double nrm = sqrt(fmax(n2[(e % NC) * 2], 0.0));
+  const float f = nrm > 1e-15 ? (float)(1.0 / nrm) : 1.f;
+  const float2 v = w[e];
+  out[e] = make_float2(v.x * f, v.y * f);
+}
+
+template <typename K, typename... A>
+void launch_nrt(int nrt, K k1, K k2, K k3, K k4, dim3 grid, dim3 block, hipStream_t st, A... a) {
+  switch (nrt) {
+    case 1: hipLaunchKernelGGL(k1, grid, block, 0, st, a...); break;
+    case 2: hipLaunchKernelGGL(k2, grid, block, 0, st, a...); break;
+    case 3: hipLaunchKernelGGL(k3, grid, block, 0, st, a...); break;
+    default: hipLaunchKernelGGL(k4, grid, block, 0, st, a...); break;
+  }
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
+}  // namespace
+
+bool LockstepCoarseSolver::available(const CoarseOp<float>& cop, int ncols, bool odd_even) {
+  static const bool off = getenv("DDAMG_BOOTSTRAP_NO_LOCKSTEP") != nullptr;
+  return !off && odd_even && !cop.distributed() && ncols >= 2 && ncols <= NC && cop.n() <= 64 && cop.n() % 4 == 0 && cop.V() % 2 == 0;
+}
+
+LockstepCoarseSolver::~LockstepCoarseSolver() {
+  for (int i = 0; i < 4; i++) if (W_[i]) (void)hipFree(W_[i]);
+  if (basis_) (void)hipFree(basis_);
+  if (w_) (void)hipFree(w_);
+  if (d_partial_) (void)hipFree(d_partial_);
+  if (d_h_) (void)hipFree(d_h_);
+  if (d_coef_) (void)hipFree(d_coef_);
+  if (h_h_) (void)hipHostFree(h_h_);
+  if (h_coef_) (void)hipHostFree(h_coef_);
+}
+
+void LockstepCoarseSolver::init(const CoarseOp<float>* cop, int max_steps, double tol, hipStream_t st) {
+  cop_ = cop; V_ = cop->V(); Ve_ = V_ / 2; n_ = cop->n(); max_steps_ = max_steps; tol_ = tol; st_ = st;
+  for (int i = 0; i < 4; i++) DDAMG_HIP_CHECK(device_alloc(&W_[i], sizeof(float2) * batch_elems()));
+  DDAMG_HIP_CHECK(device_alloc(&basis_, sizeof(float2) * even_elems() * (size_t)(max_steps_ + 1)));
+  DDAMG_HIP_CHECK(device_alloc(&w_, sizeof(float2) * even_elems()));
+  DDAMG_HIP_CHECK(device_alloc(&d_partial_, sizeof(double) * 2 * DOT_BLOCKS * DOT_CHUNK * NC));
+  DDAMG_HIP_CHECK(device_alloc(&d_h_, sizeof(double) * 2 * (max_steps_ + 2) * NC));
+  DDAMG_HIP_CHECK(device_alloc(&d_coef_, sizeof(double) * 2 * (max_steps_ + 2) * NC));
+  DDAMG_HIP_CHECK(hipHostMalloc(&h_h_, sizeof(double) * 2 * (max_steps_ + 2) * NC));
+  DDAMG_HIP_CHECK(hipHostMalloc(&h_coef_, sizeof(double) * 2 * (max_steps_ + 2) * NC));
+}
+
+void LockstepCoarseSolver::gather(float2* Wb, const float* src, size_t sstride, int ncols) {
+  const size_t rows = (size_t)V_ * n_, tot = rows * NC;
+  hipLaunchKernelGGL(ls_gather_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st_, Wb, src, sstride, ncols, rows);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+void LockstepCoarseSolver::scatter(float* dst, size_t dstride, const float2* Wb, int ncols) {
+  const size_t rows = (size_t)V_ * n_, tot = rows * ncols;
+  hipLaunchKernelGGL(ls_scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st_, dst, dstride, Wb, ncols, rows);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+void LockstepCoarseSolver::self(float2* out, const float2* in, int s0, int s1, bool inverse) {
+  launch_nrt((n_ + 15) / 16, ls_self_kernel<1>, ls_self_kernel<2>, ls_self_kernel<3>, ls_self_kernel<4>, dim3(s1 - s0), dim3(128), st_, out, in, cop_->dev(), s0,
+             inverse ? 1 : 0);
+}
+void LockstepCoarseSolver::hop(float2* out, const float2* in, int s0, int s1, float sign, bool accumulate) {
+  launch_nrt((n_ + 15) / 16, ls_hop_kernel<1>, ls_hop_kernel<2>, ls_hop_kernel<3>, ls_hop_kernel<4>, dim3(s1 - s0), dim3(128), st_, out, in, cop_->dev(), s0, sign,
+             accumulate ? 1 : 0);
+}
+// coarse_apply_schur_complement_PRECISION (src/coarse_oddeven_generic.c:1162-1189) for all columns
+void LockstepCoarseSolver::schur(float2* out, const float2* in) {
+  self(out, in, 0, Ve_, false);                // out_e = D_ee in_e
+  hop(W_[2], in, Ve_, V_, -1.f, false);        // t0_o = -H_oe in_e   (= D_oe in_e)
+  self(W_[3], W_[2], Ve_, V_, true);           // t1_o = D_oo^-1 t0_o
+  hop(out, W_[3], 0, Ve_, +1.f, true);         // out_e += H_eo t1_o  (= -D_eo t1_o)
+}
+void LockstepCoarseSolver::dots(const float2* basis, int m, const float2* w, double* d_out) {
+  const size_t rows = (size_t)Ve_ * n_;
+  for (int i0 = 0; i0 < m; i0 += DOT_CHUNK) {
+    const int mc = std::min(DOT_CHUNK, m - i0);
+    hipLaunchKernelGGL(ls_dot_kernel, dim3(DOT_BLOCKS), dim3(256), 0, st_, d_partial_, basis + (size_t)i0 * even_elems(), even_elems(), mc, w, rows);
+    hipLaunchKernelGGL(ls_dot_final_kernel, dim3((mc * NC + 255) / 256), dim3(256), 0, st_, d_out + (size_t)i0 * NC * 2, d_partial_, DOT_BLOCKS, mc);
+  }
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+void LockstepCoarseSolver::axpy(float2* w, const float2* basis, int m, const double* d_coef, double sign) {
+  const size_t el = even_elems();
+  hipLaunchKernelGGL(ls_axpy_kernel, dim3((unsigned)((el + 255) / 256)), dim3(256), 0, st_, w, basis, el, m, d_coef, sign, el);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+void LockstepCoarseSolver::scale_inv(float2* out, const float2* w, const double* d_norm) {
+  const size_t el = even_elems();
+  hipLaunchKernelGGL(ls_scale_inv_kernel, dim3((unsigned)((el + 255) / 256)), dim3(256), 0, st_, out, w, d_norm, el);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
+int LockstepCoarseSolver::solve(float* X, size_t xstride, const float* B, size_t bstride, int ncols, int* iters) {
+  typedef std::complex<double> cd;
+  DDAMG_REQUIRE(ready() && ncols <= NC, "lockstep coarse solver not set up");
+  float2 *x = W_[0], *b = W_[1];
+  const size_t el = even_elems();
+  gather(b, B, bstride, ncols);
+  DDAMG_HIP_CHECK(hipMemsetAsync(x, 0, sizeof(float2) * batch_elems(), st_));
+  // coarse_solve_odd_even_PRECISION (src/coarse_oddeven_generic.c:1139-1159): right-hand side of the even-site system
+  self(x, b, Ve_, V_, true);                   // x_o = D_oo^-1 b_o
+  hop(b, x, 0, Ve_, +1.f, true);               // b_e <- b_e - D_eo x_o
+  // ---- GMRES on S x_e = b_e, initial guess zero: every column its own recurrence (Gmres<T>::solve, krylov.h) ----
+  const int ld = max_steps_ + 2;
+  struct Col { std::vector<cd> H, gamma, c, s; double norm_r0 = 0; int j = -1, iter = 0; bool done = false, ok = false; };
+  std::vector<Col> cols(ncols);
+  for (auto& q : cols) { q.H.assign((size_t)(max_steps_ + 1) * ld, cd(0)); q.gamma.assign(ld, cd(0)); q.c.assign(ld, cd(0)); q.s.assign(ld, cd(0)); }
+  dots(b, 1, b, d_h_);
+  DDAMG_HIP_CHECK(hipMemcpyAsync(h_h_, d_h_, sizeof(double) * 2 * NC, hipMemcpyDeviceToHost, st_));
+  scale_inv(basis_, b, d_h_);                  // V_0 = r / ||r||
+  DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
+  int open = 0;
+  for (int c = 0; c < ncols; c++) {
+    cols[c].norm_r0 = std::sqrt(std::max(h_h_[2 * c], 0.0));
+    cols[c].gamma[0] = cols[c].norm_r0;
+    if (!(cols[c].norm_r0 > 0)) { cols[c].done = true; cols[c].ok = true; }   // zero right-hand side: x = 0
+    else open++;
+  }
+  steps_taken = 0;
+  for (int j = 0; j < max_steps_ && open > 0; j++) {
+    steps_taken++;
+    const float2* Vj = basis_ + (size_t)j * el;
+    schur(w_, Vj);
+    dots(basis_, j + 1, w_, d_h_);                               // classical Gram-Schmidt (arnoldi_step_PRECISION :810-893)
+    axpy(w_, basis_, j + 1, d_h_, -1.0);
+    dots(w_, 1, w_, d_h_ + (size_t)(j + 1) * NC * 2);            // ... and the separate norm
+    DDAMG_HIP_CHECK(hipMemcpyAsync(h_h_, d_h_, sizeof(double) * 2 * NC * (j + 2), hipMemcpyDeviceToHost, st_));
+    scale_inv(basis_ + (size_t)(j + 1) * el, w_, d_h_ + (size_t)(j + 1) * NC * 2);
+    DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
+    for (int c = 0; c < ncols; c++) {
+      Col& q = cols[c];
+      if (q.done) continue;
+      q.j = j; q.iter++;
+      cd* Hj = &q.H[(size_t)j * ld];
+      for (int i = 0; i <= j; i++) Hj[i] = cd(h_h_[((size_t)i * NC + c) * 2], h_h_[((size_t)i * NC + c) * 2 + 1]);
+      Hj[j + 1] = std::sqrt(std::max(h_h_[((size_t)(j + 1) * NC + c) * 2], 0.0));
+      if (std::abs(Hj[j + 1]) > tol_ / 10) {
+        // qr_update_PRECISION (src/linsolve_generic.c:898-940)
+        for (int i = 0; i < j; i++) {
+          const cd beta = (-q.s[i]) * Hj[i] + q.c[i] * Hj[i + 1];
+          Hj[i] = std::conj(q.c[i]) * Hj[i] + std::conj(q.s[i]) * Hj[i + 1];
+          Hj[i + 1] = beta;
+        }
+        const cd beta = std::sqrt(std::norm(Hj[j]) + std::norm(Hj[j + 1]));
+        q.s[j] = Hj[j + 1] / beta; q.c[j] = Hj[j] / beta;
+        q.gamma[j + 1] = (-q.s[j]) * q.gamma[j]; q.gamma[j] = std::conj(q.c[j]) * q.gamma[j];
+        Hj[j] = beta; Hj[j + 1] = 0;
+        const double rel = std::abs(q.gamma[j + 1]) / q.norm_r0;
+        if (rel < tol_ || rel > 1e5) { q.done = true; q.ok = true; open--; }
+      } else {
+        q.done = true; q.ok = true; open--;    // lucky breakdown
+      }
+    }
+  }
+  // compute_solution_PRECISION (:943-982) per column; a column that is still open gets no update here (iters = -1)
+  const int m = steps_taken;
+  std::fill(h_coef_, h_coef_ + (size_t)2 * NC * std::max(m, 1), 0.0);
+  int total = 0;
+  for (int c = 0; c < ncols; c++) {
+    Col& q = cols[c];
+    iters[c] = (q.done && q.ok) ? q.iter : -1;
+    if (iters[c] < 0 || q.j < 0) continue;
+    total += q.iter;
+    std::vector<cd> y(q.j + 1);
+    for (int i = q.j; i >= 0; i--) {
+      y[i] = q.gamma[i];
+      for (int k = i + 1; k <= q.j; k++) y[i] -= q.H[(size_t)k * ld + i] * y[k];
+      y[i] /= q.H[(size_t)i * ld + i];
+    }
+    for (int i = 0; i <= q.j; i++) { h_coef_[((size_t)i * NC + c) * 2] = y[i].real(); h_coef_[((size_t)i * NC + c) * 2 + 1] = y[i].imag(); }
+  }
+  if (m > 0) {
+    DDAMG_HIP_CHECK(hipMemcpyAsync(d_coef_, h_coef_, sizeof(double) * 2 * NC * m, hipMemcpyHostToDevice, st_));
+    axpy(x, basis_, m, d_coef_, +1.0);         // x_e = sum_i y_i V_i  (x_e was zero)
+  }
+  hop(b, x, Ve_, V_, +1.f, true);              // b_o <- b_o - D_oe x_e
+  self(x, b, Ve_, V_, true);                   // x_o = D_oo^-1 b_o
+  scatter(X, xstride, x, ncols);
+  DDAMG_HIP_CHECK(hipStreamSynchronize(st_));  // h_coef_ / h_h_ are reused by the next call
+  return total;
+}
+
+}  // namespace ddamg

@@ -405,6 +405,18 @@ int Multigrid<T>::coarse_solve() {
   return it;
 }
 
+template <typename T>
+bool Multigrid<T>::coarse_solve_many(T* X, size_t xstride, const T* B, size_t bstride, int ncols, int* iters) {
+  if constexpr (sizeof(T) == 4) {
+    MGLevel<T>& lv = *lv_.back();
+    if (gath_.on || !LockstepCoarseSolver::available(lv.cop, ncols, par_.odd_even != 0)) return false;
+    if (!lockstep_.ready()) lockstep_.init(&lv.cop, std::min(lv.gm.restart_length, 24), lv.gm.tol, st_);
+    coarse_iter_count += lockstep_.solve(X, xstride, B, bstride, ncols, iters);
+    return true;
+  }
+  return false;
+}
+
 // ---- V-cycle / K-cycle (post-smoothing only) --------------------------------------------------------
 template <typename T>
 void Multigrid<T>::vcycle(int l, T* phi, T* Dphi, const T* eta, int res) {
@@ -687,7 +699,23 @@ bool Multigrid<T>::bootstrap_vcycles_batched() {
   T* Cx = gal_C_ + (size_t)N * cs;   // N coarse solutions
   const View all = whole(lv.nel), call = whole(nx.nel);
   lv.fip.restrict_batch(Cb, cs, tv_base(0), tv_stride(0), N, st_);
-  for (int i = 0; i < N; i++) {
+  // two levels: the N coarsest-level solves as N GMRES recurrences in lockstep, the coarse operator on the matrix cores
+  // (coarse_lockstep.h); a column that needs more steps than the lockstep basis holds falls back to the one-at-a-time solver
+  bool in_lockstep = false;
+  if constexpr (sizeof(T) == 4) {
+    if (nx.coarsest && !gath_.on && LockstepCoarseSolver::available(nx.cop, N, par_.odd_even != 0)) {
+      std::vector<int> its(N);
+      coarse_solve_many(Cx, cs, Cb, cs, N, its.data());
+      for (int i = 0; i < N; i++)
+        if (its[i] < 0) {
+          vec_copy<T>(nx.gm.b, Cb + (size_t)i * cs, call, st_);
+          coarse_solve();
+          vec_copy<T>(Cx + (size_t)i * cs, nx.gm.x, call, st_);
+        }
+      in_lockstep = true;
+    }
+  }
+  for (int i = 0; i < N && !in_lockstep; i++) {
     vec_copy<T>(nx.gm.b, Cb + (size_t)i * cs, call, st_);
     if (nx.coarsest) {
       coarse_solve();

@@ -14,6 +14,7 @@
 #include "transfer.h"
 #include "coarse_op.h"
 #include "coarse_mg.h"
+#include "coarse_lockstep.h"
 #include "krylov.h"
 #include "../../include/ddamg_hip.h"
 #include <memory>
@@ -96,6 +97,8 @@ class Multigrid {
   void restrict_to(int l, T* phi_c, const T* phi);               // level l -> l+1
   void interpolate(int l, T* phi, const T* phi_c, bool add);     // level l+1 -> l
   int coarse_solve();                                            // coarsest level, vectors coarse_x()/coarse_b()
+  // ncols right-hand sides in lockstep (coarse_lockstep.h); X, B: columns of ordinary coarsest-level vectors; false if the shape is not covered
+  bool coarse_solve_many(T* X, size_t xstride, const T* B, size_t bstride, int ncols, int* iters);
   void vcycle(int l, T* phi, T* Dphi, const T* eta, int res);
 
   int num_levels() const { return (int)lv_.size(); }
@@ -127,6 +130,7 @@ class Multigrid {
   T* cwork_ = nullptr;    // coarse work space (5 vectors of the largest coarse level)
 
   GatheredCoarsest<T> gath_;
+  LockstepCoarseSolver lockstep_;   // the bootstrap's coarsest-level solves, all test vectors at once (fp32, single process)
   void setup_gathered_coarsest();
   void schur(T* out, const T* in);
   void schur_on(const CoarseOp<T>& cop, int V, T* t0, T* t1, T* out, const T* in);

@@ -411,6 +411,29 @@ int ddamg_hip_coarse_solve(ddamg_hip_ctx* c, ddamg_hip_vec* x, const ddamg_hip_v
   DDAMG_API_END
 }
 
+int ddamg_hip_coarse_solve_many(ddamg_hip_ctx* c, int ncols, ddamg_hip_vec* const* x, const ddamg_hip_vec* const* b, int* iterations) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && c->mg32 && x && b && iterations, "coarse_solve_many needs the fp32 hierarchy (mixed_precision >= 1)");
+  DDAMG_REQUIRE(ncols >= 2 && ncols <= 32, "2 <= ncols <= 32");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  const int lc = c->par.num_levels - 1;
+  for (int k = 0; k < ncols; k++) { check_vec(c, x[k], lc); check_vec(c, b[k], lc); DDAMG_REQUIRE(x[k]->precision == 32 && b[k]->precision == 32, "fp32 vectors expected"); }
+  // columns next to each other in one buffer, as the bootstrap holds them
+  const size_t cs = b[0]->bytes / sizeof(float);
+  float *B = nullptr, *X = nullptr;
+  DDAMG_HIP_CHECK(device_alloc(&B, sizeof(float) * cs * ncols));
+  DDAMG_HIP_CHECK(device_alloc(&X, sizeof(float) * cs * ncols));
+  for (int k = 0; k < ncols; k++) DDAMG_HIP_CHECK(hipMemcpyAsync(B + (size_t)k * cs, b[k]->data, b[k]->bytes, hipMemcpyDeviceToDevice, c->stream));
+  const bool ok = c->mg32->coarse_solve_many(X, cs, B, cs, ncols, iterations);
+  if (ok)
+    for (int k = 0; k < ncols; k++)
+      if (iterations[k] >= 0) DDAMG_HIP_CHECK(hipMemcpyAsync(x[k]->data, X + (size_t)k * cs, x[k]->bytes, hipMemcpyDeviceToDevice, c->stream));
+  DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
+  DDAMG_HIP_CHECK(hipFree(B)); DDAMG_HIP_CHECK(hipFree(X));
+  DDAMG_REQUIRE(ok, "coarse_solve_many: shape not covered (fp32, single process, odd-even, at most 64 dof per site)");
+  DDAMG_API_END
+}
+
 int ddamg_hip_vcycle(ddamg_hip_ctx* c, ddamg_hip_vec* phi, const ddamg_hip_vec* eta) {
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c && c->setup_done, "setup has not been run");

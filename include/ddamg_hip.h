@@ -153,6 +153,12 @@ int ddamg_hip_interpolate(ddamg_hip_ctx* ctx, ddamg_hip_vec* fine, const ddamg_h
 int ddamg_hip_coarse_apply(ddamg_hip_ctx* ctx, ddamg_hip_vec* out, const ddamg_hip_vec* in);
 /* replaces coarse_solve_odd_even_PRECISION (src/coarse_oddeven_generic.c:1139-1159) */
 int ddamg_hip_coarse_solve(ddamg_hip_ctx* ctx, ddamg_hip_vec* x, const ddamg_hip_vec* b, int* iterations);
+/* the same for ncols <= 32 right-hand sides at once: ncols independent GMRES recurrences advanced in lockstep, the coarse
+ * operator applied to all columns on the matrix cores (v_mfma_f32_16x16x4_f32), as the bootstrap setup runs the coarsest-level
+ * solves of its Nvec test vectors (the reference solves them one by one, src/setup_generic.c:441-503).  fp32 V-cycle, single
+ * process, odd-even.  iterations[c]: GMRES iterations of column c, -1 if it needed more steps than the lockstep basis holds
+ * (x[c] is then not written). */
+int ddamg_hip_coarse_solve_many(ddamg_hip_ctx* ctx, int ncols, ddamg_hip_vec* const* x, const ddamg_hip_vec* const* b, int* iterations);
 /* replaces vcycle_PRECISION(phi, NULL, eta, _NO_RES) (src/vcycle_generic.c:91-141) */
 int ddamg_hip_vcycle(ddamg_hip_ctx* ctx, ddamg_hip_vec* phi, const ddamg_hip_vec* eta);
 

@@ -562,3 +562,39 @@ def test_coarse_operator_single_read_form(gold4, monkeypatch):
     ''')
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ), timeout=300)
     assert r.returncode == 0 and "ERR" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_coarsest_solves_of_many_right_hand_sides_in_lockstep(gold_b4, gold8):
+    """coarse_lockstep.h: the coarsest-level odd-even Schur GMRES for many right-hand sides at once -- independent recurrences
+    advanced together, the coarse operator on the matrix cores -- against the one-at-a-time solver column by column: the same
+    iteration count (one more or less where the stopping test falls on the rounding of the operator kernel), the same solution
+    to the accuracy of the solve (both stop at the relative residual 5e-2; the Krylov spaces are the same up to rounding)"""
+    ctx = make_ctx_b4(gold_b4, gold8)
+    ctx.setup(2)
+    lc = 1
+    n = ctx.ndof(lc); Vc = ctx.volume(lc)
+    ncols = 7
+    bs, xs, xr, itr = [], [], [], []
+    for c in range(ncols):
+        bh = splitmix_uniform(Vc * n * 2, 100 + c).reshape(Vc, n, 2)
+        if c == 3:
+            bh[:] = 0.0                       # a zero right-hand side among the columns: x = 0, no iterations
+        b = ctx.vector(lc, 32).upload(bh); x = ctx.vector(lc, 32); r = ctx.vector(lc, 32)
+        bs.append(b); xs.append(x)
+        itr.append(ctx.coarse_solve(r, b) if c != 3 else 0)
+        xr.append(r.download() if c != 3 else np.zeros_like(bh))
+    its = ctx.coarse_solve_many(xs, bs)
+    for c in range(ncols):
+        assert its[c] >= 0 and abs(its[c] - itr[c]) <= 1, (c, its, itr)
+        got = xs[c].download()
+        if c == 3:
+            assert np.all(got == 0.0)
+        elif its[c] == itr[c]:
+            assert relerr(got, xr[c]) < 1e-4, (c, relerr(got, xr[c]))
+        # the defining property either way: the residual of the full coarse system is below the tolerance of the solve
+        if c != 3:
+            Dx = ctx.vector(lc, 32); ctx.coarse_apply(Dx, xs[c])
+            bh = bs[c].download()
+            assert np.linalg.norm(Dx.download() - bh) / np.linalg.norm(bh) < 5.5e-2
+            Dx.free()
+    ctx.close()
