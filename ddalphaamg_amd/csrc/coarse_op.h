@@ -69,6 +69,9 @@ class CoarseOp {
   // out[s0,s1) (+)= sign * sum over the 8 neighbours of the hopping terms of `in`
   //   accumulate=false: out = sign*H(in) ; accumulate=true: out += sign*H(in)
   void hop(T* out, const T* in, int s0, int s1, double sign, bool accumulate, hipStream_t st) const;
+  // even-site Schur complement out_e = (D_ee - D_eo D_oo^-1 D_oe) in_e of a lattice ordered [even][odd], in two launches (the self-coupling
+  // products in the epilogue / as the ninth product of the hopping-term workgroups); t: scratch (its odd part is written).  Single process.
+  void schur_fused(T* out, T* t, const T* in, hipStream_t st) const;
   // masked / listed form used by the coarse Schwarz smoother and the coarse Galerkin construction
   void apply_masked(T* out, const T* in, const int* site_list, int nsites, const unsigned char* dir_mask, bool mask_invert,
                     double sign_self, double sign_hop, bool accumulate, hipStream_t st) const;

@@ -7,7 +7,7 @@
 
 namespace ddamg {
 
-enum { MODE_FULL = 0, MODE_HOP = 1, MODE_SELF = 2, MODE_SELFINV = 3 };
+enum { MODE_FULL = 0, MODE_HOP = 1, MODE_SELF = 2, MODE_SELFINV = 3, MODE_HOPINV = 4 };   // HOPINV: out = M0^-1 (sign_hop * hopping term)
 
 template <typename T> struct C2;
 template <> struct C2<float> { using t = float2; };
@@ -69,7 +69,8 @@ __device__ __forceinline__ void wave_mv(const T* __restrict__ Mbase, const T* __
 template <typename T, int NT, int mode>
 __global__ void coarse_site_kernel(T* __restrict__ out, const T* __restrict__ in, CoarseOpDev<T> op, int s0,
                                    T sign_self, T sign_hop, int accumulate,
-                                   const int* __restrict__ site_list, const unsigned char* __restrict__ dir_mask, int mask_invert, int swizzle) {
+                                   const int* __restrict__ site_list, const unsigned char* __restrict__ dir_mask, int mask_invert, int swizzle,
+                                   const T* __restrict__ in_self) {
   __shared__ T res[9 * 2 * 8 * NT];
   // workgroups are dealt round-robin over the 8 XCDs: hand XCD k the k-th contiguous eighth of the sites, so that sites
   // next to each other in the level's order (one Schwarz block, one aggregate) share an L2 -- a link is read by both of
@@ -89,10 +90,12 @@ __global__ void coarse_site_kernel(T* __restrict__ out, const T* __restrict__ in
   const size_t V = op.V;
   T* r = res + (size_t)w * 2 * np;
   int prod = w;                       // MODE_FULL: 0 self, 1..4 fwd, 5..8 bwd
-  if (mode == MODE_HOP) prod = w + 1; // 1..4 fwd, 5..8 bwd
+  if (mode == MODE_HOP || mode == MODE_HOPINV) prod = w + 1; // 1..4 fwd, 5..8 bwd
   const T* Mx = op.M + (size_t)x * 5 * op.msize * 2;
   if (mode == MODE_SELF || (mode == MODE_FULL && prod == 0)) {
-    wave_mv<T, NT, false>(Mx, in + (size_t)x * n * 2, n, r);
+    // (MODE_FULL with in_self: the self coupling acts on another vector than the hopping terms -- the even-site half of the
+    // Schur complement, D_ee v_e - D_eo t_o, in one launch)
+    wave_mv<T, NT, false>(Mx, (in_self ? in_self : in) + (size_t)x * n * 2, n, r);
   } else if (mode == MODE_SELFINV) {
     wave_mv<T, NT, false>(op.Minv + (size_t)x * op.msize * 2, in + (size_t)x * n * 2, n, r);
   } else if (!((dmask >> (prod - 1)) & 1u)) {
@@ -114,6 +117,21 @@ __global__ void coarse_site_kernel(T* __restrict__ out, const T* __restrict__ in
   }
   __syncthreads();
   const int nwaves = blockDim.x >> 6;
+  if (mode == MODE_HOPINV) {
+    // the odd-site half of the Schur complement in one launch: t_o = D_oo^-1 (sign * H_oe v_e).  The hopping term of the site is
+    // summed into the ninth slot of `res`, one wavefront multiplies it with the inverse of the self coupling.
+    T* hv = res + (size_t)8 * 2 * np;
+    for (int k = threadIdx.x; k < 2 * np; k += blockDim.x) {
+      T sum = 0;
+      if (k < 2 * n) for (int ww = 0; ww < nwaves; ww++) sum += res[(size_t)ww * 2 * np + k];
+      hv[k] = sign_hop * sum;
+    }
+    __syncthreads();
+    if (w == 0) wave_mv<T, NT, false>(op.Minv + (size_t)x * op.msize * 2, hv, n, res);
+    __syncthreads();
+    for (int k = threadIdx.x; k < 2 * n; k += blockDim.x) out[(size_t)x * n * 2 + k] = res[k];
+    return;
+  }
   for (int k = threadIdx.x; k < 2 * n; k += blockDim.x) {
     T v = accumulate ? out[(size_t)x * n * 2 + k] : (T)0;
     if (mode == MODE_FULL) {
@@ -427,9 +445,9 @@ void CoarseOp<T>::pack_and_begin(const T* in, hipStream_t st) const {
 
 template <typename T>
 static void launch_site(const CoarseOpDev<T>& op, T* out, const T* in, int s0, int s1, int mode, double ss, double sh, bool acc, hipStream_t st,
-                        const int* site_list = nullptr, const unsigned char* dir_mask = nullptr, bool mask_invert = false) {
+                        const int* site_list = nullptr, const unsigned char* dir_mask = nullptr, bool mask_invert = false, const T* in_self = nullptr) {
   if (s1 <= s0) return;
-  const int waves = mode == MODE_FULL ? 9 : (mode == MODE_HOP ? 8 : 1);
+  const int waves = mode == MODE_FULL ? 9 : ((mode == MODE_HOP || mode == MODE_HOPINV) ? 8 : 1);
   dim3 grid(s1 - s0), block(64 * waves);
   int swz = (s1 - s0) >= 64 ? 1 : 0;   // measured at 48^4, three levels: 3 % on the whole solve
   // The couplings of a level (302 MB at 8^4 x 48) are streamed once per hopping term and are larger than the 256 MB
@@ -437,10 +455,11 @@ static void launch_site(const CoarseOpDev<T>& op, T* out, const T* in, int s0, i
   // second hopping term therefore starts where the previous one ended.
   static const bool alternate = getenv("DDAMG_COARSE_SWEEP_SAME_WAY") == nullptr;   // 53.3 -> 51.0 us per hopping term at 8^4 x 48
   static unsigned hop_count = 0;
-  if (alternate && mode == MODE_HOP && site_list == nullptr && (hop_count++ & 1u)) swz |= 2;
-#define DDAMG_LAUNCH(NTV, MODEV) hipLaunchKernelGGL((coarse_site_kernel<T, NTV, MODEV>), grid, block, 0, st, out, in, op, s0, (T)ss, (T)sh, acc ? 1 : 0, site_list, dir_mask, mask_invert ? 1 : 0, swz)
+  if (alternate && (mode == MODE_HOP || mode == MODE_HOPINV || (mode == MODE_FULL && in_self)) && site_list == nullptr && (hop_count++ & 1u)) swz |= 2;
+#define DDAMG_LAUNCH(NTV, MODEV) hipLaunchKernelGGL((coarse_site_kernel<T, NTV, MODEV>), grid, block, 0, st, out, in, op, s0, (T)ss, (T)sh, acc ? 1 : 0, site_list, dir_mask, mask_invert ? 1 : 0, swz, in_self)
 #define DDAMG_CASE(NTV) case NTV: \
     if (mode == MODE_FULL) DDAMG_LAUNCH(NTV, MODE_FULL); else if (mode == MODE_HOP) DDAMG_LAUNCH(NTV, MODE_HOP); \
+    else if (mode == MODE_HOPINV) DDAMG_LAUNCH(NTV, MODE_HOPINV); \
     else if (mode == MODE_SELF) DDAMG_LAUNCH(NTV, MODE_SELF); else DDAMG_LAUNCH(NTV, MODE_SELFINV); \
     break;
   switch (op.nt) {
@@ -489,6 +508,15 @@ template <typename T> void CoarseOp<T>::apply(T* out, const T* in, hipStream_t s
   // the forward terms across the process boundary that the first pass left out
   if (overlap && n_fwd_off_ > 0)
     launch_site<T>(op, out, in, 0, n_fwd_off_, MODE_HOP, 0.0, -1.0, true, st, d_fwd_off_sites_, d_fwd_off_mask_, false);
+}
+// coarse_apply_schur_complement_PRECISION (src/coarse_oddeven_generic.c:1162-1189) in two launches on a lattice ordered
+// [even sites][odd sites]: t_o = D_oo^-1 D_oe v_e with the inverse in the epilogue of the hopping term, then
+// out_e = D_ee v_e - D_eo t_o with the self coupling as the ninth product of the workgroup.  Single process.
+template <typename T> void CoarseOp<T>::schur_fused(T* out, T* t, const T* in, hipStream_t st) const {
+  DDAMG_REQUIRE(out != in && t != in && out != t && !arena_.active(), "schur_fused: distinct vectors, single process");
+  const int Ve = V_ / 2;
+  launch_site<T>(dev(), t, in, Ve, V_, MODE_HOPINV, 0.0, -1.0, false, st);                               // t_o = D_oo^-1 (-H_oe v_e)
+  launch_site<T>(dev(), out, t, 0, Ve, MODE_FULL, 1.0, +1.0, false, st, nullptr, nullptr, false, in);    // out_e = D_ee v_e + H_eo t_o
 }
 template <typename T> void CoarseOp<T>::hop(T* out, const T* in, int s0, int s1, double sign, bool accumulate, hipStream_t st) const {
   DDAMG_REQUIRE(out != in, "coarse hopping term cannot run in place");

@@ -357,6 +357,11 @@ void Multigrid<T>::gmres_smoother(int l, T* phi, const T* eta, int cycles, int r
 template <typename T>
 void Multigrid<T>::schur_on(const CoarseOp<T>& cop, int V, T* t0, T* t1, T* out, const T* in) {
   const int Ve = V / 2;
+  // two launches instead of four (the self-coupling products inside the hopping-term launches, CoarseOp::schur_fused): measured
+  // at 32^4 (8^4 x 48 coarsest level) 46.3 against 46.0 ms per solve -- the serial epilogue costs what the two 11 us launches
+  // cost -- so it is an option, not the default
+  static const bool fused = getenv("DDAMG_COARSE_SCHUR_FUSED") != nullptr;
+  if (fused && !cop.distributed()) { cop.schur_fused(out, t1, in, st_); return; }
   cop.self_mul(out, in, 0, Ve, false, st_);        // out_e = D_ee in_e
   cop.hop(t0, in, Ve, V, -1.0, false, st_);        // tmp0_o = -H_oe in_e   (= D_oe in_e)
   cop.self_mul(t1, t0, Ve, V, true, st_);          // tmp1_o = D_oo^-1 tmp0_o
