@@ -280,11 +280,18 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
+def mfma_source_hash():
+    h = hashlib.sha256()
+    for f in ("coarse_lockstep.hip", "coarse_lockstep.h", "coarse_batch.hip", "coarse_op.h"):
+        h.update(open(os.path.join(REPO, "ddalphaamg_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def pmc_traffic(precision):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (2*FETCH_SIZE + WRITE_SIZE,
     calibrated as MI355X_MICROARCH.md prescribes).  The file records the hash of the kernel sources it was measured on; when
     the kernel has changed since, the number is stale and null is reported instead."""
-    for name in ("r02_traffic.json", "r01_traffic.json"):
+    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             d = json.load(open(os.path.join(REPO, "profiles", name)))
             e = d["dirac_apply_lds_kernel<float>"]
@@ -300,29 +307,39 @@ def pmc_traffic(precision):
 
 
 def coarse_operator_report():
-    """what the north star asks to see next to the solve: the coarse operator against its roofline and the matrix-core
-    utilisation where the coarse operator is applied to many right-hand sides.  From the committed round-2 profiles
-    (profiles/r02_solve32_kernel_stats.csv, profiles/r02_pmc_mfma.json), not measured in this run."""
+    """what the north star asks to see next to the solve: the coarse operator against its roofline (one right-hand side: the
+    solve path) and the matrix-core utilisation where the coarse operator is applied to many right-hand sides (the bootstrap's
+    coarsest-level solves in lockstep, the Galerkin construction).  From the committed profiles, not measured in this run: the
+    MFMA figures carry the hash of the kernel sources they were measured on and are reported as null once those changed."""
     import csv
     out = {}
+    for R in ("r03", "r02"):
+        try:
+            rows = list(csv.DictReader(open(os.path.join(REPO, "profiles", R + "_solve32_kernel_stats.csv"))))
+            r = [x for x in rows if "coarse_site_kernel<float, 6, 1>" in x["Name"]][0]     # <T, n/8, MODE_HOP>
+            us = float(r["AverageUs"]); n = 48; sites = 8 ** 4 // 2
+            byts = sites * 8 * n * n * 8        # a half hopping term reads 4 own and 4 neighbours' links per site, 8 B per complex
+            out["solve_path"] = {"kernel": "coarse_site_kernel, hopping-term instantiation (one right-hand side: VALU tile GEMV, arithmetic intensity ~2 flop/B)",
+                                 "us_per_half_hopping_term_8^4_n48": us, "GB/s": byts / us / 1e3, "frac_of_hbm_peak": byts / us / 1e3 / 8000.0,
+                                 "note": "302 MB of couplings per launch (the whole 8^4 coarse operator: a half hopping term uses every link once)",
+                                 "source": "profiles/" + R + "_solve32_kernel_stats.csv"}
+            break
+        except Exception:
+            continue
     try:
-        rows = list(csv.DictReader(open(os.path.join(REPO, "profiles", "r02_solve32_kernel_stats.csv"))))
-        r = [x for x in rows if "coarse_site_kernel<float, 6, 1>" in x["Name"]][0]     # <T, n/8, MODE_HOP>
-        us = float(r["AverageUs"]); n = 48; sites = 8 ** 4 // 2
-        byts = sites * 8 * n * n * 8        # a half hopping term reads 4 own and 4 neighbours' links per site, 8 B per complex
-        out["solve_path"] = {"kernel": "coarse_site_kernel, hopping-term instantiation (one right-hand side: VALU tile GEMV, arithmetic intensity ~2 flop/B)",
-                             "us_per_half_hopping_term_8^4_n48": us, "GB/s": byts / us / 1e3, "frac_of_hbm_peak": byts / us / 1e3 / 8000.0,
-                             "note": "302 MB of couplings per launch (the whole 8^4 coarse operator: a half hopping term uses every link once)",
-                             "source": "profiles/r02_solve32_kernel_stats.csv"}
-    except Exception:
-        pass
-    try:
-        d = json.load(open(os.path.join(REPO, "profiles", "r02_pmc_mfma.json")))
-        k = [x for x in d if "coarse_batch_apply_kernel" in x][0]
-        busy = d[k]["SQ_VALU_MFMA_BUSY_CYCLES"]["mean"]; cyc = d[k]["GRBM_GUI_ACTIVE"]["mean"] / 8.0   # counted per XCD
-        out["multi_rhs"] = {"kernel": "coarse_batch_apply_kernel (all 2*Nvec columns of the coarse-level Galerkin construction at once: "
-                                      "complex n x n times n x 64 on v_mfma_f32_16x16x4_f32)",
-                            "mfma_busy": busy / (cyc * 1024.0), "source": "profiles/r02_pmc_mfma.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs), 48^4 three-level setup"}
+        d = json.load(open(os.path.join(REPO, "profiles", "r03_mfma_busy.json")))
+        stale = d.get("kernel_source_sha16") != mfma_source_hash()
+        def entry(key, what):
+            e = d.get(key, {})
+            return {"kernel": what, "mfma_busy": None if (stale or "mfma_busy" not in e) else e["mfma_busy"], "source": e.get("source"),
+                    "stale": (f"measured on kernel sources {d.get('kernel_source_sha16')}, current {mfma_source_hash()}" if stale else None)}
+        out["multi_rhs"] = {
+            "formula": d.get("formula"),
+            "bootstrap_coarsest_solves_in_lockstep": entry("lockstep_hop", "ls_hop_kernel: hopping terms of the coarsest-level Schur complement for all Nvec test vectors of a "
+                                                           "bootstrap iteration at once, complex n x n times n x 32 on v_mfma_f32_16x16x4_f32 (32^4 two-level setup)"),
+            "galerkin_coarse_apply": entry("galerkin_coarse_apply", "coarse_batch_apply_kernel: all 2*Nvec columns of the coarse-level Galerkin construction (48^4 three-level setup)"),
+            "galerkin_restrict": entry("galerkin_restrict", "restrict_mfma_kernel: 240 fields x 24 vectors per aggregate on v_mfma_f32_32x32x2_f32"),
+        }
     except Exception:
         pass
     return out or None
@@ -424,13 +441,14 @@ def run_solve(q, G, grid, coords, world, rank, transport, group):
 
 def committed_n1_strong(G):
     """seconds per solve of the strong-scaling configuration on ONE GPU, measured by the build on its own MI355X box and
-    committed with its provenance (profiles/r02_strong_scaling_n1.json): the denominator of `speedup_vs_n1` on N > 1"""
-    try:
-        d = json.load(open(os.path.join(REPO, "profiles", "r02_strong_scaling_n1.json")))
-        if list(d["global_lattice"]) == list(G):
-            return d
-    except Exception:
-        pass
+    committed with its provenance (profiles/r03_strong_scaling_n1.json, else r02): the denominator of `speedup_vs_n1` on N > 1"""
+    for name in ("r03_strong_scaling_n1.json", "r02_strong_scaling_n1.json"):
+        try:
+            d = json.load(open(os.path.join(REPO, "profiles", name)))
+            if list(d["global_lattice"]) == list(G):
+                return d
+        except Exception:
+            continue
     return None
 
 

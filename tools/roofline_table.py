@@ -3,7 +3,8 @@
 committed kernel statistics (profiles/r02_bench_kernel_stats.csv, profiles/r02_solve32_kernel_stats.csv): average
 duration, algorithmic bytes per launch (SURVEY.md 8d figures x units per launch), achieved rate, fraction of 8 TB/s.
 Writes profiles/r02_roofline_table.md."""
-import csv, os
+import csv, os, sys
+R = sys.argv[1] if len(sys.argv) > 1 else "r03"
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 V = 32 ** 4
 Vc, n = 8 ** 4, 48
@@ -12,7 +13,7 @@ def rows(f):
 def avg(rs, key):
     r = [x for x in rs if key in x["Name"]]
     return (float(r[0]["AverageUs"]), int(r[0]["Calls"])) if r else (None, 0)
-b, s = rows("r02_bench_kernel_stats.csv"), rows("r02_solve32_kernel_stats.csv")
+b, s = rows(R + "_bench_kernel_stats.csv"), rows(R + "_solve32_kernel_stats.csv")
 table = [
     ("dirac_apply_lds_kernel<float>", "fine operator, fp32 (headline)", b, "dirac_apply_lds_kernel<float", 816 * V, "816 B/site"),
     ("dirac_apply_lds_kernel<double>", "fine operator, fp64 (outer residual)", s, "dirac_apply_lds_kernel<double", 1632 * V, "1632 B/site"),
@@ -29,7 +30,7 @@ for name, what, rs, key, byts, unit in table:
         continue
     out.append(f"| `{name}` | {what} | {calls} | {us:.1f} | {byts / 1e6:.1f} MB ({unit}) | {byts / us / 1e6:.2f} | {byts / us / 1e6 / 8.0:.2f} |")
 txt = ("Solve-path kernels at 32^4 (two levels, Nvec 24) against the HBM roofline; durations from the committed rocprofv3 kernel\n"
-       "statistics (`r02_bench_kernel_stats.csv`, `r02_solve32_kernel_stats.csv`; the solve run includes the setup's launches of the\n"
+       "statistics (`" + R + "_bench_kernel_stats.csv`, `" + R + "_solve32_kernel_stats.csv`; the solve run includes the setup's launches of the\n"
        "same kernels), bytes = SURVEY.md section 8d per-unit figures x units per launch.  Written by tools/roofline_table.py.\n\n" + "\n".join(out) + "\n")
-open(os.path.join(REPO, "profiles", "r02_roofline_table.md"), "w").write(txt)
+open(os.path.join(REPO, "profiles", R + "_roofline_table.md"), "w").write(txt)
 print(txt)
