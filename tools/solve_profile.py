@@ -6,6 +6,9 @@ import os, sys, time, json
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests")); sys.path.insert(0, os.path.join(REPO, "tools"))
+if os.environ.get("DDAMG_IMPORT_TORCH"):   # the configuration bench.py runs in: torch's HIP runtime loaded first
+    import torch
+    torch.cuda.init(); torch.cuda.synchronize()
 import bench, synth  # noqa: E402
 import ddalphaamg_amd as dd  # noqa: E402
 from ddalphaamg_amd import api  # noqa: E402
