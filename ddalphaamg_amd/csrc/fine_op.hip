@@ -508,6 +508,74 @@ __device__ __forceinline__ void gauss_jordan6(double (&mr)[6][12], double (&mi)[
   }
 }
 
+// In-place Gauss-Jordan inversion of a complex 6x6 matrix without pivoting, every index a compile-time constant: the matrix
+// stays in registers (the pivoting form above indexes its rows dynamically and lives in scratch memory: 577 us per 65k
+// sites against 60 us).  The clover blocks are Hermitian with the diagonal 4 + m0 +- O(csw) -- the reference factorises them
+// by Cholesky without pivoting (src/oddeven_generic.c:24-60) --; returns false when a pivot is too small for that, and the
+// caller then takes the pivoting form.
+__device__ __forceinline__ bool invert6_in_place(double (&ar)[6][6], double (&ai)[6][6]) {
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const double n2 = ar[k][k] * ar[k][k] + ai[k][k] * ai[k][k];
+    ok = ok && n2 > 1e-24;
+    const double pr = ar[k][k] / n2, pi = -ai[k][k] / n2;     // 1 / pivot
+#pragma unroll
+    for (int j = 0; j < 6; j++)
+      if (j != k) { const double xr = ar[k][j], xi = ai[k][j]; ar[k][j] = xr * pr - xi * pi; ai[k][j] = xr * pi + xi * pr; }
+#pragma unroll
+    for (int i = 0; i < 6; i++)
+      if (i != k) {
+        const double fr = ar[i][k], fi = ai[i][k];
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+          if (j != k) { ar[i][j] -= fr * ar[k][j] - fi * ai[k][j]; ai[i][j] -= fr * ai[k][j] + fi * ar[k][j]; }
+        ar[i][k] = -(fr * pr - fi * pi); ai[i][k] = -(fr * pi + fi * pr);
+      }
+    ar[k][k] = pr; ai[k][k] = pi;
+  }
+  return ok;
+}
+// inverse of the Hermitian 6x6 block given by its real diagonal d and strict upper triangle (ur, ui), row-major pairs
+// (i < j): out_d the diagonal of the inverse, (our, oui) its strict upper triangle
+__device__ __forceinline__ void invert_herm6(const double (&d)[6], const double (&ur)[15], const double (&ui)[15], double (&od)[6], double (&our)[15], double (&oui)[15]) {
+  double ar[6][6], ai[6][6];
+  {
+    int k = 0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      ar[i][i] = d[i]; ai[i][i] = 0.0;
+#pragma unroll
+      for (int j = i + 1; j < 6; j++, k++) { ar[i][j] = ur[k]; ai[i][j] = ui[k]; ar[j][i] = ur[k]; ai[j][i] = -ui[k]; }
+    }
+  }
+  if (!invert6_in_place(ar, ai)) {
+    // cold path: partial pivoting (dynamic row indices, scratch memory)
+    double mr[6][12], mi[6][12];
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 12; j++) { mr[i][j] = (j == 6 + i) ? 1.0 : 0.0; mi[i][j] = 0.0; }
+    int k = 0;
+    for (int i = 0; i < 6; i++) {
+      mr[i][i] = d[i];
+      for (int j = i + 1; j < 6; j++, k++) { mr[i][j] = ur[k]; mi[i][j] = ui[k]; mr[j][i] = ur[k]; mi[j][i] = -ui[k]; }
+    }
+    gauss_jordan6(mr, mi);
+    k = 0;
+    for (int i = 0; i < 6; i++) {
+      od[i] = mr[i][6 + i];
+      for (int j = i + 1; j < 6; j++, k++) { our[k] = mr[i][6 + j]; oui[k] = mi[i][6 + j]; }
+    }
+    return;
+  }
+  int k = 0;
+#pragma unroll
+  for (int i = 0; i < 6; i++) {
+    od[i] = ar[i][i];
+#pragma unroll
+    for (int j = i + 1; j < 6; j++, k++) { our[k] = ar[i][j]; oui[k] = ai[i][j]; }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(128) void operator_layout_kernel(T* __restrict__ D, T* __restrict__ clover, T* __restrict__ clover_inv,
                                                               const double* __restrict__ D_lex, const double* __restrict__ clover_lex,
@@ -519,36 +587,27 @@ __global__ __launch_bounds__(128) void operator_layout_kernel(T* __restrict__ D,
     for (int r = 0; r < 18; r++)
       D[(size_t)mu * 18 * V + soa_index_dev<T>(18, V, s, r)] = (T)D_lex[(lx * 36 + mu * 9) * 2 + r];
   const double* c = clover_lex + lx * 42 * 2;
+#pragma unroll
   for (int b = 0; b < 2; b++) {
-    double mr[6][12], mi[6][12];   // [A | 1] -> [1 | A^-1]
-    for (int i = 0; i < 6; i++)
-      for (int j = 0; j < 12; j++) { mr[i][j] = (j == 6 + i) ? 1.0 : 0.0; mi[i][j] = 0.0; }
-    for (int i = 0; i < 6; i++) mr[i][i] = c[2 * (6 * b + i)];
-    int k = 12 + 15 * b;
-    for (int i = 0; i < 6; i++)
-      for (int j = i + 1; j < 6; j++, k++) {
-        mr[i][j] = c[2 * k]; mi[i][j] = c[2 * k + 1];
-        mr[j][i] = c[2 * k]; mi[j][i] = -c[2 * k + 1];
-      }
-    int r0 = 36 * b;
-    for (int i = 0; i < 6; i++) clover[soa_index_dev<T>(72, V, s, r0 + i)] = (T)mr[i][i];
-    r0 += 6;
-    for (int i = 0; i < 6; i++)
-      for (int j = i + 1; j < 6; j++) {
-        clover[soa_index_dev<T>(72, V, s, r0)] = (T)mr[i][j];
-        clover[soa_index_dev<T>(72, V, s, r0 + 1)] = (T)mi[i][j];
-        r0 += 2;
-      }
-    gauss_jordan6(mr, mi);
-    r0 = 36 * b;
-    for (int i = 0; i < 6; i++) clover_inv[soa_index_dev<T>(72, V, s, r0 + i)] = (T)mr[i][6 + i];
-    r0 += 6;
-    for (int i = 0; i < 6; i++)
-      for (int j = i + 1; j < 6; j++) {
-        clover_inv[soa_index_dev<T>(72, V, s, r0)] = (T)mr[i][6 + j];
-        clover_inv[soa_index_dev<T>(72, V, s, r0 + 1)] = (T)mi[i][6 + j];
-        r0 += 2;
-      }
+    double d[6], ur[15], ui[15], od[6], our[15], oui[15];
+#pragma unroll
+    for (int i = 0; i < 6; i++) d[i] = c[2 * (6 * b + i)];
+#pragma unroll
+    for (int k = 0; k < 15; k++) { ur[k] = c[2 * (12 + 15 * b + k)]; ui[k] = c[2 * (12 + 15 * b + k) + 1]; }
+    invert_herm6(d, ur, ui, od, our, oui);
+    const int r0 = 36 * b;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      clover[soa_index_dev<T>(72, V, s, r0 + i)] = (T)d[i];
+      clover_inv[soa_index_dev<T>(72, V, s, r0 + i)] = (T)od[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 15; k++) {
+      clover[soa_index_dev<T>(72, V, s, r0 + 6 + 2 * k)] = (T)ur[k];
+      clover[soa_index_dev<T>(72, V, s, r0 + 6 + 2 * k + 1)] = (T)ui[k];
+      clover_inv[soa_index_dev<T>(72, V, s, r0 + 6 + 2 * k)] = (T)our[k];
+      clover_inv[soa_index_dev<T>(72, V, s, r0 + 6 + 2 * k + 1)] = (T)oui[k];
+    }
   }
 }
 
@@ -557,28 +616,27 @@ template <typename T>
 __global__ __launch_bounds__(128) void clover_shift_kernel(T* clover, T* __restrict__ clover_inv, const double* clover64, double diff, int V) {
   const size_t s = (size_t)blockIdx.x * 128 + threadIdx.x;
   if (s >= (size_t)V) return;
+#pragma unroll
   for (int b = 0; b < 2; b++) {
-    double mr[6][12], mi[6][12];
-    for (int i = 0; i < 6; i++)
-      for (int j = 0; j < 12; j++) { mr[i][j] = (j == 6 + i) ? 1.0 : 0.0; mi[i][j] = 0.0; }
-    int r0 = 36 * b;
-    for (int i = 0; i < 6; i++) mr[i][i] = clover64[soa_index_dev<double>(72, V, s, r0 + i)] + diff;
-    for (int i = 0; i < 6; i++) clover[soa_index_dev<T>(72, V, s, r0 + i)] = (T)mr[i][i];
-    r0 += 6;
-    for (int i = 0; i < 6; i++)
-      for (int j = i + 1; j < 6; j++, r0 += 2) {
-        const double re = clover64[soa_index_dev<double>(72, V, s, r0)], im = clover64[soa_index_dev<double>(72, V, s, r0 + 1)];
-        mr[i][j] = re; mi[i][j] = im; mr[j][i] = re; mi[j][i] = -im;
-      }
-    gauss_jordan6(mr, mi);
-    r0 = 36 * b;
-    for (int i = 0; i < 6; i++) clover_inv[soa_index_dev<T>(72, V, s, r0 + i)] = (T)mr[i][6 + i];
-    r0 += 6;
-    for (int i = 0; i < 6; i++)
-      for (int j = i + 1; j < 6; j++, r0 += 2) {
-        clover_inv[soa_index_dev<T>(72, V, s, r0)] = (T)mr[i][6 + j];
-        clover_inv[soa_index_dev<T>(72, V, s, r0 + 1)] = (T)mi[i][6 + j];
-      }
+    double d[6], ur[15], ui[15], od[6], our[15], oui[15];
+    const int r0 = 36 * b;
+#pragma unroll
+    for (int i = 0; i < 6; i++) d[i] = clover64[soa_index_dev<double>(72, V, s, r0 + i)] + diff;
+#pragma unroll
+    for (int k = 0; k < 15; k++) {
+      ur[k] = clover64[soa_index_dev<double>(72, V, s, r0 + 6 + 2 * k)];
+      ui[k] = clover64[soa_index_dev<double>(72, V, s, r0 + 6 + 2 * k + 1)];
+    }
+#pragma unroll
+    for (int i = 0; i < 6; i++) clover[soa_index_dev<T>(72, V, s, r0 + i)] = (T)d[i];
+    invert_herm6(d, ur, ui, od, our, oui);
+#pragma unroll
+    for (int i = 0; i < 6; i++) clover_inv[soa_index_dev<T>(72, V, s, r0 + i)] = (T)od[i];
+#pragma unroll
+    for (int k = 0; k < 15; k++) {
+      clover_inv[soa_index_dev<T>(72, V, s, r0 + 6 + 2 * k)] = (T)our[k];
+      clover_inv[soa_index_dev<T>(72, V, s, r0 + 6 + 2 * k + 1)] = (T)oui[k];
+    }
   }
 }
 template <typename T>

@@ -4,7 +4,7 @@ import os, sys, time
 import numpy as np
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tests"))
-from bench import synth_gauge
+from bench import synth_gauge_random as synth_gauge
 import ddalphaamg_amd as dd
 from ddalphaamg_amd import api
 L = [32] * 4; V = 32 ** 4
