@@ -375,7 +375,11 @@ template <typename T>
 bool CoarseOp<T>::block_minres(T* x, T* r, T* latest, const int* blocks, int nblocks, const BlockPlan& plan, int iters, double eps, hipStream_t st) const {
   static const bool off = getenv("DDAMG_COARSE_SAP_UNFUSED") != nullptr;
   const int np = 8 * nt_, BS = plan.block_sites;
-  const size_t lds = 48 * sizeof(double) + sizeof(T) * 2 * np * ((size_t)2 * BS + (size_t)2 * plan.nitems);
+  size_t lds = 48 * sizeof(double) + sizeof(T) * 2 * np * ((size_t)2 * BS + (size_t)2 * plan.nitems);
+  // workgroups per CU (experiment knob): the couplings of a block are streamed once per MinRes step; with fewer blocks in flight
+  // the steps 2.. of a block may still find them in the Infinity Cache
+  static const int wg_per_cu = getenv("DDAMG_COARSE_SAP_WG_PER_CU") ? atoi(getenv("DDAMG_COARSE_SAP_WG_PER_CU")) : 0;
+  if (wg_per_cu > 0) lds = std::max(lds, (size_t)(160 * 1024 / wg_per_cu) - 1024);
   if (off || plan.nitems == 0 || (size_t)BS * n_ > (size_t)BLOCK_MINRES_THREADS * BLOCK_MINRES_MAXE || lds > 150 * 1024) return false;
   if (nblocks <= 0) return true;
   const CoarseOpDev<T> op = dev();
