@@ -696,7 +696,12 @@ bool Multigrid<T>::bootstrap_vcycles_batched() {
   MGLevel<T>& nx = *lv_[1];
   const int N = lv.nvec;
   const size_t ws = (size_t)24 * lv.g->V, cs = (size_t)nx.g->V * nx.n * 2;
-  if (off || sizeof(T) != 4 || comm_ != nullptr || lv.fop->distributed() || !gal_W_ || !gal_C_) return false;
+  // (on a process grid as well: restriction and interpolation are local to the aggregates, which never straddle a process
+  // boundary; the coarse solves and smoother calls in between communicate as they do one vector at a time.
+  // DDAMG_BOOTSTRAP_BATCHED_SINGLE_PROCESS_ONLY restores the round-2 restriction to one process.)
+  static const bool single_only = getenv("DDAMG_BOOTSTRAP_BATCHED_SINGLE_PROCESS_ONLY") != nullptr;
+  if (off || sizeof(T) != 4 || !gal_W_ || !gal_C_) return false;
+  if (single_only && (comm_ != nullptr || lv.fop->distributed())) return false;
   if (!Interpolation<T>::restrict_batch_available(lv.fip.agg_sites, N) || !Interpolation<T>::interpolate_batch_available(lv.fip.agg_sites, N, N)) return false;
   if (gal_W_elems_ < (size_t)N * ws || gal_C_elems_ < (size_t)2 * N * cs) return false;
   T* F = gal_W_;                 // N fine vectors: the iterates of the V-cycles
