@@ -64,6 +64,38 @@ __device__ __forceinline__ void wave_mv(const T* __restrict__ Mbase, const T* __
   }
 }
 
+// the same product with the matrix already in registers (lane l holds element l of every 8x8 tile): self couplings that a
+// wavefront applies in every MinRes step of a block (coarse_block_minres_kernel)
+template <typename T, int NT>
+__device__ __forceinline__ void wave_mv_reg(const typename C2<T>::t (&m)[NT * NT], const T* __restrict__ v, int n, T* __restrict__ res) {
+  using c2 = typename C2<T>::t;
+  const int l = threadIdx.x & 63, a = l >> 3, b = l & 7;
+  T xr[NT], xi[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+    const int k = b + 8 * t;
+    if (k < n) { c2 z = *reinterpret_cast<const c2*>(v + 2 * k); xr[t] = z.x; xi[t] = z.y; }
+    else { xr[t] = 0; xi[t] = 0; }
+  }
+  T ar[NT], ai[NT];
+#pragma unroll
+  for (int t = 0; t < NT; t++) { ar[t] = 0; ai[t] = 0; }
+#pragma unroll
+  for (int p = 0; p < NT; p++)
+#pragma unroll
+    for (int q = 0; q < NT; q++) {
+      const c2 e = m[p * NT + q];
+      ar[p] += e.x * xr[q] - e.y * xi[q];
+      ai[p] += e.x * xi[q] + e.y * xr[q];
+    }
+#pragma unroll
+  for (int t = 0; t < NT; t++) {
+#pragma unroll
+    for (int o = 1; o < 8; o <<= 1) { ar[t] += __shfl_xor(ar[t], o, 64); ai[t] += __shfl_xor(ai[t], o, 64); }
+    if (b == 0) { res[2 * (a + 8 * t)] = ar[t]; res[2 * (a + 8 * t) + 1] = ai[t]; }
+  }
+}
+
 // MODE is a template parameter so that the hopping terms and the (8 times lighter) self-coupling products show up under
 // their own names in kernel statistics
 template <typename T, int NT, int mode>
@@ -219,8 +251,33 @@ __global__ __launch_bounds__(BLOCK_MINRES_THREADS) void coarse_block_minres_kern
     lphi[e] = 0;
   }
   __syncthreads();
+  // The self couplings of the block (the first BS items) stay in registers across the MinRes steps when every wavefront owns
+  // one of them per wavefront (the register budget of 8 wavefronts per workgroup allows no more: two per wavefront spill 169
+  // registers): a 2^4 block streams 48 matrices per step, from the second step on 40 (885 -> 737 KB per step at n = 48)
+  using c2 = typename C2<T>::t;
+  constexpr int RES = 1;
+  const bool resident = NT <= 6;   // the first RES * nw self items; the others are streamed like the links
+  c2 mres[RES][NT * NT];
+  if (resident) {
+#pragma unroll
+    for (int q = 0; q < RES; q++) {
+      const int item = w + q * nw;
+      if (item < BS) {
+        const c2* M = reinterpret_cast<const c2*>(op.M + (s0 + item) * 5 * op.msize * 2) + (tid & 63);
+#pragma unroll
+        for (int e = 0; e < NT * NT; e++) mres[q][e] = M[e * 64];
+      }
+    }
+  }
   for (int it = 0; it < iters; it++) {
-    for (int item = w; item < nitems; item += nw) {
+    if (resident) {
+#pragma unroll
+      for (int q = 0; q < RES; q++) {
+        const int item = w + q * nw;      // self items are (i, -1, i) with i = item
+        if (item < BS) wave_mv_reg<T, NT>(mres[q], rl + (size_t)item * 2 * np, n, slots + (size_t)(2 * item) * 2 * np);
+      }
+    }
+    for (int item = (resident ? RES * nw : 0) + w; item < nitems; item += nw) {
       const int i = items[3 * item], mu = items[3 * item + 1], j = items[3 * item + 2];
       const T* Mx = op.M + (s0 + i) * 5 * op.msize * 2;
       if (mu < 0) wave_mv<T, NT, false>(Mx, rl + (size_t)i * 2 * np, n, slots + (size_t)(2 * item) * 2 * np);
