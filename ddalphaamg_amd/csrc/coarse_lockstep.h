@@ -27,6 +27,7 @@ class LockstepCoarseSolver {
   ~LockstepCoarseSolver();
   static bool available(const CoarseOp<float>& cop, int ncols, bool odd_even);
   void init(const CoarseOp<float>* cop, int max_steps, double tol, hipStream_t st);
+  void release();                            // the batches are setup workspace: freed with the Galerkin workspace after a setup
   bool ready() const { return cop_ != nullptr; }
   // Solves D_c x_c = b_c for columns c < ncols (ordinary coarse vectors, column c at B + c*bstride / X + c*xstride).
   // iters[c] = GMRES iterations of column c, or -1 if the column did not converge within max_steps (the caller then solves

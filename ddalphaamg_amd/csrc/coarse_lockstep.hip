@@ -205,8 +205,9 @@ bool LockstepCoarseSolver::available(const CoarseOp<float>& cop, int ncols, bool
   return !off && odd_even && !cop.distributed() && ncols >= 2 && ncols <= NC && cop.n() <= 64 && cop.n() % 4 == 0 && cop.V() % 2 == 0;
 }
 
-LockstepCoarseSolver::~LockstepCoarseSolver() {
-  for (int i = 0; i < 4; i++) if (W_[i]) (void)hipFree(W_[i]);
+LockstepCoarseSolver::~LockstepCoarseSolver() { release(); }
+void LockstepCoarseSolver::release() {
+  for (int i = 0; i < 4; i++) if (W_[i]) { (void)hipFree(W_[i]); W_[i] = nullptr; }
   if (basis_) (void)hipFree(basis_);
   if (w_) (void)hipFree(w_);
   if (d_partial_) (void)hipFree(d_partial_);
@@ -214,6 +215,7 @@ LockstepCoarseSolver::~LockstepCoarseSolver() {
   if (d_coef_) (void)hipFree(d_coef_);
   if (h_h_) (void)hipHostFree(h_h_);
   if (h_coef_) (void)hipHostFree(h_coef_);
+  basis_ = nullptr; w_ = nullptr; d_partial_ = d_h_ = d_coef_ = h_h_ = h_coef_ = nullptr; cop_ = nullptr;
 }
 
 void LockstepCoarseSolver::init(const CoarseOp<float>* cop, int max_steps, double tol, hipStream_t st) {

@@ -650,6 +650,7 @@ void Multigrid<T>::release_setup_workspace() {
   if (gal_W_) { DDAMG_HIP_CHECK(hipFree(gal_W_)); gal_W_ = nullptr; gal_W_elems_ = 0; }
   if (gal_C_) { DDAMG_HIP_CHECK(hipFree(gal_C_)); gal_C_ = nullptr; gal_C_elems_ = 0; }
   if (gal_cwork_) { DDAMG_HIP_CHECK(hipFree(gal_cwork_)); gal_cwork_ = nullptr; }
+  lockstep_.release();
 }
 
 template <typename T>
