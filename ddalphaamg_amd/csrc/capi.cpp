@@ -84,7 +84,7 @@ int ddamg_hip_create(const ddamg_hip_params* p, ddamg_hip_ctx** out) {
   {
     bool grid = false;
     for (int mu = 0; mu < 4; mu++) grid = grid || p->process_grid[mu] > 1 || p->process_grid[mu] == -1;
-    if (grid && comm_cus_from_env() > 0) DDAMG_HIP_CHECK(create_cu_masked_stream(&c->stream, comm_cus_from_env(), false));
+    if (grid && comm_cus_for(p->num_levels) > 0) DDAMG_HIP_CHECK(create_cu_masked_stream(&c->stream, comm_cus_for(p->num_levels), false));
     else DDAMG_HIP_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
   }
   DDAMG_HIP_CHECK(hipEventCreate(&c->ev0));
@@ -258,7 +258,7 @@ int ddamg_hip_comm_init_rccl(ddamg_hip_ctx* c, const void* id128) {
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c && id128, "null argument");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
-  install_comm(c, comm_create_rccl(c->levels[0]->geom, id128));
+  install_comm(c, comm_create_rccl(c->levels[0]->geom, id128, comm_cus_for(c->par.num_levels)));
   DDAMG_API_END
 }
 
@@ -266,7 +266,7 @@ int ddamg_hip_comm_init_host(ddamg_hip_ctx* c, ddamg_hip_exchange_fn fn, ddamg_h
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c, "null argument");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
-  install_comm(c, comm_create_host(c->levels[0]->geom, fn, reduce_fn, user));
+  install_comm(c, comm_create_host(c->levels[0]->geom, fn, reduce_fn, user, comm_cus_for(c->par.num_levels)));
   DDAMG_API_END
 }
 

@@ -7,7 +7,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int NB = COARSE_BATCH_COLS;
 
 bool coarse_galerkin_batch_available(int n, int ncols, bool distributed, size_t elem_size) {
-  return elem_size == 4 && !distributed && ncols <= NB && n <= 64 && n % 4 == 0;
+  // on a process grid the forward couplings across the process boundary take their operand from a halo of the batch
+  // (CoarseOp::wide_halo_exchange); DDAMG_COARSE_GALERKIN_DIST_UNBATCHED keeps the column-by-column construction there
+  static const bool dist_off = getenv("DDAMG_COARSE_GALERKIN_DIST_UNBATCHED") != nullptr;
+  return elem_size == 4 && !(distributed && dist_off) && ncols <= NB && n <= 64 && n % 4 == 0;
 }
 
 // V[x][k][j] = P_{j mod N}(x,k) if k belongs to chirality j / N (k < n/2 <-> chirality 0), else 0; columns >= 2N are 0
@@ -71,9 +74,10 @@ __device__ __forceinline__ void store_tile(float2* __restrict__ out, int n, int 
 
 // out[0][x] = M0 B(x) - sum over couplings that stay inside the aggregate;  out[1+mu][x] = + forward coupling in mu if
 // it leaves the aggregate, else 0.  One workgroup (4 wavefronts x 16 columns) per site.
+struct BatchHalo { const float2* recv; int off[4]; };   // the batch at the forward neighbours on other processes (null: one process)
 template <int NRT>
 __global__ __launch_bounds__(256) void coarse_batch_apply_kernel(float2* __restrict__ out, size_t out_stride, const float2* __restrict__ Vb,
-                                                                 CoarseOpDev<float> op, const unsigned char* __restrict__ agg_face) {
+                                                                 CoarseOpDev<float> op, const unsigned char* __restrict__ agg_face, BatchHalo halo) {
   const int x = blockIdx.x, n = op.n, nt = op.nt;
   const int col0 = (threadIdx.x >> 6) * 16;
   const unsigned face = agg_face[x];
@@ -87,7 +91,11 @@ __global__ __launch_bounds__(256) void coarse_batch_apply_kernel(float2* __restr
     f32x4 aR[NRT], aI[NRT];
 #pragma unroll
     for (int rt = 0; rt < NRT; rt++) { aR[rt] = f32x4{0, 0, 0, 0}; aI[rt] = f32x4{0, 0, 0, 0}; }
-    if (face & (1u << mu)) product<NRT, false>(Mx + (size_t)(1 + mu) * op.msize, nt, n, Vb + (size_t)yf * n * NB, col0, 1.f, aR, aI);
+    if (face & (1u << mu)) {
+      // across an aggregate face -- possibly across the process boundary: then the neighbour's batch came with the halo
+      const float2* By = yf >= 0 ? Vb + (size_t)yf * n * NB : halo.recv + ((size_t)halo.off[mu] + (size_t)(-1 - yf)) * n * NB;
+      product<NRT, false>(Mx + (size_t)(1 + mu) * op.msize, nt, n, By, col0, 1.f, aR, aI);
+    }
     else product<NRT, false>(Mx + (size_t)(1 + mu) * op.msize, nt, n, Vb + (size_t)yf * n * NB, col0, -1.f, a0R, a0I);
     store_tile<NRT>(out + (size_t)(1 + mu) * out_stride + (size_t)x * n * NB, n, col0, aR, aI);
     if (!(face & (1u << (4 + mu))))
@@ -141,13 +149,18 @@ void coarse_galerkin_batched(CoarseOp<float>& next, const CoarseOp<float>& op, c
   float2* Vb = reinterpret_cast<float2*>(work);
   float2* Y = Vb + bs;
   hipLaunchKernelGGL(batch_input_kernel, dim3((unsigned)((bs + 255) / 256)), dim3(256), 0, st, Vb, ip.P, ip.pstride, V, n, N);
+  BatchHalo halo{nullptr, {0, 0, 0, 0}};
+  if (op.distributed()) {
+    halo.recv = reinterpret_cast<const float2*>(op.wide_halo_exchange(Vb, sizeof(float2) * (size_t)n * NB, st));
+    for (int mu = 0; mu < 4; mu++) halo.off[mu] = op.wide_site_offset(mu);
+  }
   const CoarseOpDev<float> dev = op.dev();
   const int nrt = (n + 15) / 16;
   switch (nrt) {
-    case 1: hipLaunchKernelGGL((coarse_batch_apply_kernel<1>), dim3(V), dim3(256), 0, st, Y, bs, Vb, dev, d_agg_face); break;
-    case 2: hipLaunchKernelGGL((coarse_batch_apply_kernel<2>), dim3(V), dim3(256), 0, st, Y, bs, Vb, dev, d_agg_face); break;
-    case 3: hipLaunchKernelGGL((coarse_batch_apply_kernel<3>), dim3(V), dim3(256), 0, st, Y, bs, Vb, dev, d_agg_face); break;
-    default: hipLaunchKernelGGL((coarse_batch_apply_kernel<4>), dim3(V), dim3(256), 0, st, Y, bs, Vb, dev, d_agg_face); break;
+    case 1: hipLaunchKernelGGL((coarse_batch_apply_kernel<1>), dim3(V), dim3(256), 0, st, Y, bs, Vb, dev, d_agg_face, halo); break;
+    case 2: hipLaunchKernelGGL((coarse_batch_apply_kernel<2>), dim3(V), dim3(256), 0, st, Y, bs, Vb, dev, d_agg_face, halo); break;
+    case 3: hipLaunchKernelGGL((coarse_batch_apply_kernel<3>), dim3(V), dim3(256), 0, st, Y, bs, Vb, dev, d_agg_face, halo); break;
+    default: hipLaunchKernelGGL((coarse_batch_apply_kernel<4>), dim3(V), dim3(256), 0, st, Y, bs, Vb, dev, d_agg_face, halo); break;
   }
   DDAMG_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(coarse_batch_restrict_store_kernel, dim3(ip.num_aggs, 5), dim3(256), 0, st, next.matrices(), next.nt(), next.msize(), Y, bs,

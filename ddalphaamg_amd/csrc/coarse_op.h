@@ -55,6 +55,11 @@ class CoarseOp {
     return d;
   }
   void set_comm(Comm* c) { comm_ = c; }
+  // halo exchange of a WIDE per-site payload (row_bytes per site of `src`, a multiple of 16: the n x 64 batch of the coarse
+  // Galerkin construction): returns the receive arena; what the neighbour in direction d sent for my face site with slot s
+  // (nb = -1 - s) starts at row wide_site_offset(d) + s.  Blocking in stream order (setup path).
+  const char* wide_halo_exchange(const void* src, size_t row_bytes, hipStream_t st) const;
+  int wide_site_offset(int d) const { return wide_arena_.site_offset(d); }
   bool distributed() const { return arena_.active(); }
   // fill the receive buffers from `in` (every routine below that includes hopping terms does this itself)
   void halo_exchange(const T* in, hipStream_t st) const;
@@ -98,6 +103,9 @@ class CoarseOp {
   int V_ = 0, n_ = 0, nt_ = 0;
   size_t msize_ = 0;
   mutable HaloArena arena_;
+  mutable HaloArena wide_arena_;      // created at the first wide_halo_exchange
+  mutable size_t wide_row_bytes_ = 0;
+  const Geometry* geom_ = nullptr;
   Comm* comm_ = nullptr;
   // on a process grid: sites without / with a neighbour on another process (sorted), for the overlap of the exchange with
   // the interior work (the reference's ghost_sendrecv ... interior hopping terms ... ghost_wait, src/coarse_oddeven_generic.c:

@@ -481,6 +481,30 @@ __global__ void coarse_halo_pack_kernel(T* __restrict__ send, const T* __restric
   }
 }
 
+// rows of 16-byte units: dst row i <- src row face_sites[i]
+__global__ __launch_bounds__(256) void gather_face_rows_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, const int* __restrict__ face_sites,
+                                                               size_t row16, size_t total16) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total16; e += (size_t)gridDim.x * 256) {
+    const size_t i = e / row16, k = e - i * row16;
+    dst[e] = src[(size_t)face_sites[i] * row16 + k];
+  }
+}
+template <typename T>
+const char* CoarseOp<T>::wide_halo_exchange(const void* src, size_t row_bytes, hipStream_t st) const {
+  DDAMG_REQUIRE(arena_.active() && geom_ != nullptr, "wide halo exchange on an undivided lattice");
+  DDAMG_REQUIRE(row_bytes % 16 == 0, "wide halo rows must be multiples of 16 bytes");
+  if (!wide_arena_.active()) { wide_arena_.init(*geom_, row_bytes); wide_row_bytes_ = row_bytes; }
+  DDAMG_REQUIRE(wide_row_bytes_ == row_bytes, "wide halo exchange: the payload size of a level does not change");
+  const size_t row16 = row_bytes / 16, total16 = row16 * (size_t)wide_arena_.total_sites();
+  hipLaunchKernelGGL(gather_face_rows_kernel, dim3((unsigned)std::min<size_t>((total16 + 255) / 256, 8192)), dim3(256), 0, st,
+                     reinterpret_cast<uint4*>(wide_arena_.send()), reinterpret_cast<const uint4*>(src), wide_arena_.d_face_sites(), row16, total16);
+  DDAMG_HIP_CHECK(hipGetLastError());
+  wide_arena_.mark_packed(st);
+  wide_arena_.exchange_begin(comm_, st);
+  wide_arena_.exchange_finish(comm_, st);
+  return wide_arena_.recv();
+}
+
 template <typename T>
 void CoarseOp<T>::halo_exchange(const T* in, hipStream_t st) const {
   if (!arena_.active()) return;
@@ -703,6 +727,7 @@ template <typename T> CoarseOp<T>::~CoarseOp() {
 }
 template <typename T>
 void CoarseOp<T>::alloc(const Geometry& g, int n) {
+  geom_ = &g;
   V_ = g.V; n_ = n; nt_ = (n + 7) / 8; msize_ = (size_t)nt_ * nt_ * 64;
   DDAMG_REQUIRE(n % 2 == 0 && nt_ <= 8, "coarse dof per site must be even and at most 64");
   DDAMG_HIP_CHECK(device_alloc(&M_, sizeof(T) * 2 * msize_ * 5 * V_));

@@ -82,7 +82,12 @@ inline hipError_t create_cu_masked_stream(hipStream_t* st, int n_reserved, bool 
   }
   return hipExtStreamCreateWithCUMask(st, (uint32_t)words, mask);
 }
-inline int comm_cus_from_env() { const char* e = getenv("DDAMG_COMM_CUS"); return e ? atoi(e) : 24; }
+// Default, measured on the rehearsed 8-GPU problem (tools/gpu/comm_cus.sh, three self-exchanged directions at 32^3 x 64):
+// the fine operator ALONE is faster with 24 reserved CUs (185 against 213 us per apply: its transport kernel does not queue
+// behind the interior tiles), the multigrid solve as a whole is faster on plain streams (106.7 against 117 ms per solve, setup
+// 2.36 against 2.66 s: every kernel of a CU-masked stream pays for the mask, whatever the number of CUs).  So contexts without
+// a hierarchy (operator, pure Krylov methods) reserve 24 CUs, multigrid contexts none; DDAMG_COMM_CUS overrides both.
+inline int comm_cus_for(int num_levels) { const char* e = getenv("DDAMG_COMM_CUS"); return e ? atoi(e) : (num_levels <= 1 ? 24 : 0); }
 
 
 enum { DIR_T = 0, DIR_Z = 1, DIR_Y = 2, DIR_X = 3 };  // reference src/clifford.h:33

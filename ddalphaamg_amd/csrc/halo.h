@@ -24,8 +24,9 @@ struct HaloDev {
 
 struct Comm;  // transport state (RCCL communicator or host callback), shared by both precisions
 
-Comm* comm_create_rccl(const Geometry& g, const void* id128);
-Comm* comm_create_host(const Geometry& g, ddamg_hip_exchange_fn fn, ddamg_hip_allreduce_fn reduce_fn, void* user);
+// comm_cus: compute units reserved for the transport stream (0: a plain high-priority stream), see common.h comm_cus_for
+Comm* comm_create_rccl(const Geometry& g, const void* id128, int comm_cus);
+Comm* comm_create_host(const Geometry& g, ddamg_hip_exchange_fn fn, ddamg_hip_allreduce_fn reduce_fn, void* user, int comm_cus);
 void comm_destroy(Comm* c);
 void rccl_unique_id(void* id128);
 // host-buffer primitives over either transport (setup-time exchanges such as the gauge-field halo): blocking

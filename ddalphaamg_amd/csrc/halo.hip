@@ -24,6 +24,7 @@ struct Comm {
   ddamg_hip_allreduce_fn reduce_fn = nullptr;
   void* user = nullptr;
   int rank = 0, nranks = 1;
+  int comm_cus = 0;                             // compute units reserved for this transport's streams
   hipEvent_t ev_a = nullptr, ev_b = nullptr;   // ordering between the compute stream and the transport stream
   // split-phase reductions (pipelined Arnoldi): a communicator, stream and event pair of their own, so that a global sum in
   // flight does not queue in front of the halo exchange of the operator application it is meant to hide behind
@@ -95,7 +96,7 @@ void comm_allreduce(Comm* c, double* d_buf, int n, hipStream_t st) {
   }
 }
 
-static void create_transport_stream(hipStream_t* st);
+static void create_transport_stream(hipStream_t* st, int comm_cus);
 void comm_allreduce_begin(Comm* c, double* d_buf, int n, hipStream_t st) {
   if (!c || c->kind != 1) return;
   if (!c->red_tried) {
@@ -105,7 +106,7 @@ void comm_allreduce_begin(Comm* c, double* d_buf, int n, hipStream_t st) {
     ncclComm_t sub = nullptr;
     if (ncclCommSplit(c->nccl, 0, c->rank, &sub, nullptr) == ncclSuccess && sub) {
       c->nccl_red = sub;
-      create_transport_stream(&c->stream_red);
+      create_transport_stream(&c->stream_red, c->comm_cus);
       DDAMG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_ra, hipEventDisableTiming));
       DDAMG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_rb, hipEventDisableTiming));
     } else {
@@ -127,8 +128,8 @@ void comm_allreduce_end(Comm* c, double* d_buf, int n, hipStream_t st) {
 
 // the transport stream gets the highest priority: its (few, small) kernels must not queue behind the operator kernels
 // they overlap with
-static void create_transport_stream(hipStream_t* st) {
-  if (comm_cus_from_env() > 0) { DDAMG_HIP_CHECK(create_cu_masked_stream(st, comm_cus_from_env(), true)); return; }
+static void create_transport_stream(hipStream_t* st, int comm_cus) {
+  if (comm_cus > 0) { DDAMG_HIP_CHECK(create_cu_masked_stream(st, comm_cus, true)); return; }
   int lo = 0, hi = 0;
   DDAMG_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
   DDAMG_HIP_CHECK(hipStreamCreateWithPriority(st, hipStreamNonBlocking, hi));
@@ -178,22 +179,24 @@ void rccl_unique_id(void* id128) {
   memcpy(id128, &id, sizeof id);
 }
 
-Comm* comm_create_rccl(const Geometry& g, const void* id128) {
+Comm* comm_create_rccl(const Geometry& g, const void* id128, int comm_cus) {
   Comm* c = new Comm;
   c->kind = 1; c->rank = g.rank; c->nranks = g.nranks;
   ncclUniqueId id;
   memcpy(&id, id128, sizeof id);
-  create_transport_stream(&c->stream);
+  c->comm_cus = comm_cus;
+  create_transport_stream(&c->stream, comm_cus);
   DDAMG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming));
   DDAMG_HIP_CHECK(hipEventCreateWithFlags(&c->ev_b, hipEventDisableTiming));
   DDAMG_NCCL_CHECK(ncclCommInitRank(&c->nccl, g.nranks, id, g.rank));
   return c;
 }
-Comm* comm_create_host(const Geometry& g, ddamg_hip_exchange_fn fn, ddamg_hip_allreduce_fn reduce_fn, void* user) {
+Comm* comm_create_host(const Geometry& g, ddamg_hip_exchange_fn fn, ddamg_hip_allreduce_fn reduce_fn, void* user, int comm_cus) {
   DDAMG_REQUIRE(fn != nullptr, "exchange callback is null");
   Comm* c = new Comm;
   c->kind = 2; c->rank = g.rank; c->nranks = g.nranks; c->fn = fn; c->reduce_fn = reduce_fn; c->user = user;
-  create_transport_stream(&c->stream);
+  c->comm_cus = comm_cus;
+  create_transport_stream(&c->stream, comm_cus);
   return c;
 }
 void comm_destroy(Comm* c) {

@@ -18,10 +18,10 @@ __device__ __forceinline__ void agg_hop_pair(const T* __restrict__ v, int chir, 
   {
     const int j = op.nb[(size_t)MU * V + s];
     T pn[24], U[18];
-    if (!DIST || j >= 0) {
-      load_site<T, 24>(v, V, j, pn);
-      mask_chirality<T>(pn, chir);
-    }
+    // (a neighbour on another process has no site here: the load reads this site instead and its value is not used -- a
+    // conditional load leaves pn partly undefined and the compiler then keeps it in scratch memory: 975 against 571 us)
+    load_site<T, 24>(v, V, (DIST && j < 0) ? s : (size_t)j, pn);
+    mask_chirality<T>(pn, chir);
     load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, s, U);
     if (face & (1u << MU)) {
       T acc[24];
