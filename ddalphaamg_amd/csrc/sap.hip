@@ -826,7 +826,13 @@ void SapSmoother<T>::launch(int color, int mode, unsigned skip_mask, const T* et
       p.faces_d_out = (face_out & 1) ? faces_d_ : nullptr;
       p.faces_x_out = (face_out & 2) ? faces_x_ : nullptr;
       const bool dist = op_->distributed();
-      if (dist && p.mode != MODE_NONE) {
+      static const bool no_split = getenv("DDAMG_SAP_NO_SPLIT") != nullptr;   // experiment: exchange first, then all blocks in one launch
+      if (dist && p.mode != MODE_NONE && no_split) {
+        op_->halo_begin(p.mode == MODE_FULLRES ? pio_.halo_src : latest, st);
+        op_->halo_finish(st);
+        p.blocks = d_color_blocks_[color]; p.nblocks = ncol_[color];
+        sap_pair_launch(p, true, st);
+      } else if (dist && p.mode != MODE_NONE) {
         op_->halo_begin(p.mode == MODE_FULLRES ? pio_.halo_src : latest, st);
         p.blocks = d_color_blocks_[color]; p.nblocks = ncol_interior_[color];
         sap_pair_launch(p, true, st);
