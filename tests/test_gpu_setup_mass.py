@@ -108,3 +108,39 @@ def test_mass_shift_on_the_device_equals_upload_and_rebuild(gold8, levels):
     _, cl_back = A.get_operator()
     assert np.max(np.abs(cl_back - cl0)) < 1e-15
     A.close(); B.close()
+
+
+@pytest.mark.parametrize("csw", [0.0, 1.0])
+def test_mass_shift_of_the_operator_alone_with_and_without_a_clover_term(gold8, csw):
+    """csw == 0: the reference's clover field is the 12 diagonal entries 4 + m0 only (src/dirac.c:41-43, shift_update_PRECISION adds to
+    them, src/dirac_generic.c:517-527); here the same kernel serves both cases.  Shifted context against one built at the new
+    mass: the same stored operator, the same applied operator in both precisions, the same odd-even smoother (the 6x6 inverses)."""
+    L = [8, 8, 8, 8]; V = 4096
+    U = gold8["gauge"]
+    phi = splitmix_uniform(V * 24, 6).reshape(V, 12, 2)
+    outs = []
+    for shifted in (True, False):
+        p = api.default_params(); p.num_levels = 2
+        for mu in range(4):
+            p.local_lattice[0][mu] = 8; p.block_lattice[0][mu] = 4; p.local_lattice[1][mu] = 2
+        p.num_vect[0] = 8; p.mixed_precision, p.method, p.odd_even = 1, 2, 1
+        p.m0, p.csw = (-0.3 if shifted else 0.15), csw
+        ctx = dd.Context(p)
+        ctx.set_gauge(U, anti_pbc=True)
+        if shifted:
+            ctx.shift_mass(0.15)
+        D, cl = ctx.get_operator()
+        res = [D, cl]
+        for prec in (32, 64):
+            x = ctx.vector(0, prec).upload(phi); y = ctx.vector(0, prec)
+            ctx.dirac_apply(y, x); res.append(y.download())
+        e = ctx.vector(0, 32).upload(phi); s = ctx.vector(0, 32)
+        ctx.smoother(s, e, 2, initial_guess_zero=True)
+        res.append(s.download())
+        outs.append(res)
+        ctx.close()
+    a, b = outs
+    assert np.array_equal(a[0], b[0]) and np.max(np.abs(a[1] - b[1])) < 1e-15
+    assert relerr(a[2], b[2]) < 1e-6 and relerr(a[3], b[3]) < 1e-14 and relerr(a[4], b[4]) < 1e-5
+    if csw == 0.0:
+        assert np.all(a[1][:, 12:, :] == 0.0) and np.allclose(a[1][:, :12, 0], 4.15)
