@@ -99,6 +99,29 @@ class FineOp {
 }  // namespace ddamg
 #include "dirac_device.h"
 namespace ddamg {
+// the link U_mu(s): 18 reals from the full storage, or 12 reals + the reconstruction of the third row
+//   row2 = sgn * 2 conj(row0 x row1)      (links hold U/2: |row| = 1/2, so conj(row0 x row1) = row2 / (2 sgn))
+template <typename T, int MU, bool CMP>
+__device__ __forceinline__ void load_link(const FineOpDev<T>& op, size_t V, size_t s, T (&U)[18]) {
+  if constexpr (!CMP) {
+    load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, s, U);
+  } else {
+    T r[12];
+    load_site<T, 12>(op.Dc + (size_t)MU * 12 * V, V, s, r);
+    const T sg = (T)2 * (T)op.Dsgn[(size_t)MU * V + s];
+#pragma unroll
+    for (int k = 0; k < 12; k++) U[k] = r[k];
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+      // c = a_{k1} b_{k2} - a_{k2} b_{k1}
+      const T cr = r[2 * k1] * r[6 + 2 * k2] - r[2 * k1 + 1] * r[6 + 2 * k2 + 1] - (r[2 * k2] * r[6 + 2 * k1] - r[2 * k2 + 1] * r[6 + 2 * k1 + 1]);
+      const T ci = r[2 * k1] * r[6 + 2 * k2 + 1] + r[2 * k1 + 1] * r[6 + 2 * k2] - (r[2 * k2] * r[6 + 2 * k1 + 1] + r[2 * k2 + 1] * r[6 + 2 * k1]);
+      U[12 + 2 * k] = sg * cr; U[12 + 2 * k + 1] = -sg * ci;
+    }
+  }
+}
+
 // couplings to a site on another GPU: the neighbour sent the projected half spinor (halo.h)
 template <typename T, int MU>
 __device__ __forceinline__ void halo_forward(const FineOpDev<T>& op, int slot, const T (&U)[18], T (&eta)[24]) {

@@ -63,6 +63,29 @@ Multigrid<T>::Multigrid(const ddamg_hip_params& par, const std::vector<const Geo
       else { if (par.method != 4) lv.csap.setup(g, &lv.cop, par.block_iter[d], par.method, st_); lv.cip.alloc(g, *geoms[d + 1], lv.n, lv.nvec); }
       DDAMG_HIP_CHECK(device_alloc(&lv.d_agg_face, g.V));
       DDAMG_HIP_CHECK(hipMemcpy(lv.d_agg_face, g.agg_face.data(), g.V, hipMemcpyHostToDevice));
+      if (d == 0) {
+        // the forward faces of an aggregate in compact form (AggFaces, transfer.h) -- where every aggregate has the same shape
+        // and site order (it has, with the aggregate -> block -> parity ordering, unless blocks of odd extent alternate)
+        const int as = lv.fip.agg_sites, nagg = lv.fip.num_aggs;
+        bool same = as > 0 && as < 65536 && (size_t)as * nagg == (size_t)g.V;
+        for (int s = 0; same && s < g.V; s++) same = (g.agg_face[s] & 0xF) == (g.agg_face[s % as] & 0xF);
+        if (same) {
+          std::vector<unsigned short> tab((size_t)4 * as, 0), list;
+          AggFaces& af = lv.agg_faces;
+          af.agg_sites = as;
+          for (int mu = 0; mu < 4; mu++) {
+            af.loff[mu] = (int)list.size();
+            for (int i = 0; i < as; i++)
+              if (g.agg_face[i] & (1u << mu)) { tab[(size_t)mu * as + i] = (unsigned short)(list.size() - af.loff[mu]); list.push_back((unsigned short)i); }
+            af.nface[mu] = (int)list.size() - af.loff[mu];
+          }
+          tab.insert(tab.end(), list.begin(), list.end());
+          DDAMG_HIP_CHECK(device_alloc(&lv.d_agg_tables, sizeof(unsigned short) * tab.size()));
+          DDAMG_HIP_CHECK(hipMemcpy(lv.d_agg_tables, tab.data(), sizeof(unsigned short) * tab.size(), hipMemcpyHostToDevice));
+          af.rank = lv.d_agg_tables;
+          af.list = lv.d_agg_tables + (size_t)4 * as;
+        }
+      }
       for (int mu = 0; mu < 4; mu++) {
         std::vector<unsigned char> m(g.V);
         for (int s = 0; s < g.V; s++) m[s] = g.agg_face[s] & (unsigned char)(1u << mu);
@@ -228,6 +251,7 @@ Multigrid<T>::~Multigrid() {
     for (int i = 0; i < 3; i++) if (lv.sbuf[i]) (void)hipFree(lv.sbuf[i]);
     for (int q = 0; q < 2; q++) if (lv.d_parity_sites[q]) (void)hipFree(lv.d_parity_sites[q]);
     if (lv.d_agg_face) (void)hipFree(lv.d_agg_face);
+    if (lv.d_agg_tables) (void)hipFree(lv.d_agg_tables);
     for (int mu = 0; mu < 4; mu++) if (lv.d_dir_mask[mu]) (void)hipFree(lv.d_dir_mask[mu]);
   }
   if (d_identity0_) (void)hipFree(d_identity0_);
@@ -550,6 +574,15 @@ void Multigrid<T>::build_coarse_operator(int l) {
     // batched form: D P for a whole batch of columns (5 fields each), then ONE restriction on the matrix cores
     const size_t ws = (size_t)24 * lv.g->V;             // one fine vector
     const size_t cs = (size_t)nx.g->V * nx.n * 2;       // one coarse vector
+    // the four forward parts of a column on the aggregate faces only (AggFaces, transfer.h): 2 instead of 5 fields per column
+    // to write and to restrict with 4^4 aggregates
+    static const bool no_compact = getenv("DDAMG_GALERKIN_FULL_FIELDS") != nullptr;
+    const AggFaces& af = lv.agg_faces;
+    const bool compact = !no_compact && 2 * N <= 64 && Interpolation<T>::restrict_compact_available(lv.fip.agg_sites, N, af);
+    const int nagg = lv.fip.num_aggs, as = lv.fip.agg_sites;
+    const size_t wcol = compact ? (size_t)24 * af.column_sites(nagg) : 5 * ws;          // one column of W, whole lattice
+    const size_t wcol_agg = compact ? (size_t)24 * af.column_sites(1) : (size_t)5 * 24 * as;   // ... one aggregate of it
+    const int max_batch = compact ? 64 : 256 / 5;
     // the batch workspace is allocated once per setup and kept until release_setup_workspace(): allocating and
     // freeing tens of GB for every build costs more than the build itself
     static const bool no_slab = getenv("DDAMG_GALERKIN_NO_SLABS") != nullptr;
@@ -557,28 +590,28 @@ void Multigrid<T>::build_coarse_operator(int l) {
       size_t free_b = 0, total_b = 0;
       DDAMG_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
       gal_batch_ = 2 * N;
-      while (gal_batch_ > 1 && (5 * gal_batch_ > 256 || sizeof(T) * 5 * gal_batch_ * (ws + cs) > free_b / 2)) gal_batch_ = (gal_batch_ + 1) / 2;
+      while (gal_batch_ > 1 && (gal_batch_ > max_batch || sizeof(T) * gal_batch_ * (wcol + 5 * cs) > free_b / 2)) gal_batch_ = (gal_batch_ + 1) / 2;
       gal_slab_aggs_ = 0;
       const char* force_slab = getenv("DDAMG_GALERKIN_SLAB_AGGS");   // tests: slabs of this many aggregates at any volume
-      if ((gal_batch_ < 2 * N || force_slab) && 5 * 2 * N <= 256 && !lv.fop->distributed() && !no_slab) {
+      if ((gal_batch_ < 2 * N || force_slab) && 2 * N <= max_batch && !lv.fop->distributed() && !no_slab) {
         // all columns do not fit next to each other for the whole lattice.  Fewer columns per pass starve the N dimension
         // of the restriction GEMM (64^4: 6 of 48 columns, 30 of 240 fields, 4x the time); instead keep ALL columns and walk
         // the lattice in slabs of whole aggregates -- D P and its restriction are local to an aggregate
-        const size_t per_agg = sizeof(T) * 5 * 2 * N * 24 * (size_t)lv.fip.agg_sites;
+        const size_t per_agg = sizeof(T) * 2 * N * wcol_agg;
         const size_t coarse_b = sizeof(T) * 5 * 2 * N * cs;           // gal_C_: all columns on the coarse lattice
         DDAMG_REQUIRE(coarse_b + per_agg < free_b, "Galerkin construction: not enough device memory for the coarse columns and one aggregate of fields");
         // half of the free memory for the two buffers where that leaves room for at least one aggregate, else what is left
         // after the coarse columns (unsigned arithmetic: never subtract past zero)
         const size_t budget = free_b / 2 > coarse_b + per_agg ? free_b / 2 - coarse_b : free_b - coarse_b - (free_b - coarse_b) / 8;
-        gal_slab_aggs_ = (int)std::min<size_t>((size_t)lv.fip.num_aggs, std::max<size_t>(1, budget / per_agg));
-        if (force_slab) gal_slab_aggs_ = std::max(1, std::min(atoi(force_slab), lv.fip.num_aggs));
+        gal_slab_aggs_ = (int)std::min<size_t>((size_t)nagg, std::max<size_t>(1, budget / per_agg));
+        if (force_slab) gal_slab_aggs_ = std::max(1, std::min(atoi(force_slab), nagg));
         DDAMG_REQUIRE(per_agg * (size_t)gal_slab_aggs_ + coarse_b < free_b, "Galerkin construction: slab workspace does not fit the free device memory");
         gal_batch_ = 2 * N;
         DDAMG_HIP_CHECK(device_alloc(&gal_W_, per_agg * (size_t)gal_slab_aggs_));
         gal_W_elems_ = per_agg / sizeof(T) * (size_t)gal_slab_aggs_;
       } else {
-        DDAMG_HIP_CHECK(device_alloc(&gal_W_, sizeof(T) * 5 * gal_batch_ * ws));
-        gal_W_elems_ = (size_t)5 * gal_batch_ * ws;
+        DDAMG_HIP_CHECK(device_alloc(&gal_W_, sizeof(T) * gal_batch_ * wcol));
+        gal_W_elems_ = (size_t)gal_batch_ * wcol;
       }
       DDAMG_HIP_CHECK(device_alloc(&gal_C_, sizeof(T) * 5 * gal_batch_ * cs));
       gal_C_elems_ = (size_t)5 * gal_batch_ * cs;
@@ -586,21 +619,32 @@ void Multigrid<T>::build_coarse_operator(int l) {
     const int batch = gal_batch_;
     T *Wb = gal_W_, *Cb = gal_C_;
     if (gal_slab_aggs_ > 0) {
-      const int nagg = lv.fip.num_aggs, as = lv.fip.agg_sites;
       for (int a0 = 0; a0 < nagg; a0 += gal_slab_aggs_) {
         const int na = std::min(gal_slab_aggs_, nagg - a0);
         const size_t wss = (size_t)24 * na * as;        // one field of this slab
-        for (int c = 0; c < 2 * N; c++)
-          aggregate_dirac_slab<T>(Wb + (size_t)5 * c * wss, lv.fip.interp_vector(c % N), c / N, *lv.fop, lv.d_agg_face, (size_t)a0 * as, (size_t)na * as, st_);
-        lv.fip.restrict_batch_slab(Cb, cs, Wb, wss, 5 * 2 * N, a0, na, st_);
+        if (compact) {
+          for (int c = 0; c < 2 * N; c++)
+            aggregate_dirac_compact<T>(Wb + (size_t)c * na * wcol_agg, lv.fip.interp_vector(c % N), c / N, *lv.fop, lv.d_agg_face, af, a0, na, st_);
+          lv.fip.restrict_batch_compact(Cb, cs, Wb, 2 * N, af, a0, na, st_);
+        } else {
+          for (int c = 0; c < 2 * N; c++)
+            aggregate_dirac_slab<T>(Wb + (size_t)5 * c * wss, lv.fip.interp_vector(c % N), c / N, *lv.fop, lv.d_agg_face, (size_t)a0 * as, (size_t)na * as, st_);
+          lv.fip.restrict_batch_slab(Cb, cs, Wb, wss, 5 * 2 * N, a0, na, st_);
+        }
       }
       for (int c = 0; c < 2 * N; c++) galerkin_store_column<T>(nx.cop, Cb + (size_t)5 * c * cs, c, st_);
     } else
     for (int c0 = 0; c0 < 2 * N; c0 += batch) {
       const int nb = std::min(batch, 2 * N - c0);
-      for (int c = 0; c < nb; c++)
-        aggregate_dirac<T>(Wb + (size_t)5 * c * ws, lv.fip.interp_vector((c0 + c) % N), (c0 + c) / N, *lv.fop, lv.d_agg_face, st_);
-      lv.fip.restrict_batch(Cb, cs, Wb, ws, 5 * nb, st_);
+      if (compact) {
+        for (int c = 0; c < nb; c++)
+          aggregate_dirac_compact<T>(Wb + (size_t)c * wcol, lv.fip.interp_vector((c0 + c) % N), (c0 + c) / N, *lv.fop, lv.d_agg_face, af, 0, nagg, st_);
+        lv.fip.restrict_batch_compact(Cb, cs, Wb, nb, af, 0, nagg, st_);
+      } else {
+        for (int c = 0; c < nb; c++)
+          aggregate_dirac<T>(Wb + (size_t)5 * c * ws, lv.fip.interp_vector((c0 + c) % N), (c0 + c) / N, *lv.fop, lv.d_agg_face, st_);
+        lv.fip.restrict_batch(Cb, cs, Wb, ws, 5 * nb, st_);
+      }
       for (int c = 0; c < nb; c++) galerkin_store_column<T>(nx.cop, Cb + (size_t)5 * c * cs, c0 + c, st_);
     }
   } else if (l == 0) {

@@ -50,6 +50,8 @@ struct MGLevel {
   int n_parity_sites[2] = {0, 0};
   // setup helpers
   unsigned char* d_agg_face = nullptr;
+  AggFaces agg_faces;                    // depth 0: the forward faces of an aggregate in compact form (Galerkin construction)
+  unsigned short* d_agg_tables = nullptr;
   unsigned char* d_dir_mask[4] = {nullptr, nullptr, nullptr, nullptr};
   std::vector<int> ref_order;   // site visited i-th by the reference's vector loops on this level
 };

@@ -20,6 +20,12 @@ void aggregate_dirac(T* W, const T* v, int chir, const FineOp<T>& op, const unsi
 template <typename T>
 void aggregate_dirac_slab(T* W, const T* v, int chir, const FineOp<T>& op, const unsigned char* d_agg_face, size_t site0, size_t nsites, hipStream_t st);
 
+// the same for the aggregates [agg0, agg0 + naggs) with the four forward parts kept on the aggregate faces only: W is one
+// column in the layout of AggFaces (transfer.h) -- self part on all sites, then the forward part of direction mu on the sites
+// whose forward neighbour in mu lies in another aggregate.  2/5 of the bytes of the full form (4^4 aggregates).
+template <typename T>
+void aggregate_dirac_compact(T* W, const T* v, int chir, const FineOp<T>& op, const unsigned char* d_agg_face, const AggFaces& af, int agg0, int naggs, hipStream_t st);
+
 // column `col` of the five coarse matrices of every coarse site <- P^H W[part]
 template <typename T>
 void galerkin_column(CoarseOp<T>& cop, const Interpolation<T>& ip, const T* W, int col, T* work, hipStream_t st);

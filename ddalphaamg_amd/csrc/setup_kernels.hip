@@ -10,10 +10,12 @@ __device__ __forceinline__ void mask_chirality(T (&v)[24], int chir) {
   for (int k = 0; k < 12; k++) v[12 * (1 - chir) + k] = 0;
 }
 
-// W holds the sites [w0site, w0site + Vw) of the lattice only (Vw == V, w0site == 0: the whole lattice)
-template <typename T, int MU, bool DIST>
+// W holds the sites [w0site, w0site + Vw) of the lattice only (Vw == V, w0site == 0: the whole lattice).
+// COMPACT: the forward part of direction MU is kept on the face sites only (AggFaces: aggregate `wagg` of W, local site `li`)
+template <typename T, int MU, bool DIST, bool COMPACT>
 __device__ __forceinline__ void agg_hop_pair(const T* __restrict__ v, int chir, const FineOpDev<T>& op, const unsigned char face,
-                                             size_t s, T (&w0)[24], T* __restrict__ W, size_t wstride, size_t Vw, size_t w0site) {
+                                             size_t s, T (&w0)[24], T* __restrict__ W, size_t wstride, size_t Vw, size_t w0site,
+                                             const AggFaces& af, size_t wagg, int li, size_t naggs) {
   const size_t V = op.V;
   {
     const int j = op.nb[(size_t)MU * V + s];
@@ -34,13 +36,19 @@ __device__ __forceinline__ void agg_hop_pair(const T* __restrict__ v, int chir, 
       hop_accumulate<T, MU, true>(U, pn, acc);  // acc = -hop
 #pragma unroll
       for (int k = 0; k < 24; k++) acc[k] = -acc[k];
-      store_site<T, 24>(W + (size_t)(1 + MU) * wstride, Vw, s - w0site, acc);
+      if constexpr (COMPACT)
+        store_site<T, 24>(W + (size_t)24 * af.part_offset_sites(1 + MU, naggs), naggs * (size_t)af.nface[MU],
+                          wagg * (size_t)af.nface[MU] + af.rank[MU * af.agg_sites + li], acc);
+      else
+        store_site<T, 24>(W + (size_t)(1 + MU) * wstride, Vw, s - w0site, acc);
     } else {
       hop_accumulate<T, MU, true>(U, pn, w0);
-      T z[24];
+      if constexpr (!COMPACT) {
+        T z[24];
 #pragma unroll
-      for (int k = 0; k < 24; k++) z[k] = 0;
-      store_site<T, 24>(W + (size_t)(1 + MU) * wstride, Vw, s - w0site, z);
+        for (int k = 0; k < 24; k++) z[k] = 0;
+        store_site<T, 24>(W + (size_t)(1 + MU) * wstride, Vw, s - w0site, z);
+      }
     }
   }
   if (!(face & (1u << (4 + MU)))) {
@@ -53,14 +61,21 @@ __device__ __forceinline__ void agg_hop_pair(const T* __restrict__ v, int chir, 
   }
 }
 
-template <typename T, bool DIST>
+template <typename T, bool DIST, bool COMPACT>
 __global__ __launch_bounds__(256) void aggregate_dirac_kernel(T* __restrict__ W, const T* __restrict__ v, int chir, FineOpDev<T> op,
-                                                              const unsigned char* __restrict__ agg_face, size_t w0site, size_t Vw) {
+                                                              const unsigned char* __restrict__ agg_face, size_t w0site, size_t Vw, AggFaces af) {
   const size_t s = w0site + (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t V = op.V;
   if (s >= w0site + Vw) return;
   const size_t ws = (size_t)24 * Vw;
   const unsigned char face = agg_face[s];
+  size_t wagg = 0, naggs = 0;
+  int li = 0;
+  if constexpr (COMPACT) {
+    wagg = (s - w0site) / (size_t)af.agg_sites;
+    li = (int)((s - w0site) - wagg * (size_t)af.agg_sites);
+    naggs = Vw / (size_t)af.agg_sites;
+  }
   T w0[24];
   {
     T p[24], cl[36];
@@ -70,11 +85,121 @@ __global__ __launch_bounds__(256) void aggregate_dirac_kernel(T* __restrict__ W,
     if (chir == 0) { load_site<T, 36>(op.clover, V, s, cl); herm6_mul<T>(cl, p, w0); }
     else { load_site<T, 36>(op.clover + (size_t)36 * V, V, s, cl); herm6_mul<T>(cl, p + 12, w0 + 12); }
   }
-  agg_hop_pair<T, 0, DIST>(v, chir, op, face, s, w0, W, ws, Vw, w0site);
-  agg_hop_pair<T, 1, DIST>(v, chir, op, face, s, w0, W, ws, Vw, w0site);
-  agg_hop_pair<T, 2, DIST>(v, chir, op, face, s, w0, W, ws, Vw, w0site);
-  agg_hop_pair<T, 3, DIST>(v, chir, op, face, s, w0, W, ws, Vw, w0site);
+  agg_hop_pair<T, 0, DIST, COMPACT>(v, chir, op, face, s, w0, W, ws, Vw, w0site, af, wagg, li, naggs);
+  agg_hop_pair<T, 1, DIST, COMPACT>(v, chir, op, face, s, w0, W, ws, Vw, w0site, af, wagg, li, naggs);
+  agg_hop_pair<T, 2, DIST, COMPACT>(v, chir, op, face, s, w0, W, ws, Vw, w0site, af, wagg, li, naggs);
+  agg_hop_pair<T, 3, DIST, COMPACT>(v, chir, op, face, s, w0, W, ws, Vw, w0site, af, wagg, li, naggs);
   store_site<T, 24>(W, Vw, s - w0site, w0);
+}
+
+// ---- the same on a 256-site tile through LDS (one process, face-compacted output) -----------------------------------
+// The gather form above fetches eight neighbour spinors and four neighbour links per site through the cache.  Here, as in
+// dirac_apply_lds_kernel (fine_op.hip), a workgroup keeps the chirality half of its 256 sites in LDS, every site multiplies
+// with its own four links only -- the forward term directly, the backward term as the product U^dagger (1 + gamma_mu) v(s)
+// handed to the site s + mu through LDS -- and only the forward neighbours across an aggregate face come from global
+// memory (a quarter of the sites per direction with 4^4 aggregates; a neighbour inside the aggregate but outside the tile
+// too, for aggregates larger than a tile).  CHIR is a template parameter so that the zero half of the input folds away.
+template <typename T, int MU, int CHIR, bool CMP>
+__device__ __forceinline__ void agg_tile_dir(const T* __restrict__ vh, const FineOpDev<T>& op, const unsigned face, size_t s, bool live, size_t tile0,
+                                             const T (&p)[24], T (&e)[24], const T* __restrict__ sp, T* __restrict__ hb,
+                                             T* __restrict__ W, const AggFaces& af, size_t wagg, int li, size_t naggs) {
+  const size_t V = op.V;
+  const int t = threadIdx.x;
+  T U[18];
+  if (live) load_link<T, MU, CMP>(op, V, s, U);
+  // (a) backward product for my +mu neighbour, if it belongs to my aggregate
+  if (live && !(face & (1u << MU))) {
+    T h[12], g[12];
+    spin_project<T, MU, +1>(p, h);
+    su3_mul_dag<T>(U, h, g);
+#pragma unroll
+    for (int c = 0; c < 12; c++) hb[c * 256 + t] = g[c];
+  }
+  // (b) forward term with my own link: into the self part, or -- across the face -- the forward part of direction mu
+  if (live) {
+    const size_t j = (size_t)op.nb[(size_t)MU * V + s];
+    T pn[24];
+#pragma unroll
+    for (int k = 0; k < 12; k++) pn[12 * (1 - CHIR) + k] = 0;
+    const bool in_tile = !(face & (1u << MU)) && j >= tile0 && j < tile0 + 256;
+    if (in_tile) {
+#pragma unroll
+      for (int c = 0; c < 12; c++) pn[12 * CHIR + c] = sp[c * 256 + (int)(j - tile0)];
+    } else {
+      T ph[12];
+      load_site<T, 12>(vh, V, j, ph);
+#pragma unroll
+      for (int c = 0; c < 12; c++) pn[12 * CHIR + c] = ph[c];
+    }
+    if (face & (1u << MU)) {
+      T acc[24];
+#pragma unroll
+      for (int k = 0; k < 24; k++) acc[k] = 0;
+      hop_accumulate<T, MU, true>(U, pn, acc);  // acc = -hop
+#pragma unroll
+      for (int k = 0; k < 24; k++) acc[k] = -acc[k];
+      store_site<T, 24>(W + (size_t)24 * af.part_offset_sites(1 + MU, naggs), naggs * (size_t)af.nface[MU],
+                        wagg * (size_t)af.nface[MU] + af.rank[MU * af.agg_sites + li], acc);
+    } else {
+      hop_accumulate<T, MU, true>(U, pn, e);
+    }
+  }
+  __syncthreads();
+  // (c) backward term inside the aggregate: the product of site s - mu (LDS), or from global memory outside the tile
+  if (live && !(face & (1u << (4 + MU)))) {
+    const size_t j = (size_t)op.nb[(size_t)(4 + MU) * V + s];
+    if (j >= tile0 && j < tile0 + 256) {
+      T g[12];
+#pragma unroll
+      for (int c = 0; c < 12; c++) g[c] = hb[c * 256 + (int)(j - tile0)];
+      spin_reconstruct_sub<T, MU, +1>(g, e);
+    } else {
+      T pn[24], ph[12], Un[18];
+      load_site<T, 12>(vh, V, j, ph);
+#pragma unroll
+      for (int c = 0; c < 12; c++) { pn[12 * CHIR + c] = ph[c]; pn[12 * (1 - CHIR) + c] = 0; }
+      load_link<T, MU, CMP>(op, V, j, Un);
+      hop_accumulate<T, MU, false>(Un, pn, e);
+    }
+  }
+  // no second barrier: the caller alternates between two hb buffers
+}
+
+template <typename T, int CHIR, bool CMP>
+__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) void aggregate_dirac_tile_kernel(T* __restrict__ W, const T* __restrict__ v, FineOpDev<T> op,
+                                                                                             const unsigned char* __restrict__ agg_face, size_t w0site, size_t Vw,
+                                                                                             AggFaces af) {
+  __shared__ T sp[12 * 256];
+  __shared__ T hb[2 * 12 * 256];
+  const size_t V = op.V;
+  const size_t tile0 = w0site + (size_t)blockIdx.x * 256;
+  const size_t s = tile0 + threadIdx.x;
+  const bool live = s < w0site + Vw;
+  const T* __restrict__ vh = v + (size_t)12 * CHIR * V;      // the chirality half: chunk rows 3 CHIR .. 3 CHIR + 2
+  unsigned face = 0;
+  size_t wagg = 0;
+  int li = 0;
+  const size_t naggs = Vw / (size_t)af.agg_sites;
+  T p[24], e[24];
+#pragma unroll
+  for (int k = 0; k < 24; k++) { p[k] = 0; e[k] = 0; }
+  if (live) {
+    face = agg_face[s];
+    wagg = (s - w0site) / (size_t)af.agg_sites;
+    li = (int)((s - w0site) - wagg * (size_t)af.agg_sites);
+    T ph[12], cl[36];
+    load_site<T, 12>(vh, V, s, ph);
+#pragma unroll
+    for (int c = 0; c < 12; c++) { p[12 * CHIR + c] = ph[c]; sp[c * 256 + threadIdx.x] = ph[c]; }
+    load_site<T, 36>(op.clover + (size_t)36 * CHIR * V, V, s, cl);
+    herm6_mul<T>(cl, p + 12 * CHIR, e + 12 * CHIR);
+  }
+  __syncthreads();
+  agg_tile_dir<T, 0, CHIR, CMP>(vh, op, face, s, live, tile0, p, e, sp, hb, W, af, wagg, li, naggs);
+  agg_tile_dir<T, 1, CHIR, CMP>(vh, op, face, s, live, tile0, p, e, sp, hb + 12 * 256, W, af, wagg, li, naggs);
+  agg_tile_dir<T, 2, CHIR, CMP>(vh, op, face, s, live, tile0, p, e, sp, hb, W, af, wagg, li, naggs);
+  agg_tile_dir<T, 3, CHIR, CMP>(vh, op, face, s, live, tile0, p, e, sp, hb + 12 * 256, W, af, wagg, li, naggs);
+  if (live) store_site<T, 24>(W, Vw, s - w0site, e);
 }
 
 template <typename T>
@@ -85,9 +210,9 @@ void aggregate_dirac(T* W, const T* v, int chir, const FineOp<T>& op, const unsi
     DDAMG_HIP_CHECK(hipMemcpyAsync(W + chir * half, v + chir * half, sizeof(T) * half, hipMemcpyDeviceToDevice, st));
     DDAMG_HIP_CHECK(hipMemsetAsync(W + (1 - chir) * half, 0, sizeof(T) * half, st));
     op.halo_exchange(W, st);
-    hipLaunchKernelGGL((aggregate_dirac_kernel<T, true>), dim3((op.V() + 255) / 256), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face, (size_t)0, (size_t)op.V());
+    hipLaunchKernelGGL((aggregate_dirac_kernel<T, true, false>), dim3((op.V() + 255) / 256), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face, (size_t)0, (size_t)op.V(), AggFaces{});
   } else {
-    hipLaunchKernelGGL((aggregate_dirac_kernel<T, false>), dim3((op.V() + 255) / 256), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face, (size_t)0, (size_t)op.V());
+    hipLaunchKernelGGL((aggregate_dirac_kernel<T, false, false>), dim3((op.V() + 255) / 256), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face, (size_t)0, (size_t)op.V(), AggFaces{});
   }
   DDAMG_HIP_CHECK(hipGetLastError());
 }
@@ -95,11 +220,39 @@ void aggregate_dirac(T* W, const T* v, int chir, const FineOp<T>& op, const unsi
 template <typename T>
 void aggregate_dirac_slab(T* W, const T* v, int chir, const FineOp<T>& op, const unsigned char* d_agg_face, size_t site0, size_t nsites, hipStream_t st) {
   DDAMG_REQUIRE(!op.distributed(), "the slab form of the Galerkin construction is a single-process path");
-  hipLaunchKernelGGL((aggregate_dirac_kernel<T, false>), dim3((unsigned)((nsites + 255) / 256)), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face, site0, nsites);
+  hipLaunchKernelGGL((aggregate_dirac_kernel<T, false, false>), dim3((unsigned)((nsites + 255) / 256)), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face, site0, nsites, AggFaces{});
   DDAMG_HIP_CHECK(hipGetLastError());
 }
 template void aggregate_dirac_slab<float>(float*, const float*, int, const FineOp<float>&, const unsigned char*, size_t, size_t, hipStream_t);
 template void aggregate_dirac_slab<double>(double*, const double*, int, const FineOp<double>&, const unsigned char*, size_t, size_t, hipStream_t);
+
+template <typename T>
+void aggregate_dirac_compact(T* W, const T* v, int chir, const FineOp<T>& op, const unsigned char* d_agg_face, const AggFaces& af, int agg0, int naggs, hipStream_t st) {
+  const size_t site0 = (size_t)agg0 * af.agg_sites, nsites = (size_t)naggs * af.agg_sites;
+  if (op.distributed()) {
+    DDAMG_REQUIRE(agg0 == 0 && nsites == (size_t)op.V(), "Galerkin construction on a process grid: whole lattice only");
+    // the self part of the column serves as scratch for the chirality-masked copy whose boundary is sent to the neighbours
+    const size_t half = (size_t)12 * op.V();
+    DDAMG_HIP_CHECK(hipMemcpyAsync(W + chir * half, v + chir * half, sizeof(T) * half, hipMemcpyDeviceToDevice, st));
+    DDAMG_HIP_CHECK(hipMemsetAsync(W + (1 - chir) * half, 0, sizeof(T) * half, st));
+    op.halo_exchange(W, st);
+    hipLaunchKernelGGL((aggregate_dirac_kernel<T, true, true>), dim3((unsigned)((nsites + 255) / 256)), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face, site0, nsites, af);
+  } else {
+    static const bool gather = getenv("DDAMG_AGGREGATE_DIRAC_GATHER") != nullptr;
+    const dim3 grid((unsigned)((nsites + 255) / 256));
+    if (gather) hipLaunchKernelGGL((aggregate_dirac_kernel<T, false, true>), grid, dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face, site0, nsites, af);
+    else if (op.links_compressed()) {
+      if (chir == 0) hipLaunchKernelGGL((aggregate_dirac_tile_kernel<T, 0, true>), grid, dim3(256), 0, st, W, v, op.dev(), d_agg_face, site0, nsites, af);
+      else hipLaunchKernelGGL((aggregate_dirac_tile_kernel<T, 1, true>), grid, dim3(256), 0, st, W, v, op.dev(), d_agg_face, site0, nsites, af);
+    } else {
+      if (chir == 0) hipLaunchKernelGGL((aggregate_dirac_tile_kernel<T, 0, false>), grid, dim3(256), 0, st, W, v, op.dev(), d_agg_face, site0, nsites, af);
+      else hipLaunchKernelGGL((aggregate_dirac_tile_kernel<T, 1, false>), grid, dim3(256), 0, st, W, v, op.dev(), d_agg_face, site0, nsites, af);
+    }
+  }
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+template void aggregate_dirac_compact<float>(float*, const float*, int, const FineOp<float>&, const unsigned char*, const AggFaces&, int, int, hipStream_t);
+template void aggregate_dirac_compact<double>(double*, const double*, int, const FineOp<double>&, const unsigned char*, const AggFaces&, int, int, hipStream_t);
 
 // work: 5 coarse AoS vectors [part][Vc][n]; write column `col` of matrix `part` of every coarse site
 template <typename T>

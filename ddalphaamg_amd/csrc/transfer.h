@@ -16,6 +16,28 @@
 
 namespace ddamg {
 
+// Aggregate faces in compact form, for the Galerkin construction (coarse_aggregate_neighbor_couplings,
+// src/coarse_operator_generic.c:238-285): the field of the forward couplings in direction mu applied to an interpolation vector
+// is zero away from the sites whose forward neighbour lies in another aggregate (1/4 of the sites of a 4^4 aggregate), so it
+// is kept -- and restricted -- on those sites only.  Every aggregate has the same shape and site order; rank[mu][i] is the
+// position of local site i among the face sites of direction mu in that order, list its inverse.
+struct AggFaces {
+  const unsigned short* rank = nullptr;   // device [4][agg_sites]
+  const unsigned short* list = nullptr;   // device, direction mu at list + loff[mu], nface[mu] entries
+  int agg_sites = 0;
+  int nface[4] = {0, 0, 0, 0};
+  int loff[4] = {0, 0, 0, 0};
+  __host__ __device__ bool valid() const { return rank != nullptr; }
+  // sites of one column (self part + four forward parts) for naggs aggregates, and where a part starts in it
+  __host__ __device__ size_t column_sites(size_t naggs) const { return naggs * (size_t)(agg_sites + nface[0] + nface[1] + nface[2] + nface[3]); }
+  __host__ __device__ size_t part_offset_sites(int part, size_t naggs) const {
+    size_t o = 0;
+    if (part > 0) o = agg_sites;
+    for (int mu = 0; mu + 1 < part; mu++) o += nface[mu];
+    return naggs * o;
+  }
+};
+
 template <typename T>
 struct Interpolation {
   int V = 0, nvec = 0, num_aggs = 0, agg_sites = 0;
@@ -41,6 +63,12 @@ struct Interpolation {
   // the same for the aggregates [agg0, agg0 + naggs): phi holds only their sites (fields of naggs*agg_sites sites)
   void restrict_batch_slab(T* phi_c, size_t out_stride, const T* phi, size_t in_stride, int nw, int agg0, int naggs, hipStream_t st) const;
   static bool restrict_batch_available(int agg_sites_, int nvec_) { return sizeof(T) == 4 && agg_sites_ % 16 == 0 && nvec_ <= 32; }
+  // the Galerkin construction's five fields of ncols <= 64 columns in face-compacted form (see AggFaces and transfer.hip)
+  void restrict_batch_compact(T* phi_c, size_t out_stride, const T* W, int ncols, const AggFaces& af, int agg0, int naggs, hipStream_t st) const;
+  static bool restrict_compact_available(int agg_sites_, int nvec_, const AggFaces& af) {
+    return restrict_batch_available(agg_sites_, nvec_) && af.valid() && af.agg_sites == agg_sites_ && af.nface[0] % 16 == 0 && af.nface[1] % 16 == 0 &&
+           af.nface[2] % 16 == 0 && af.nface[3] % 16 == 0;
+  }
   // phi (+)= P phi_c
   void interpolate(T* phi, const T* phi_c, bool add, hipStream_t st) const;
   // many coarse vectors at once (fp32, nrhs <= 32): out[w] = P phi_c[w].  P is read once for all of them -- the setup's

@@ -140,19 +140,41 @@ void Interpolation<T>::restrict5(T* phi_c, size_t out_stride, const T* phi, size
 // v_mfma_f32_32x32x2_f32: lane l supplies A[i = l&31][k = l>>5] and B[k = l>>5][j = l&31]; result register r of
 // lane l is row (r&3) + 8*(r>>2) + 4*(l>>5), column l&31.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-// KSPLIT (at most 32 fields: one column tile, the bootstrap's 24 right-hand sides): the four wavefronts share that tile and
-// split the K range of every block instead of owning column tiles; their partial tiles are added through LDS at the end
-template <bool KSPLIT>
+// The column sets ("parts") of one launch, one per blockIdx.y: where a part's field lies inside a column of W, how many
+// K-sites an aggregate has in it and which sites of the aggregate they are.  The ordinary restriction is one part with all
+// sites of the aggregate; the Galerkin construction's face-compacted fields (AggFaces) are four more parts with the face
+// sites only.
+struct RestrictParts {
+  size_t woff[5];   // offset (floats) of the part's field inside a column of W
+  size_t Vw[5];     // sites of that field in W (its chunk-row stride)
+  size_t ooff[5];   // offset (floats) of the part's result inside a column of out
+  int ksites[5];    // K-sites per aggregate
+  int loff[5];      // offset of the part's site list in site_list, -1: all sites of the aggregate in order
+};
+// NTL column tiles of 32: 8 -- wavefront v owns the tiles v and v+4; 1, 2, 4 -- 4/NTL wavefronts share a tile and split the K
+// range of every block instead (at most 32 fields: the bootstrap's 24 right-hand sides; 64: the 2*Nvec columns of one part of
+// the Galerkin construction); their partial tiles are added through LDS at the end in a fixed order
+template <int NTL>
 __global__ __launch_bounds__(256, 2) void restrict_mfma_kernel(float* __restrict__ out, size_t out_stride, const float* __restrict__ W, size_t wstride, int nw,
                                                               const float* __restrict__ P, size_t pstride, int nvec, int V, int agg_sites,
-                                                              const int* __restrict__ agg_csite, int a0, size_t Vw, size_t w0site) {
+                                                              const int* __restrict__ agg_csite, int a0, RestrictParts parts,
+                                                              const unsigned short* __restrict__ site_list) {
   constexpr int KS = 16;            // sites per K block
+  constexpr bool KSPLIT = NTL < 8;
+  constexpr int KP = KSPLIT ? 4 / NTL : 1;   // wavefronts per tile
   __shared__ float As[4 * KS][33];
   __shared__ float Bs[4 * KS][257];
-  // W holds the sites [w0site, w0site + Vw) only (the whole lattice: a0 = 0, Vw = V, w0site = 0)
+  const int part = blockIdx.y;
   const int a = a0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const size_t s0 = (size_t)a * agg_sites;
+  const int ksites = parts.ksites[part];
+  const unsigned short* __restrict__ list = parts.loff[part] >= 0 ? site_list + parts.loff[part] : nullptr;
+  const size_t Vw = parts.Vw[part];
+  W += parts.woff[part];
+  out += parts.ooff[part];
+  const size_t s0 = (size_t)a * agg_sites;                  // first site of the aggregate in P
+  const size_t w0 = (size_t)blockIdx.x * ksites;            // first K-site of the aggregate in W
   const int ntile = (nw + 31) >> 5;
+  const int my_tile = KSPLIT ? wv % NTL : 0, my_kpart = KSPLIT ? wv / NTL : 0;
   for (int e = tid; e < 4 * KS * 33; e += 256) (&As[0][0])[e] = 0.f;   // rows i >= nvec stay zero
   for (int h = 0; h < 2; h++) {
     f32x16 accR[2], accI[2];
@@ -160,20 +182,20 @@ __global__ __launch_bounds__(256, 2) void restrict_mfma_kernel(float* __restrict
     for (int t = 0; t < 2; t++)
 #pragma unroll
       for (int r = 0; r < 16; r++) { accR[t][r] = 0.f; accI[t][r] = 0.f; }
-    // K blocks of this chirality: (chunk row kk, 16 sites from sb).  The operands of block b+1 are requested from global
+    // K blocks of this chirality: (chunk row kk, 16 K-sites from sb).  The operands of block b+1 are requested from global
     // memory before the products of block b are issued, so that the loads travel behind the matrix instructions
-    const int nsb = agg_sites / KS, nblk = 3 * nsb;
-    constexpr int RB = KSPLIT ? 2 : 16;   // float4 of B per thread and block: 32 or 256 columns x 16 sites
+    const int nsb = ksites / KS, nblk = 3 * nsb;
+    constexpr int RB = 2 * NTL;           // float4 of B per thread and block: 32 * NTL columns x 16 sites
     float4 pa[2], pb[RB];
     auto fetch = [&](int b) {
       const int kk = 3 * h + b / nsb, sb = (b % nsb) * KS;
-      const size_t row = ((size_t)kk * V + s0 + sb) * 4;
-      const size_t wrow = ((size_t)kk * Vw + (s0 - w0site) + sb) * 4;
+      const size_t wrow = ((size_t)kk * Vw + w0 + sb) * 4;
 #pragma unroll
       for (int r = 0; r < 2; r++) {
         const int e = tid + 256 * r, i = e / KS, sl = e % KS;
         pa[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (i < nvec) pa[r] = *reinterpret_cast<const float4*>(P + (size_t)i * pstride + row + sl * 4);
+        const size_t site = s0 + (list ? (size_t)list[sb + sl] : (size_t)(sb + sl));
+        if (i < nvec) pa[r] = *reinterpret_cast<const float4*>(P + (size_t)i * pstride + ((size_t)kk * V + site) * 4);
       }
 #pragma unroll
       for (int r = 0; r < RB; r++) {
@@ -198,13 +220,13 @@ __global__ __launch_bounds__(256, 2) void restrict_mfma_kernel(float* __restrict
       __syncthreads();
       if (b + 1 < nblk) fetch(b + 1);
 #pragma unroll 1
-      for (int kp = KSPLIT ? (KS / 2) * wv : 0; kp < (KSPLIT ? (KS / 2) * (wv + 1) : 2 * KS); kp++) {
+      for (int kp = KSPLIT ? (2 * KS / KP) * my_kpart : 0; kp < (KSPLIT ? (2 * KS / KP) * (my_kpart + 1) : 2 * KS); kp++) {
         const int k = 2 * kp + (lane >> 5);
         const float aR = As[k][lane & 31];
         const float aI = (k & 1) ? As[k ^ 1][lane & 31] : -As[k ^ 1][lane & 31];
 #pragma unroll
         for (int t = 0; t < (KSPLIT ? 1 : 2); t++) {
-          const int tile = KSPLIT ? 0 : wv + 4 * t;
+          const int tile = KSPLIT ? my_tile : wv + 4 * t;
           if (tile < ntile) {
             const float bv = Bs[k][tile * 32 + (lane & 31)];
             accR[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(aR, bv, accR[t], 0, 0, 0);
@@ -214,32 +236,33 @@ __global__ __launch_bounds__(256, 2) void restrict_mfma_kernel(float* __restrict
       }
     }
     const size_t cbase = ((size_t)agg_csite[a] * 2 * nvec + (size_t)h * nvec) * 2;
-    if constexpr (KSPLIT) {
-      // the four partial tiles: through LDS (the B stage is free now), wavefront 0 adds them in a fixed order
+    if constexpr (KSPLIT && KP > 1) {
+      // the KP partial tiles of a column tile: through LDS (the B stage is free now), the first wavefront of the tile adds them
+      // in a fixed order
       float* scratch = &Bs[0][0];
       __syncthreads();
-      if (wv > 0) {
+      if (my_kpart > 0) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-          scratch[((wv - 1) * 32 + r) * 64 + lane] = accR[0][r];
-          scratch[((wv - 1) * 32 + 16 + r) * 64 + lane] = accI[0][r];
+          scratch[(((my_kpart - 1) * NTL + my_tile) * 32 + r) * 64 + lane] = accR[0][r];
+          scratch[(((my_kpart - 1) * NTL + my_tile) * 32 + 16 + r) * 64 + lane] = accI[0][r];
         }
       }
       __syncthreads();
-      if (wv == 0) {
+      if (my_kpart == 0) {
 #pragma unroll
         for (int r = 0; r < 16; r++)
 #pragma unroll
-          for (int w = 0; w < 3; w++) {
-            accR[0][r] += scratch[(w * 32 + r) * 64 + lane];
-            accI[0][r] += scratch[(w * 32 + 16 + r) * 64 + lane];
+          for (int w = 0; w < KP - 1; w++) {
+            accR[0][r] += scratch[((w * NTL + my_tile) * 32 + r) * 64 + lane];
+            accI[0][r] += scratch[((w * NTL + my_tile) * 32 + 16 + r) * 64 + lane];
           }
       }
     }
 #pragma unroll
     for (int t = 0; t < (KSPLIT ? 1 : 2); t++) {
-      const int col = KSPLIT ? (lane & 31) : (wv + 4 * t) * 32 + (lane & 31);
-      if (col < nw && (!KSPLIT || wv == 0)) {
+      const int col = KSPLIT ? my_tile * 32 + (lane & 31) : (wv + 4 * t) * 32 + (lane & 31);
+      if (col < nw && (!KSPLIT || my_kpart == 0)) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
           const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -253,14 +276,21 @@ __global__ __launch_bounds__(256, 2) void restrict_mfma_kernel(float* __restrict
   }
 }
 
+static RestrictParts whole_aggregates(size_t Vw, int agg_sites) {
+  RestrictParts p{};
+  p.woff[0] = 0; p.Vw[0] = Vw; p.ooff[0] = 0; p.ksites[0] = agg_sites; p.loff[0] = -1;
+  return p;
+}
+
 template <typename T>
 void Interpolation<T>::restrict_batch(T* phi_c, size_t out_stride, const T* phi, size_t in_stride, int nw, hipStream_t st) const {
   if constexpr (sizeof(T) == 4) {
     DDAMG_REQUIRE(restrict_batch_available(agg_sites, nvec) && nw >= 1 && nw <= 256, "batched restriction: unsupported shape");
-    if (nw <= 32) hipLaunchKernelGGL(restrict_mfma_kernel<true>, dim3(num_aggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
-                                     0, (size_t)V, (size_t)0);
-    else hipLaunchKernelGGL(restrict_mfma_kernel<false>, dim3(num_aggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
-                            0, (size_t)V, (size_t)0);
+    const RestrictParts parts = whole_aggregates((size_t)V, agg_sites);
+    if (nw <= 32) hipLaunchKernelGGL(restrict_mfma_kernel<1>, dim3(num_aggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
+                                     0, parts, (const unsigned short*)nullptr);
+    else hipLaunchKernelGGL(restrict_mfma_kernel<8>, dim3(num_aggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
+                            0, parts, (const unsigned short*)nullptr);
     DDAMG_HIP_CHECK(hipGetLastError());
   } else {
     DDAMG_REQUIRE(false, "batched restriction is an fp32 path");
@@ -270,8 +300,35 @@ template <typename T>
 void Interpolation<T>::restrict_batch_slab(T* phi_c, size_t out_stride, const T* phi, size_t in_stride, int nw, int agg0, int naggs, hipStream_t st) const {
   if constexpr (sizeof(T) == 4) {
     DDAMG_REQUIRE(restrict_batch_available(agg_sites, nvec) && nw >= 1 && nw <= 256 && agg0 >= 0 && agg0 + naggs <= num_aggs, "batched restriction: unsupported shape");
-    hipLaunchKernelGGL(restrict_mfma_kernel<false>, dim3(naggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
-                       agg0, (size_t)naggs * agg_sites, (size_t)agg0 * agg_sites);
+    const RestrictParts parts = whole_aggregates((size_t)naggs * agg_sites, agg_sites);
+    hipLaunchKernelGGL(restrict_mfma_kernel<8>, dim3(naggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
+                       agg0, parts, (const unsigned short*)nullptr);
+    DDAMG_HIP_CHECK(hipGetLastError());
+  } else {
+    DDAMG_REQUIRE(false, "batched restriction is an fp32 path");
+  }
+}
+// The Galerkin construction's five fields per column in face-compacted form (AggFaces): column c of W is one region of
+// af.column_sites(naggs) sites, its self part over all sites of the aggregates [agg0, agg0 + naggs) followed by the four
+// forward parts over their face sites.  The five results of column c go to phi_c + (5c + part) * out_stride.
+template <typename T>
+void Interpolation<T>::restrict_batch_compact(T* phi_c, size_t out_stride, const T* W, int ncols, const AggFaces& af, int agg0, int naggs, hipStream_t st) const {
+  if constexpr (sizeof(T) == 4) {
+    DDAMG_REQUIRE(restrict_compact_available(agg_sites, nvec, af) && ncols >= 1 && ncols <= 64 && agg0 >= 0 && agg0 + naggs <= num_aggs,
+                  "compact batched restriction: unsupported shape");
+    RestrictParts parts{};
+    for (int p = 0; p < 5; p++) {
+      parts.woff[p] = (size_t)24 * af.part_offset_sites(p, naggs);
+      parts.Vw[p] = (size_t)naggs * (p == 0 ? af.agg_sites : af.nface[p - 1]);
+      parts.ooff[p] = (size_t)p * out_stride;
+      parts.ksites[p] = p == 0 ? af.agg_sites : af.nface[p - 1];
+      parts.loff[p] = p == 0 ? -1 : af.loff[p - 1];
+    }
+    const size_t wstride = (size_t)24 * af.column_sites(naggs);
+    if (ncols <= 32) hipLaunchKernelGGL(restrict_mfma_kernel<1>, dim3(naggs, 5), dim3(256), 0, st, phi_c, 5 * out_stride, W, wstride, ncols, P, pstride, nvec, V, agg_sites, agg_csite,
+                                        agg0, parts, af.list);
+    else hipLaunchKernelGGL(restrict_mfma_kernel<2>, dim3(naggs, 5), dim3(256), 0, st, phi_c, 5 * out_stride, W, wstride, ncols, P, pstride, nvec, V, agg_sites, agg_csite,
+                            agg0, parts, af.list);
     DDAMG_HIP_CHECK(hipGetLastError());
   } else {
     DDAMG_REQUIRE(false, "batched restriction is an fp32 path");
