@@ -576,7 +576,7 @@ void Multigrid<T>::build_coarse_operator(int l) {
     const size_t cs = (size_t)nx.g->V * nx.n * 2;       // one coarse vector
     // the four forward parts of a column on the aggregate faces only (AggFaces, transfer.h): 2 instead of 5 fields per column
     // to write and to restrict with 4^4 aggregates
-    static const bool no_compact = getenv("DDAMG_GALERKIN_FULL_FIELDS") != nullptr;
+    const bool no_compact = getenv("DDAMG_GALERKIN_FULL_FIELDS") != nullptr;   // read at every build: tests switch it within one process
     const AggFaces& af = lv.agg_faces;
     const bool compact = !no_compact && 2 * N <= 64 && Interpolation<T>::restrict_compact_available(lv.fip.agg_sites, N, af);
     const int nagg = lv.fip.num_aggs, as = lv.fip.agg_sites;

@@ -238,7 +238,7 @@ void aggregate_dirac_compact(T* W, const T* v, int chir, const FineOp<T>& op, co
     op.halo_exchange(W, st);
     hipLaunchKernelGGL((aggregate_dirac_kernel<T, true, true>), dim3((unsigned)((nsites + 255) / 256)), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face, site0, nsites, af);
   } else {
-    static const bool gather = getenv("DDAMG_AGGREGATE_DIRAC_GATHER") != nullptr;
+    const bool gather = getenv("DDAMG_AGGREGATE_DIRAC_GATHER") != nullptr;   // read at every call: tests switch it within one process
     const dim3 grid((unsigned)((nsites + 255) / 256));
     if (gather) hipLaunchKernelGGL((aggregate_dirac_kernel<T, false, true>), grid, dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face, site0, nsites, af);
     else if (op.links_compressed()) {

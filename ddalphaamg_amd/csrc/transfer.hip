@@ -155,24 +155,32 @@ struct RestrictParts {
 // range of every block instead (at most 32 fields: the bootstrap's 24 right-hand sides; 64: the 2*Nvec columns of one part of
 // the Galerkin construction); their partial tiles are added through LDS at the end in a fixed order
 template <int NTL>
-__global__ __launch_bounds__(256, 2) void restrict_mfma_kernel(float* __restrict__ out, size_t out_stride, const float* __restrict__ W, size_t wstride, int nw,
+__global__ __launch_bounds__(256, (NTL == 2 ? 4 : 2)) void restrict_mfma_kernel(float* __restrict__ out, size_t out_stride, const float* __restrict__ W, size_t wstride, int nw,
                                                               const float* __restrict__ P, size_t pstride, int nvec, int V, int agg_sites,
                                                               const int* __restrict__ agg_csite, int a0, RestrictParts parts,
-                                                              const unsigned short* __restrict__ site_list) {
+                                                              const unsigned short* __restrict__ site_list, int nparts, int naggs) {
   constexpr int KS = 16;            // sites per K block
   constexpr bool KSPLIT = NTL < 8;
   constexpr int KP = KSPLIT ? 4 / NTL : 1;   // wavefronts per tile
+  constexpr int BW = NTL == 2 ? 65 : 257;    // NTL == 2: 25 KB of LDS, four workgroups per CU (its 16 KB of partial tiles fit)
   __shared__ float As[4 * KS][33];
-  __shared__ float Bs[4 * KS][257];
-  const int part = blockIdx.y;
-  const int a = a0 + blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  __shared__ float Bs[4 * KS][BW];
+  // gridDim.y == 1: blockIdx.x = aggregate.  With `nparts` parts the workgroups of one aggregate are dealt to ONE XCD (ids 8
+  // apart within a group of 8 aggregates), so that the rows of P the parts share are read from HBM once
+  int part = 0, ai = blockIdx.x;
+  if (nparts > 1) {
+    const int grp = blockIdx.x / (8 * nparts), r = blockIdx.x % (8 * nparts);
+    part = r >> 3; ai = grp * 8 + (r & 7);
+    if (ai >= naggs) return;
+  }
+  const int a = a0 + ai, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int ksites = parts.ksites[part];
   const unsigned short* __restrict__ list = parts.loff[part] >= 0 ? site_list + parts.loff[part] : nullptr;
   const size_t Vw = parts.Vw[part];
   W += parts.woff[part];
   out += parts.ooff[part];
   const size_t s0 = (size_t)a * agg_sites;                  // first site of the aggregate in P
-  const size_t w0 = (size_t)blockIdx.x * ksites;            // first K-site of the aggregate in W
+  const size_t w0 = (size_t)ai * ksites;                    // first K-site of the aggregate in W
   const int ntile = (nw + 31) >> 5;
   const int my_tile = KSPLIT ? wv % NTL : 0, my_kpart = KSPLIT ? wv / NTL : 0;
   for (int e = tid; e < 4 * KS * 33; e += 256) (&As[0][0])[e] = 0.f;   // rows i >= nvec stay zero
@@ -219,7 +227,7 @@ __global__ __launch_bounds__(256, 2) void restrict_mfma_kernel(float* __restrict
       }
       __syncthreads();
       if (b + 1 < nblk) fetch(b + 1);
-#pragma unroll 1
+#pragma unroll (NTL == 2 ? 4 : 1)
       for (int kp = KSPLIT ? (2 * KS / KP) * my_kpart : 0; kp < (KSPLIT ? (2 * KS / KP) * (my_kpart + 1) : 2 * KS); kp++) {
         const int k = 2 * kp + (lane >> 5);
         const float aR = As[k][lane & 31];
@@ -288,9 +296,9 @@ void Interpolation<T>::restrict_batch(T* phi_c, size_t out_stride, const T* phi,
     DDAMG_REQUIRE(restrict_batch_available(agg_sites, nvec) && nw >= 1 && nw <= 256, "batched restriction: unsupported shape");
     const RestrictParts parts = whole_aggregates((size_t)V, agg_sites);
     if (nw <= 32) hipLaunchKernelGGL(restrict_mfma_kernel<1>, dim3(num_aggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
-                                     0, parts, (const unsigned short*)nullptr);
+                                     0, parts, (const unsigned short*)nullptr, 1, num_aggs);
     else hipLaunchKernelGGL(restrict_mfma_kernel<8>, dim3(num_aggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
-                            0, parts, (const unsigned short*)nullptr);
+                            0, parts, (const unsigned short*)nullptr, 1, num_aggs);
     DDAMG_HIP_CHECK(hipGetLastError());
   } else {
     DDAMG_REQUIRE(false, "batched restriction is an fp32 path");
@@ -302,7 +310,7 @@ void Interpolation<T>::restrict_batch_slab(T* phi_c, size_t out_stride, const T*
     DDAMG_REQUIRE(restrict_batch_available(agg_sites, nvec) && nw >= 1 && nw <= 256 && agg0 >= 0 && agg0 + naggs <= num_aggs, "batched restriction: unsupported shape");
     const RestrictParts parts = whole_aggregates((size_t)naggs * agg_sites, agg_sites);
     hipLaunchKernelGGL(restrict_mfma_kernel<8>, dim3(naggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
-                       agg0, parts, (const unsigned short*)nullptr);
+                       agg0, parts, (const unsigned short*)nullptr, 1, num_aggs);
     DDAMG_HIP_CHECK(hipGetLastError());
   } else {
     DDAMG_REQUIRE(false, "batched restriction is an fp32 path");
@@ -325,10 +333,11 @@ void Interpolation<T>::restrict_batch_compact(T* phi_c, size_t out_stride, const
       parts.loff[p] = p == 0 ? -1 : af.loff[p - 1];
     }
     const size_t wstride = (size_t)24 * af.column_sites(naggs);
-    if (ncols <= 32) hipLaunchKernelGGL(restrict_mfma_kernel<1>, dim3(naggs, 5), dim3(256), 0, st, phi_c, 5 * out_stride, W, wstride, ncols, P, pstride, nvec, V, agg_sites, agg_csite,
-                                        agg0, parts, af.list);
-    else hipLaunchKernelGGL(restrict_mfma_kernel<2>, dim3(naggs, 5), dim3(256), 0, st, phi_c, 5 * out_stride, W, wstride, ncols, P, pstride, nvec, V, agg_sites, agg_csite,
-                            agg0, parts, af.list);
+    const dim3 grid((unsigned)((naggs + 7) / 8 * 8 * 5));
+    if (ncols <= 32) hipLaunchKernelGGL(restrict_mfma_kernel<1>, grid, dim3(256), 0, st, phi_c, 5 * out_stride, W, wstride, ncols, P, pstride, nvec, V, agg_sites, agg_csite,
+                                        agg0, parts, af.list, 5, naggs);
+    else hipLaunchKernelGGL(restrict_mfma_kernel<2>, grid, dim3(256), 0, st, phi_c, 5 * out_stride, W, wstride, ncols, P, pstride, nvec, V, agg_sites, agg_csite,
+                            agg0, parts, af.list, 5, naggs);
     DDAMG_HIP_CHECK(hipGetLastError());
   } else {
     DDAMG_REQUIRE(false, "batched restriction is an fp32 path");

@@ -409,6 +409,33 @@ def test_slab_wise_galerkin_construction_is_the_same_operator(gold_b4, gold8, mo
     assert res[0][3:] == res[1][3:] and np.array_equal(res[0][2], res[1][2])
 
 
+@pytest.mark.parametrize("slabs", [None, "5"], ids=["whole-lattice", "slabs"])
+def test_face_compacted_galerkin_fields_give_the_same_operator(gold_b4, gold8, monkeypatch, slabs):
+    """the four forward parts of D P are zero away from the aggregate faces; the Galerkin construction keeps and restricts them
+    on the face sites only, and builds them on 256-site tiles through LDS.  Against the five full fields per column
+    (DDAMG_GALERKIN_FULL_FIELDS) and against the gather form of the field kernel (DDAMG_AGGREGATE_DIRAC_GATHER): the same
+    coarse operator up to the rounding of another summation order, the same solve"""
+    if slabs:
+        monkeypatch.setenv("DDAMG_GALERKIN_SLAB_AGGS", slabs)
+    res = []
+    for knob in (None, "DDAMG_GALERKIN_FULL_FIELDS", "DDAMG_AGGREGATE_DIRAC_GATHER"):
+        if knob:
+            monkeypatch.setenv(knob, "1")
+        ctx = make_ctx_b4(gold_b4, gold8)
+        ctx.setup(3)
+        Dc, clc = ctx.get_coarse_operator()
+        b = np.zeros((4096, 12, 2)); b[..., 0] = 1.0
+        x, it, cit, rr = ctx.solve(b, 1e-10)
+        res.append((Dc, clc, x, it, rr))
+        ctx.close()
+        if knob:
+            monkeypatch.delenv(knob)
+    for other in res[1:]:
+        assert relerr(res[0][0], other[0]) < 2e-5 and relerr(res[0][1], other[1]) < 2e-5
+        assert not np.array_equal(res[0][0], other[0])        # another code path did run
+        assert res[0][3] == other[3] and other[4] < 1e-10 and relerr(res[0][2], other[2]) < 1e-8
+
+
 def test_bootstrap_with_one_restriction_and_one_interpolation_for_all_test_vectors(gold_b4, gold8, monkeypatch):
     """the setup's bootstrap V-cycles of the fine level share their two passes over the interpolation operator (restriction
     on the matrix cores, batched interpolation).  Against the vector-by-vector form (DDAMG_BOOTSTRAP_UNBATCHED):
