@@ -155,14 +155,15 @@ struct RestrictParts {
 // range of every block instead (at most 32 fields: the bootstrap's 24 right-hand sides; 64: the 2*Nvec columns of one part of
 // the Galerkin construction); their partial tiles are added through LDS at the end in a fixed order
 template <int NTL>
-__global__ __launch_bounds__(256, (NTL == 2 ? 4 : 2)) void restrict_mfma_kernel(float* __restrict__ out, size_t out_stride, const float* __restrict__ W, size_t wstride, int nw,
+__global__ __launch_bounds__(256, (NTL == 2 ? 4 : NTL == 1 ? 3 : 2)) void restrict_mfma_kernel(float* __restrict__ out, size_t out_stride, const float* __restrict__ W, size_t wstride, int nw,
                                                               const float* __restrict__ P, size_t pstride, int nvec, int V, int agg_sites,
                                                               const int* __restrict__ agg_csite, int a0, RestrictParts parts,
                                                               const unsigned short* __restrict__ site_list, int nparts, int naggs) {
   constexpr int KS = 16;            // sites per K block
   constexpr bool KSPLIT = NTL < 8;
   constexpr int KP = KSPLIT ? 4 / NTL : 1;   // wavefronts per tile
-  constexpr int BW = NTL == 2 ? 65 : 257;    // NTL == 2: 25 KB of LDS, four workgroups per CU (its 16 KB of partial tiles fit)
+  // NTL == 2: 25 KB of LDS, four workgroups per CU (its 16 KB of partial tiles fit); NTL == 1: 33 KB, three (24 KB of partial tiles)
+  constexpr int BW = NTL == 2 ? 65 : NTL == 1 ? 97 : 257;
   __shared__ float As[4 * KS][33];
   __shared__ float Bs[4 * KS][BW];
   // gridDim.y == 1: blockIdx.x = aggregate.  With `nparts` parts the workgroups of one aggregate are dealt to ONE XCD (ids 8
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256, (NTL == 2 ? 4 : 2)) void restrict_mfma_kernel(
       }
       __syncthreads();
       if (b + 1 < nblk) fetch(b + 1);
-#pragma unroll (NTL == 2 ? 4 : 1)
+#pragma unroll (NTL <= 2 ? 4 : 1)
       for (int kp = KSPLIT ? (2 * KS / KP) * my_kpart : 0; kp < (KSPLIT ? (2 * KS / KP) * (my_kpart + 1) : 2 * KS); kp++) {
         const int k = 2 * kp + (lane >> 5);
         const float aR = As[k][lane & 31];
@@ -468,26 +469,35 @@ __device__ __forceinline__ void wg_allreduce(double (&v)[NV], double* red /* [NV
   }
 }
 
-// SPT = sites per thread (agg_sites <= 256*SPT)
-template <typename T, int SPT>
-__global__ void gs_aggregates_kernel(T* __restrict__ P, size_t pstride, int nvec, int V, int agg_sites) {
-  __shared__ double red[4 * 4];
+// SPT = sites per thread (agg_sites <= 256*SPT).  CB = columns per pass: the projections of CB consecutive columns on an
+// earlier vector u do not depend on each other, so u is read once for all of them and their CB coefficients are summed in one
+// workgroup reduction; the columns of a pass then finish among themselves in registers.  Every column sees the same operations
+// in the same order as one column per pass (CB = 1) -- results are bit-identical -- with 1/CB of the reads of the earlier
+// vectors, which is what bounds this kernel (CB = 1: 27 GB through the L2 at 32^4, Nvec 24).
+template <typename T, int SPT, int CB>
+__global__ __launch_bounds__(256) void gs_aggregates_kernel(T* __restrict__ P, size_t pstride, int nvec, int V, int agg_sites) {
+  __shared__ double red[4 * CB * 4];
   const int a = blockIdx.x, nt = blockDim.x, nw = nt >> 6;
   const size_t s0 = (size_t)a * agg_sites;
-  for (int k1 = 0; k1 < nvec; k1++) {
-    T v[SPT][24];
+  for (int k0 = 0; k0 < nvec; k0 += CB) {
+    T v[CB][SPT][24];
 #pragma unroll
-    for (int q = 0; q < SPT; q++) {
-      const int i = threadIdx.x + q * nt;
-      if (i < agg_sites) load_site<T, 24>(P + (size_t)k1 * pstride, V, s0 + i, v[q]);
-      else {
+    for (int c = 0; c < CB; c++)
 #pragma unroll
-        for (int k = 0; k < 24; k++) v[q][k] = 0;
+      for (int q = 0; q < SPT; q++) {
+        const int i = threadIdx.x + q * nt;
+        if (i < agg_sites && k0 + c < nvec) load_site<T, 24>(P + (size_t)(k0 + c) * pstride, V, s0 + i, v[c][q]);
+        else {
+#pragma unroll
+          for (int k = 0; k < 24; k++) v[c][q][k] = 0;
+        }
       }
-    }
-    for (int k2 = 0; k2 < k1; k2++) {
+    // projections on the vectors of the earlier passes
+    for (int k2 = 0; k2 < k0; k2++) {
       T u[SPT][24];
-      double al[4] = {0, 0, 0, 0};
+      double al[4 * CB];
+#pragma unroll
+      for (int k = 0; k < 4 * CB; k++) al[k] = 0;
 #pragma unroll
       for (int q = 0; q < SPT; q++) {
         const int i = threadIdx.x + q * nt;
@@ -497,45 +507,82 @@ __global__ void gs_aggregates_kernel(T* __restrict__ P, size_t pstride, int nvec
           for (int k = 0; k < 24; k++) u[q][k] = 0;
         }
 #pragma unroll
-        for (int h = 0; h < 2; h++)
+        for (int c = 0; c < CB; c++)
 #pragma unroll
-          for (int d = 0; d < 6; d++) {
-            const int k = 2 * (6 * h + d);
-            al[2 * h]     += (double)(u[q][k] * v[q][k] + u[q][k + 1] * v[q][k + 1]);
-            al[2 * h + 1] += (double)(u[q][k] * v[q][k + 1] - u[q][k + 1] * v[q][k]);
-          }
+          for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int d = 0; d < 6; d++) {
+              const int k = 2 * (6 * h + d);
+              al[4 * c + 2 * h]     += (double)(u[q][k] * v[c][q][k] + u[q][k + 1] * v[c][q][k + 1]);
+              al[4 * c + 2 * h + 1] += (double)(u[q][k] * v[c][q][k + 1] - u[q][k + 1] * v[c][q][k]);
+            }
       }
-      wg_allreduce<4>(al, red, nw);
+      wg_allreduce<4 * CB>(al, red, nw);
 #pragma unroll
-      for (int q = 0; q < SPT; q++)
+      for (int c = 0; c < CB; c++)
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const T ar = (T)al[2 * h], ai = (T)al[2 * h + 1];
+        for (int q = 0; q < SPT; q++)
 #pragma unroll
-          for (int d = 0; d < 6; d++) {
-            const int k = 2 * (6 * h + d);
-            v[q][k]     -= ar * u[q][k] - ai * u[q][k + 1];
-            v[q][k + 1] -= ar * u[q][k + 1] + ai * u[q][k];
+          for (int h = 0; h < 2; h++) {
+            const T ar = (T)al[4 * c + 2 * h], ai = (T)al[4 * c + 2 * h + 1];
+#pragma unroll
+            for (int d = 0; d < 6; d++) {
+              const int k = 2 * (6 * h + d);
+              v[c][q][k]     -= ar * u[q][k] - ai * u[q][k + 1];
+              v[c][q][k + 1] -= ar * u[q][k + 1] + ai * u[q][k];
+            }
           }
+    }
+    // the columns of this pass among themselves: column c on the finished columns c2 < c, then its norm
+#pragma unroll
+    for (int c = 0; c < CB; c++) {
+      if (k0 + c < nvec) {       // uniform
+#pragma unroll
+        for (int c2 = 0; c2 < c; c2++) {
+          double al[4] = {0, 0, 0, 0};
+#pragma unroll
+          for (int q = 0; q < SPT; q++)
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+              for (int d = 0; d < 6; d++) {
+                const int k = 2 * (6 * h + d);
+                al[2 * h]     += (double)(v[c2][q][k] * v[c][q][k] + v[c2][q][k + 1] * v[c][q][k + 1]);
+                al[2 * h + 1] += (double)(v[c2][q][k] * v[c][q][k + 1] - v[c2][q][k + 1] * v[c][q][k]);
+              }
+          wg_allreduce<4>(al, red, nw);
+#pragma unroll
+          for (int q = 0; q < SPT; q++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+              const T ar = (T)al[2 * h], ai = (T)al[2 * h + 1];
+#pragma unroll
+              for (int d = 0; d < 6; d++) {
+                const int k = 2 * (6 * h + d);
+                v[c][q][k]     -= ar * v[c2][q][k] - ai * v[c2][q][k + 1];
+                v[c][q][k + 1] -= ar * v[c2][q][k + 1] + ai * v[c2][q][k];
+              }
+            }
         }
+        double nr[2] = {0, 0};
+#pragma unroll
+        for (int q = 0; q < SPT; q++)
+#pragma unroll
+          for (int h = 0; h < 2; h++)
+#pragma unroll
+            for (int d = 0; d < 12; d++) nr[h] += (double)(v[c][q][12 * h + d] * v[c][q][12 * h + d]);
+        wg_allreduce<2>(nr, red, nw);
+        const T n0 = (T)(1.0 / sqrt(nr[0])), n1 = (T)(1.0 / sqrt(nr[1]));
+#pragma unroll
+        for (int q = 0; q < SPT; q++) {
+          const int i = threadIdx.x + q * nt;
+#pragma unroll
+          for (int d = 0; d < 12; d++) { v[c][q][d] *= n0; v[c][q][12 + d] *= n1; }
+          if (i < agg_sites) store_site<T, 24>(P + (size_t)(k0 + c) * pstride, V, s0 + i, v[c][q]);
+        }
+      }
     }
-    double nr[2] = {0, 0};
-#pragma unroll
-    for (int q = 0; q < SPT; q++)
-#pragma unroll
-      for (int h = 0; h < 2; h++)
-#pragma unroll
-        for (int d = 0; d < 12; d++) nr[h] += (double)(v[q][12 * h + d] * v[q][12 * h + d]);
-    wg_allreduce<2>(nr, red, nw);
-    const T n0 = (T)(1.0 / sqrt(nr[0])), n1 = (T)(1.0 / sqrt(nr[1]));
-#pragma unroll
-    for (int q = 0; q < SPT; q++) {
-      const int i = threadIdx.x + q * nt;
-#pragma unroll
-      for (int d = 0; d < 12; d++) { v[q][d] *= n0; v[q][12 + d] *= n1; }
-      if (i < agg_sites) store_site<T, 24>(P + (size_t)k1 * pstride, V, s0 + i, v[q]);
-    }
-    __syncthreads();  // make this vector visible to the loads of the next k1 (same workgroup, global memory)
+    __syncthreads();  // make these vectors visible to the loads of the next pass (same workgroup, global memory)
   }
 }
 
@@ -544,9 +591,15 @@ void Interpolation<T>::orthonormalize(hipStream_t st) {
   DDAMG_HIP_CHECK(hipMemcpyAsync(P, tv, sizeof(T) * pstride * nvec, hipMemcpyDeviceToDevice, st));
   const int nt = wg_threads(agg_sites);
   const int spt = (agg_sites + nt - 1) / nt;
-  if (spt == 1) hipLaunchKernelGGL((gs_aggregates_kernel<T, 1>), dim3(num_aggs), dim3(nt), 0, st, P, pstride, nvec, V, agg_sites);
-  else if (spt == 2) hipLaunchKernelGGL((gs_aggregates_kernel<T, 2>), dim3(num_aggs), dim3(nt), 0, st, P, pstride, nvec, V, agg_sites);
-  else if (spt <= 4) hipLaunchKernelGGL((gs_aggregates_kernel<T, 4>), dim3(num_aggs), dim3(nt), 0, st, P, pstride, nvec, V, agg_sites);
+  // columns per pass: 2 (measured at 32^4, Nvec 24: 6.8 ms with one column, 4.3 ms with two, 4.5 ms with four -- 190 registers,
+  // two workgroups per CU; two columns reproduce the one-column results bit for bit, four do not: the compiler contracts
+  // the products of the wider reduction differently)
+  static const int columns = getenv("DDAMG_GS_COLUMNS") ? atoi(getenv("DDAMG_GS_COLUMNS")) : 2;
+  if (spt == 1 && columns == 1) hipLaunchKernelGGL((gs_aggregates_kernel<T, 1, 1>), dim3(num_aggs), dim3(nt), 0, st, P, pstride, nvec, V, agg_sites);
+  else if (spt == 1 && columns == 4 && sizeof(T) == 4) hipLaunchKernelGGL((gs_aggregates_kernel<T, 1, 4>), dim3(num_aggs), dim3(nt), 0, st, P, pstride, nvec, V, agg_sites);
+  else if (spt == 1) hipLaunchKernelGGL((gs_aggregates_kernel<T, 1, 2>), dim3(num_aggs), dim3(nt), 0, st, P, pstride, nvec, V, agg_sites);
+  else if (spt == 2) hipLaunchKernelGGL((gs_aggregates_kernel<T, 2, 1>), dim3(num_aggs), dim3(nt), 0, st, P, pstride, nvec, V, agg_sites);
+  else if (spt <= 4) hipLaunchKernelGGL((gs_aggregates_kernel<T, 4, 1>), dim3(num_aggs), dim3(nt), 0, st, P, pstride, nvec, V, agg_sites);
   else DDAMG_REQUIRE(false, "aggregates larger than 1024 sites are not supported by the Gram-Schmidt kernel");
   DDAMG_HIP_CHECK(hipGetLastError());
 }
