@@ -140,6 +140,77 @@ __global__ __launch_bounds__(256) void coarse_batch_restrict_store_kernel(float*
   }
 }
 
+// The same on the matrix cores: per aggregate, part and chirality a complex (N x K) x (K x 64) product, K = agg_sites * n/2.
+// One workgroup of 4 wavefronts per aggregate, wavefront w the 16 columns 16 w .. 16 w + 15 and both row tiles of all five
+// parts (80 accumulator registers).  conj(P) of the aggregate and one chirality is staged in LDS in two halves of K (50 KB
+// for N <= 32, 2^4 aggregates, n = 48) and serves the five parts; Y is read once.
+// (The kernel above is bound by its dependent scalar loads of P -- 9.8 ms per build at 12^4 x 48 -> 6^4 x 56, 28.9 ms at
+// 16^4 -> 8^4; a matrix-core form that gathered P straight from global memory was slower still, and one with the whole K range
+// of P in 86 KB of dynamic LDS ran in 3.0 ms but cost 13 ms of host time per launch.)
+constexpr int RS_LDP_MAX = 232;
+__global__ __launch_bounds__(256) void coarse_batch_restrict_store_mfma_kernel(float* __restrict__ Mnext, int nt2, size_t msize2, const float2* __restrict__ Y,
+                                                                               size_t y_stride, const float* __restrict__ P, size_t pstride, int n, int N,
+                                                                               int agg_sites, const int* __restrict__ agg_csite, int ldp) {
+  __shared__ float2 Ps[32 * RS_LDP_MAX];                 // [32][ldp], ldp = K/2 + padding; rows >= N are zero
+  const int X = blockIdx.x, tid = threadIdx.x, w = tid >> 6;
+  const int l = tid & 63, r16 = l & 15, kq = l >> 4, col0 = 16 * w;
+  const int half = n >> 1, nc = 2 * N, hs = agg_sites >> 1, KC = hs * half;
+  const float2* Pp = reinterpret_cast<const float2*>(P + (size_t)X * agg_sites * n * 2);
+  const size_t ps2 = pstride / 2;                       // vectors are float2-aligned (pstride = 2 n V)
+  const float2* Yx = Y + (size_t)X * agg_sites * n * NB + col0 + r16;
+  for (int h = 0; h < 2; h++) {
+    f32x4 accR[5][2], accI[5][2];
+#pragma unroll
+    for (int part = 0; part < 5; part++)
+#pragma unroll
+      for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) { accR[part][rt][r] = 0.f; accI[part][rt][r] = 0.f; }
+    for (int kh = 0; kh < 2; kh++) {                     // the sites [kh * hs, (kh + 1) * hs) of the aggregate
+      __syncthreads();
+      for (int e = tid; e < 32 * KC; e += 256) {
+        const int v = e / KC, K = e - v * KC, xs = K / half, kk = K - xs * half;
+        Ps[v * ldp + K] = v < N ? Pp[(size_t)v * ps2 + (size_t)(kh * hs + xs) * n + h * half + kk] : make_float2(0.f, 0.f);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int part = 0; part < 5; part++) {
+        const float2* Yp = Yx + (size_t)part * y_stride;
+        for (int xs = 0; xs < hs; xs++) {
+          const size_t e0 = (size_t)(kh * hs + xs) * n + h * half + kq;
+          const float2* pa = Ps + r16 * ldp + xs * half + kq;
+#pragma unroll 2
+          for (int kk = 0; kk < half; kk += 4) {
+            const float2 b = Yp[(e0 + kk) * NB];
+            const float2 a0 = pa[kk], a1 = pa[16 * ldp + kk];
+            // conj(p) y = (pr yr + pi yi) + i (pr yi - pi yr)
+            accR[part][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.x, accR[part][0], 0, 0, 0);
+            accR[part][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b.y, accR[part][0], 0, 0, 0);
+            accI[part][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b.y, accI[part][0], 0, 0, 0);
+            accI[part][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(-a0.y, b.x, accI[part][0], 0, 0, 0);
+            accR[part][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.x, accR[part][1], 0, 0, 0);
+            accR[part][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b.y, accR[part][1], 0, 0, 0);
+            accI[part][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b.y, accI[part][1], 0, 0, 0);
+            accI[part][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(-a1.y, b.x, accI[part][1], 0, 0, 0);
+          }
+        }
+      }
+    }
+    const int j = col0 + r16;
+#pragma unroll
+    for (int part = 0; part < 5; part++) {
+      float2* Mp = reinterpret_cast<float2*>(Mnext) + ((size_t)agg_csite[X] * 5 + part) * msize2;
+#pragma unroll
+      for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int io = rt * 16 + 4 * kq + r;     // result row of register r
+          if (io < N && j < nc) Mp[tile_off_c(nt2, h * N + io, j)] = make_float2(accR[part][rt][r], accI[part][rt][r]);
+        }
+    }
+  }
+}
+
 void coarse_galerkin_batched(CoarseOp<float>& next, const CoarseOp<float>& op, const CoarseTransfer<float>& ip,
                              const unsigned char* d_agg_face, float* work, hipStream_t st) {
   const int V = op.V(), n = op.n(), N = ip.nvec;
@@ -163,6 +234,12 @@ void coarse_galerkin_batched(CoarseOp<float>& next, const CoarseOp<float>& op, c
     default: hipLaunchKernelGGL((coarse_batch_apply_kernel<4>), dim3(V), dim3(256), 0, st, Y, bs, Vb, dev, d_agg_face, halo); break;
   }
   DDAMG_HIP_CHECK(hipGetLastError());
+  const bool valu = getenv("DDAMG_COARSE_RESTRICT_VALU") != nullptr;   // read at every build: tests switch it within one process
+  const int KC = (ip.agg_sites / 2) * (n / 2), ldp = KC + (36 - KC % 32) % 32;   // ldp = 4 mod 32: the 16 rows x 4 k of an operand read spread over the banks
+  if (!valu && (n / 2) % 4 == 0 && N <= 32 && ip.pstride % 2 == 0 && ip.agg_sites % 2 == 0 && ldp <= RS_LDP_MAX)
+    hipLaunchKernelGGL(coarse_batch_restrict_store_mfma_kernel, dim3(ip.num_aggs), dim3(256), 0, st, next.matrices(), next.nt(), next.msize(), Y, bs,
+                       ip.P, ip.pstride, n, N, ip.agg_sites, ip.agg_csite, ldp);
+  else
   hipLaunchKernelGGL(coarse_batch_restrict_store_kernel, dim3(ip.num_aggs, 5), dim3(256), 0, st, next.matrices(), next.nt(), next.msize(), Y, bs,
                      ip.P, ip.pstride, n, N, ip.agg_sites, ip.agg_csite);
   DDAMG_HIP_CHECK(hipGetLastError());

@@ -830,7 +830,7 @@ void Multigrid<T>::bootstrap(int l, int iters) {
       }
       vec_scale<T>(test_vector(l, i), out, 1.0 / norm_of(l, out), 0.0, all, st_);
     }
-    if (l == 0) tick("bootstrap V-cycles", tb);
+    tick(l == 0 ? "bootstrap V-cycles" : "bootstrap V-cycles, coarse levels", tb);
     re_setup(l);
     if (l == 0 && !lv_[1]->coarsest)
       bootstrap(1, std::max(1, (int)std::lround((double)((j + 1) * par_.setup_iter[1]) / (double)iters)));

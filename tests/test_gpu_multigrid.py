@@ -456,14 +456,18 @@ def test_bootstrap_with_one_restriction_and_one_interpolation_for_all_test_vecto
     assert relerr(res[0][1], res[1][1]) < 1e-8
 
 
+@pytest.mark.parametrize("coarse_restrict", ["mfma", "valu"])
 @pytest.mark.parametrize("fixture", ["ref_16x16_3lvl.npz", "ref_16x16_3lvl_hard.npz"], ids=["random-links", "smooth-links"])
-def test_three_level_production_block_shapes_16x16(fixture):
+def test_three_level_production_block_shapes_16x16(fixture, coarse_restrict, monkeypatch):
     """16^4 with the block shapes of the production configurations -- 4^4 Schwarz blocks and aggregates on the fine level
     (-> 4^4), 2^4 on the coarse level (-> 2^4), K-cycle, Nvec 24/28, setup 3 (+2) -- against the reference's runs on
     seeded random links (m0 0.3, an easy system) and on smooth links exp(0.35 i H) (m0 -0.3, a hard one):
     resident-operator smoother, matrix-core Galerkin construction on both levels, arithmetic-neighbour stencil.
-    Same rand() stream, same iteration count and residual history."""
+    Same rand() stream, same iteration count and residual history.  The restriction of the coarse level's Galerkin
+    construction on the matrix cores (default) and in its vector-unit form (DDAMG_COARSE_RESTRICT_VALU)."""
     from conftest import load_golden, random_su3
+    if coarse_restrict == "valu":
+        monkeypatch.setenv("DDAMG_COARSE_RESTRICT_VALU", "1")
     g = load_golden(fixture)
     V = 16 ** 4
     p = api.default_params(); p.num_levels = 3

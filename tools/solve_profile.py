@@ -30,6 +30,6 @@ ctx.solve_vec(xv, bv, 1e-10)
 t0 = time.time()
 for _ in range(N):
     it, cit, rr = ctx.solve_vec(xv, bv, 1e-10)
-dt = (time.time() - t0) / N
+dt = (time.time() - t0) / max(N, 1)   # N = 0: the setup and the one warm-up solve only
 print(json.dumps({"lattice": ext, "levels": levels, "solve_s": dt, "setup_s": t_setup, "iters": it, "coarse_iters": cit, "relres": rr, "mixed_precision": mp}))
 ctx.close()
