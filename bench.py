@@ -282,7 +282,7 @@ def kernel_source_hash():
 
 def mfma_source_hash():
     h = hashlib.sha256()
-    for f in ("coarse_lockstep.hip", "coarse_lockstep.h", "coarse_batch.hip", "coarse_op.h"):
+    for f in ("coarse_lockstep.hip", "coarse_lockstep.h", "coarse_batch.hip", "coarse_op.h", "transfer.hip"):
         h.update(open(os.path.join(REPO, "ddalphaamg_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -338,7 +338,10 @@ def coarse_operator_report():
             "bootstrap_coarsest_solves_in_lockstep": entry("lockstep_hop", "ls_hop_kernel: hopping terms of the coarsest-level Schur complement for all Nvec test vectors of a "
                                                            "bootstrap iteration at once, complex n x n times n x 32 on v_mfma_f32_16x16x4_f32 (32^4 two-level setup)"),
             "galerkin_coarse_apply": entry("galerkin_coarse_apply", "coarse_batch_apply_kernel: all 2*Nvec columns of the coarse-level Galerkin construction (48^4 three-level setup)"),
-            "galerkin_restrict": entry("galerkin_restrict", "restrict_mfma_kernel: 240 fields x 24 vectors per aggregate on v_mfma_f32_32x32x2_f32"),
+            "galerkin_restrict": entry("galerkin_restrict", "restrict_mfma_kernel<2>: the 2*Nvec columns of the fine-level Galerkin construction, five parts each (the four forward "
+                                       "parts on the aggregate faces only), times 24 vectors per aggregate on v_mfma_f32_32x32x2_f32 (48^4 three-level setup)"),
+            "galerkin_coarse_restrict": entry("galerkin_coarse_restrict", "coarse_batch_restrict_store_mfma_kernel: the coarse level's five batches times its 28 vectors per "
+                                              "aggregate, conj(P) staged in LDS, on v_mfma_f32_16x16x4_f32 (48^4 three-level setup)"),
         }
     except Exception:
         pass
@@ -459,6 +462,15 @@ def main():
         args.gpus = int(env_world) if env_world else 1
     if args.gpus > 1 and env_world is None:
         sys.exit(spawn_ranks(args.gpus))     # nothing below runs in the parent
+
+    # stdout carries the one JSON line and nothing else: libraries that write to file descriptor 1 from C (RCCL prints a version
+    # banner when its first communicator is created) are sent to stderr, the line itself goes to the saved descriptor
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(json_fd, (line + "\n").encode())
 
     import numpy as np
     import torch
@@ -605,7 +617,7 @@ def main():
             print(f"bench.py: rank {rank}: {msg}", file=sys.stderr, flush=True)
             if rank == 0:
                 out.setdefault("strong_scaling", {})["error"] = msg
-                print(json.dumps(out), flush=True)
+                emit(json.dumps(out))
             os._exit(3)
 
     if world > 1:
@@ -735,7 +747,7 @@ def main():
         except Exception as e:
             out["rehearsal"] = {"error": str(e)[:300]}
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,7 +1,9 @@
 # collects the round-3 profile artefacts into gpurun_out/prof_r03/ (then: python3 tools/commit_profiles.py gpurun_out/prof_r03 r03)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/prof_r03; mkdir -p $O; R=r03
-# 1. the default bench run under the kernel trace (headline, 32^4 solve leg, 64^4 strong-scaling leg, rehearsal of the 8-GPU point)
+# 1. the default bench run under the kernel trace (headline, 32^4 solve leg, 64^4 strong-scaling leg, rehearsal of the 8-GPU point);
+#    a warm-up process first: the first process on a fresh box pays one-time allocation costs
+python3 tools/solve_profile.py 1 1 32 2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d $O/bench -o bench -- python3 bench.py > $O/bench_line.json 2> $O/bench.err
 python3 tools/rocpd_export.py stats $O/bench/bench_results.db $O/${R}_bench_kernel_stats.csv
 tail -c 600 $O/bench_line.json; echo
