@@ -593,10 +593,14 @@ void Multigrid<T>::build_coarse_operator(int l) {
       while (gal_batch_ > 1 && (gal_batch_ > max_batch || sizeof(T) * gal_batch_ * (wcol + 5 * cs) > free_b / 2)) gal_batch_ = (gal_batch_ + 1) / 2;
       gal_slab_aggs_ = 0;
       const char* force_slab = getenv("DDAMG_GALERKIN_SLAB_AGGS");   // tests: slabs of this many aggregates at any volume
-      if ((gal_batch_ < 2 * N || force_slab) && 2 * N <= max_batch && !lv.fop->distributed() && !no_slab) {
+      static const bool whole = getenv("DDAMG_GALERKIN_WHOLE_LATTICE") != nullptr;   // round 2: slabs only when the columns do not fit
+      if ((gal_batch_ < 2 * N || force_slab || !whole) && 2 * N <= max_batch && !lv.fop->distributed() && !no_slab) {
         // all columns do not fit next to each other for the whole lattice.  Fewer columns per pass starve the N dimension
         // of the restriction GEMM (64^4: 6 of 48 columns, 30 of 240 fields, 4x the time); instead keep ALL columns and walk
-        // the lattice in slabs of whole aggregates -- D P and its restriction are local to an aggregate
+        // the lattice in slabs of whole aggregates -- D P and its restriction are local to an aggregate.
+        // The slab is no larger than what the bootstrap borrows (Nvec fine vectors) or 512 aggregates: the time of a build does
+        // not depend on the slab size from 512 aggregates on, and memory that is never allocated need not be mapped -- the first
+        // process on a freshly started box pays ~20-40 ms per GB of never-used device memory
         const size_t per_agg = sizeof(T) * 2 * N * wcol_agg;
         const size_t coarse_b = sizeof(T) * 5 * 2 * N * cs;           // gal_C_: all columns on the coarse lattice
         DDAMG_REQUIRE(coarse_b + per_agg < free_b, "Galerkin construction: not enough device memory for the coarse columns and one aggregate of fields");
@@ -604,6 +608,8 @@ void Multigrid<T>::build_coarse_operator(int l) {
         // after the coarse columns (unsigned arithmetic: never subtract past zero)
         const size_t budget = free_b / 2 > coarse_b + per_agg ? free_b / 2 - coarse_b : free_b - coarse_b - (free_b - coarse_b) / 8;
         gal_slab_aggs_ = (int)std::min<size_t>((size_t)nagg, std::max<size_t>(1, budget / per_agg));
+        const size_t borrow = (sizeof(T) * (size_t)N * ws + per_agg - 1) / per_agg;      // aggregates whose slab holds Nvec fine vectors
+        if (!whole) gal_slab_aggs_ = (int)std::min<size_t>((size_t)gal_slab_aggs_, std::max<size_t>(borrow, 512));
         if (force_slab) gal_slab_aggs_ = std::max(1, std::min(atoi(force_slab), nagg));
         DDAMG_REQUIRE(per_agg * (size_t)gal_slab_aggs_ + coarse_b < free_b, "Galerkin construction: slab workspace does not fit the free device memory");
         gal_batch_ = 2 * N;

@@ -99,7 +99,7 @@ __global__ __launch_bounds__(256) void aggregate_dirac_kernel(T* __restrict__ W,
 // handed to the site s + mu through LDS -- and only the forward neighbours across an aggregate face come from global
 // memory (a quarter of the sites per direction with 4^4 aggregates; a neighbour inside the aggregate but outside the tile
 // too, for aggregates larger than a tile).  CHIR is a template parameter so that the zero half of the input folds away.
-template <typename T, int MU, int CHIR, bool CMP>
+template <typename T, int MU, int CHIR, bool CMP, bool DIST>
 __device__ __forceinline__ void agg_tile_dir(const T* __restrict__ vh, const FineOpDev<T>& op, const unsigned face, size_t s, bool live, size_t tile0,
                                              const T (&p)[24], T (&e)[24], const T* __restrict__ sp, T* __restrict__ hb,
                                              T* __restrict__ W, const AggFaces& af, size_t wagg, int li, size_t naggs) {
@@ -117,7 +117,11 @@ __device__ __forceinline__ void agg_tile_dir(const T* __restrict__ vh, const Fin
   }
   // (b) forward term with my own link: into the self part, or -- across the face -- the forward part of direction mu
   if (live) {
-    const size_t j = (size_t)op.nb[(size_t)MU * V + s];
+    const int jn = op.nb[(size_t)MU * V + s];
+    // (a forward neighbour on another process -- always across an aggregate face -- has no site here: the load reads this
+    // site instead and its value is not used; its chirality-masked, projected spinor was exchanged beforehand)
+    const bool remote = DIST && jn < 0;
+    const size_t j = remote ? s : (size_t)jn;
     T pn[24];
 #pragma unroll
     for (int k = 0; k < 12; k++) pn[12 * (1 - CHIR) + k] = 0;
@@ -135,6 +139,8 @@ __device__ __forceinline__ void agg_tile_dir(const T* __restrict__ vh, const Fin
       T acc[24];
 #pragma unroll
       for (int k = 0; k < 24; k++) acc[k] = 0;
+      if (remote) halo_forward<T, MU>(op, -1 - jn, U, acc);
+      else
       hop_accumulate<T, MU, true>(U, pn, acc);  // acc = -hop
 #pragma unroll
       for (int k = 0; k < 24; k++) acc[k] = -acc[k];
@@ -165,7 +171,7 @@ __device__ __forceinline__ void agg_tile_dir(const T* __restrict__ vh, const Fin
   // no second barrier: the caller alternates between two hb buffers
 }
 
-template <typename T, int CHIR, bool CMP>
+template <typename T, int CHIR, bool CMP, bool DIST>
 __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) void aggregate_dirac_tile_kernel(T* __restrict__ W, const T* __restrict__ v, FineOpDev<T> op,
                                                                                              const unsigned char* __restrict__ agg_face, size_t w0site, size_t Vw,
                                                                                              AggFaces af) {
@@ -195,10 +201,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) void aggregate_dirac
     herm6_mul<T>(cl, p + 12 * CHIR, e + 12 * CHIR);
   }
   __syncthreads();
-  agg_tile_dir<T, 0, CHIR, CMP>(vh, op, face, s, live, tile0, p, e, sp, hb, W, af, wagg, li, naggs);
-  agg_tile_dir<T, 1, CHIR, CMP>(vh, op, face, s, live, tile0, p, e, sp, hb + 12 * 256, W, af, wagg, li, naggs);
-  agg_tile_dir<T, 2, CHIR, CMP>(vh, op, face, s, live, tile0, p, e, sp, hb, W, af, wagg, li, naggs);
-  agg_tile_dir<T, 3, CHIR, CMP>(vh, op, face, s, live, tile0, p, e, sp, hb + 12 * 256, W, af, wagg, li, naggs);
+  agg_tile_dir<T, 0, CHIR, CMP, DIST>(vh, op, face, s, live, tile0, p, e, sp, hb, W, af, wagg, li, naggs);
+  agg_tile_dir<T, 1, CHIR, CMP, DIST>(vh, op, face, s, live, tile0, p, e, sp, hb + 12 * 256, W, af, wagg, li, naggs);
+  agg_tile_dir<T, 2, CHIR, CMP, DIST>(vh, op, face, s, live, tile0, p, e, sp, hb, W, af, wagg, li, naggs);
+  agg_tile_dir<T, 3, CHIR, CMP, DIST>(vh, op, face, s, live, tile0, p, e, sp, hb + 12 * 256, W, af, wagg, li, naggs);
   if (live) store_site<T, 24>(W, Vw, s - w0site, e);
 }
 
@@ -226,9 +232,23 @@ void aggregate_dirac_slab(T* W, const T* v, int chir, const FineOp<T>& op, const
 template void aggregate_dirac_slab<float>(float*, const float*, int, const FineOp<float>&, const unsigned char*, size_t, size_t, hipStream_t);
 template void aggregate_dirac_slab<double>(double*, const double*, int, const FineOp<double>&, const unsigned char*, size_t, size_t, hipStream_t);
 
+template <typename T, bool DIST>
+static void launch_aggregate_dirac_tile(T* W, const T* v, int chir, const FineOp<T>& op, const unsigned char* d_agg_face, const AggFaces& af, size_t site0, size_t nsites,
+                                        hipStream_t st) {
+  const dim3 grid((unsigned)((nsites + 255) / 256));
+  if (op.links_compressed()) {
+    if (chir == 0) hipLaunchKernelGGL((aggregate_dirac_tile_kernel<T, 0, true, DIST>), grid, dim3(256), 0, st, W, v, op.dev(), d_agg_face, site0, nsites, af);
+    else hipLaunchKernelGGL((aggregate_dirac_tile_kernel<T, 1, true, DIST>), grid, dim3(256), 0, st, W, v, op.dev(), d_agg_face, site0, nsites, af);
+  } else {
+    if (chir == 0) hipLaunchKernelGGL((aggregate_dirac_tile_kernel<T, 0, false, DIST>), grid, dim3(256), 0, st, W, v, op.dev(), d_agg_face, site0, nsites, af);
+    else hipLaunchKernelGGL((aggregate_dirac_tile_kernel<T, 1, false, DIST>), grid, dim3(256), 0, st, W, v, op.dev(), d_agg_face, site0, nsites, af);
+  }
+}
+
 template <typename T>
 void aggregate_dirac_compact(T* W, const T* v, int chir, const FineOp<T>& op, const unsigned char* d_agg_face, const AggFaces& af, int agg0, int naggs, hipStream_t st) {
   const size_t site0 = (size_t)agg0 * af.agg_sites, nsites = (size_t)naggs * af.agg_sites;
+  const bool gather = getenv("DDAMG_AGGREGATE_DIRAC_GATHER") != nullptr;   // read at every call: tests switch it within one process
   if (op.distributed()) {
     DDAMG_REQUIRE(agg0 == 0 && nsites == (size_t)op.V(), "Galerkin construction on a process grid: whole lattice only");
     // the self part of the column serves as scratch for the chirality-masked copy whose boundary is sent to the neighbours
@@ -236,18 +256,11 @@ void aggregate_dirac_compact(T* W, const T* v, int chir, const FineOp<T>& op, co
     DDAMG_HIP_CHECK(hipMemcpyAsync(W + chir * half, v + chir * half, sizeof(T) * half, hipMemcpyDeviceToDevice, st));
     DDAMG_HIP_CHECK(hipMemsetAsync(W + (1 - chir) * half, 0, sizeof(T) * half, st));
     op.halo_exchange(W, st);
-    hipLaunchKernelGGL((aggregate_dirac_kernel<T, true, true>), dim3((unsigned)((nsites + 255) / 256)), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face, site0, nsites, af);
+    if (gather) hipLaunchKernelGGL((aggregate_dirac_kernel<T, true, true>), dim3((unsigned)((nsites + 255) / 256)), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face, site0, nsites, af);
+    else launch_aggregate_dirac_tile<T, true>(W, v, chir, op, d_agg_face, af, site0, nsites, st);
   } else {
-    const bool gather = getenv("DDAMG_AGGREGATE_DIRAC_GATHER") != nullptr;   // read at every call: tests switch it within one process
-    const dim3 grid((unsigned)((nsites + 255) / 256));
-    if (gather) hipLaunchKernelGGL((aggregate_dirac_kernel<T, false, true>), grid, dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face, site0, nsites, af);
-    else if (op.links_compressed()) {
-      if (chir == 0) hipLaunchKernelGGL((aggregate_dirac_tile_kernel<T, 0, true>), grid, dim3(256), 0, st, W, v, op.dev(), d_agg_face, site0, nsites, af);
-      else hipLaunchKernelGGL((aggregate_dirac_tile_kernel<T, 1, true>), grid, dim3(256), 0, st, W, v, op.dev(), d_agg_face, site0, nsites, af);
-    } else {
-      if (chir == 0) hipLaunchKernelGGL((aggregate_dirac_tile_kernel<T, 0, false>), grid, dim3(256), 0, st, W, v, op.dev(), d_agg_face, site0, nsites, af);
-      else hipLaunchKernelGGL((aggregate_dirac_tile_kernel<T, 1, false>), grid, dim3(256), 0, st, W, v, op.dev(), d_agg_face, site0, nsites, af);
-    }
+    if (gather) hipLaunchKernelGGL((aggregate_dirac_kernel<T, false, true>), dim3((unsigned)((nsites + 255) / 256)), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face, site0, nsites, af);
+    else launch_aggregate_dirac_tile<T, false>(W, v, chir, op, d_agg_face, af, site0, nsites, st);
   }
   DDAMG_HIP_CHECK(hipGetLastError());
 }
