@@ -579,6 +579,9 @@ void Multigrid<T>::build_coarse_operator(int l) {
     const bool no_compact = getenv("DDAMG_GALERKIN_FULL_FIELDS") != nullptr;   // read at every build: tests switch it within one process
     const AggFaces& af = lv.agg_faces;
     const bool compact = !no_compact && 2 * N <= 64 && Interpolation<T>::restrict_compact_available(lv.fip.agg_sites, N, af);
+    // ... and their restriction written straight into the next level's matrices (DDAMG_GALERKIN_STORE_COLUMNS: through coarse
+    // column vectors and one store launch per column, as the full-field path does)
+    const bool direct = compact && getenv("DDAMG_GALERKIN_STORE_COLUMNS") == nullptr;
     const int nagg = lv.fip.num_aggs, as = lv.fip.agg_sites;
     const size_t wcol = compact ? (size_t)24 * af.column_sites(nagg) : 5 * ws;          // one column of W, whole lattice
     const size_t wcol_agg = compact ? (size_t)24 * af.column_sites(1) : (size_t)5 * 24 * as;   // ... one aggregate of it
@@ -619,10 +622,14 @@ void Multigrid<T>::build_coarse_operator(int l) {
         DDAMG_HIP_CHECK(device_alloc(&gal_W_, sizeof(T) * gal_batch_ * wcol));
         gal_W_elems_ = (size_t)gal_batch_ * wcol;
       }
-      DDAMG_HIP_CHECK(device_alloc(&gal_C_, sizeof(T) * 5 * gal_batch_ * cs));
-      gal_C_elems_ = (size_t)5 * gal_batch_ * cs;
+      // coarse column vectors: five per column, or -- with the restriction writing straight into the matrices -- only what the
+      // bootstrap borrows (Nvec right-hand sides and Nvec solutions)
+      const size_t c_cols = direct ? (size_t)2 * N : (size_t)5 * gal_batch_;
+      DDAMG_HIP_CHECK(device_alloc(&gal_C_, sizeof(T) * c_cols * cs));
+      gal_C_elems_ = c_cols * cs;
     }
     const int batch = gal_batch_;
+    DDAMG_REQUIRE(direct || gal_C_elems_ >= (size_t)5 * gal_batch_ * cs, "Galerkin construction: the workspace of this context was sized for the direct store of the restriction");
     T *Wb = gal_W_, *Cb = gal_C_;
     if (gal_slab_aggs_ > 0) {
       for (int a0 = 0; a0 < nagg; a0 += gal_slab_aggs_) {
@@ -631,27 +638,27 @@ void Multigrid<T>::build_coarse_operator(int l) {
         if (compact) {
           for (int c = 0; c < 2 * N; c++)
             aggregate_dirac_compact<T>(Wb + (size_t)c * na * wcol_agg, lv.fip.interp_vector(c % N), c / N, *lv.fop, lv.d_agg_face, af, a0, na, st_);
-          lv.fip.restrict_batch_compact(Cb, cs, Wb, 2 * N, af, a0, na, st_);
+          lv.fip.restrict_batch_compact(Cb, cs, Wb, 2 * N, af, a0, na, st_, direct ? nx.cop.matrices() : nullptr, nx.cop.nt(), nx.cop.msize(), 0);
         } else {
           for (int c = 0; c < 2 * N; c++)
             aggregate_dirac_slab<T>(Wb + (size_t)5 * c * wss, lv.fip.interp_vector(c % N), c / N, *lv.fop, lv.d_agg_face, (size_t)a0 * as, (size_t)na * as, st_);
           lv.fip.restrict_batch_slab(Cb, cs, Wb, wss, 5 * 2 * N, a0, na, st_);
         }
       }
-      for (int c = 0; c < 2 * N; c++) galerkin_store_column<T>(nx.cop, Cb + (size_t)5 * c * cs, c, st_);
+      if (!direct) for (int c = 0; c < 2 * N; c++) galerkin_store_column<T>(nx.cop, Cb + (size_t)5 * c * cs, c, st_);
     } else
     for (int c0 = 0; c0 < 2 * N; c0 += batch) {
       const int nb = std::min(batch, 2 * N - c0);
       if (compact) {
         for (int c = 0; c < nb; c++)
           aggregate_dirac_compact<T>(Wb + (size_t)c * wcol, lv.fip.interp_vector((c0 + c) % N), (c0 + c) / N, *lv.fop, lv.d_agg_face, af, 0, nagg, st_);
-        lv.fip.restrict_batch_compact(Cb, cs, Wb, nb, af, 0, nagg, st_);
+        lv.fip.restrict_batch_compact(Cb, cs, Wb, nb, af, 0, nagg, st_, direct ? nx.cop.matrices() : nullptr, nx.cop.nt(), nx.cop.msize(), c0);
       } else {
         for (int c = 0; c < nb; c++)
           aggregate_dirac<T>(Wb + (size_t)5 * c * ws, lv.fip.interp_vector((c0 + c) % N), (c0 + c) / N, *lv.fop, lv.d_agg_face, st_);
         lv.fip.restrict_batch(Cb, cs, Wb, ws, 5 * nb, st_);
       }
-      for (int c = 0; c < nb; c++) galerkin_store_column<T>(nx.cop, Cb + (size_t)5 * c * cs, c0 + c, st_);
+      if (!direct) for (int c = 0; c < nb; c++) galerkin_store_column<T>(nx.cop, Cb + (size_t)5 * c * cs, c0 + c, st_);
     }
   } else if (l == 0) {
     for (int chir = 0; chir < 2; chir++)

@@ -64,7 +64,10 @@ struct Interpolation {
   void restrict_batch_slab(T* phi_c, size_t out_stride, const T* phi, size_t in_stride, int nw, int agg0, int naggs, hipStream_t st) const;
   static bool restrict_batch_available(int agg_sites_, int nvec_) { return sizeof(T) == 4 && agg_sites_ % 16 == 0 && nvec_ <= 32; }
   // the Galerkin construction's five fields of ncols <= 64 columns in face-compacted form (see AggFaces and transfer.hip)
-  void restrict_batch_compact(T* phi_c, size_t out_stride, const T* W, int ncols, const AggFaces& af, int agg0, int naggs, hipStream_t st) const;
+  // Mdirect != null: the results go straight into columns col_base .. of the next level's coupling matrices (CoarseOp::matrices(),
+  // nt(), msize()) instead of into the coarse column vectors phi_c
+  void restrict_batch_compact(T* phi_c, size_t out_stride, const T* W, int ncols, const AggFaces& af, int agg0, int naggs, hipStream_t st,
+                              T* Mdirect = nullptr, int nt2 = 0, size_t msize2 = 0, int col_base = 0) const;
   static bool restrict_compact_available(int agg_sites_, int nvec_, const AggFaces& af) {
     return restrict_batch_available(agg_sites_, nvec_) && af.valid() && af.agg_sites == agg_sites_ && af.nface[0] % 16 == 0 && af.nface[1] % 16 == 0 &&
            af.nface[2] % 16 == 0 && af.nface[3] % 16 == 0;

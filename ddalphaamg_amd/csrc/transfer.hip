@@ -158,7 +158,8 @@ template <int NTL>
 __global__ __launch_bounds__(256, (NTL == 2 ? 4 : NTL == 1 ? 3 : 2)) void restrict_mfma_kernel(float* __restrict__ out, size_t out_stride, const float* __restrict__ W, size_t wstride, int nw,
                                                               const float* __restrict__ P, size_t pstride, int nvec, int V, int agg_sites,
                                                               const int* __restrict__ agg_csite, int a0, RestrictParts parts,
-                                                              const unsigned short* __restrict__ site_list, int nparts, int naggs) {
+                                                              const unsigned short* __restrict__ site_list, int nparts, int naggs,
+                                                              float* __restrict__ Mdirect, int nt2, size_t msize2, int col_base) {
   constexpr int KS = 16;            // sites per K block
   constexpr bool KSPLIT = NTL < 8;
   constexpr int KP = KSPLIT ? 4 / NTL : 1;   // wavefronts per tile
@@ -277,6 +278,13 @@ __global__ __launch_bounds__(256, (NTL == 2 ? 4 : NTL == 1 ? 3 : 2)) void restri
           const int i = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
           if (i < nvec) {
             float2 v; v.x = accR[t][r]; v.y = accI[t][r];
+            if (Mdirect) {
+              // straight into column col_base + col of the next level's coupling matrix `part` of this aggregate's coarse site
+              // (CoarseOp's tile layout): no coarse column vectors in between, no store launches
+              const int row = h * nvec + i, cc = col_base + col;
+              const size_t o = ((size_t)((row >> 3) * nt2 + (cc >> 3)) * 64 + (row & 7) * 8 + (cc & 7)) * 2;
+              *reinterpret_cast<float2*>(Mdirect + ((size_t)agg_csite[a] * 5 + part) * msize2 * 2 + o) = v;
+            } else
             *reinterpret_cast<float2*>(out + (size_t)col * out_stride + cbase + 2 * i) = v;
           }
         }
@@ -297,9 +305,9 @@ void Interpolation<T>::restrict_batch(T* phi_c, size_t out_stride, const T* phi,
     DDAMG_REQUIRE(restrict_batch_available(agg_sites, nvec) && nw >= 1 && nw <= 256, "batched restriction: unsupported shape");
     const RestrictParts parts = whole_aggregates((size_t)V, agg_sites);
     if (nw <= 32) hipLaunchKernelGGL(restrict_mfma_kernel<1>, dim3(num_aggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
-                                     0, parts, (const unsigned short*)nullptr, 1, num_aggs);
+                                     0, parts, (const unsigned short*)nullptr, 1, num_aggs, (float*)nullptr, 0, (size_t)0, 0);
     else hipLaunchKernelGGL(restrict_mfma_kernel<8>, dim3(num_aggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
-                            0, parts, (const unsigned short*)nullptr, 1, num_aggs);
+                            0, parts, (const unsigned short*)nullptr, 1, num_aggs, (float*)nullptr, 0, (size_t)0, 0);
     DDAMG_HIP_CHECK(hipGetLastError());
   } else {
     DDAMG_REQUIRE(false, "batched restriction is an fp32 path");
@@ -311,7 +319,7 @@ void Interpolation<T>::restrict_batch_slab(T* phi_c, size_t out_stride, const T*
     DDAMG_REQUIRE(restrict_batch_available(agg_sites, nvec) && nw >= 1 && nw <= 256 && agg0 >= 0 && agg0 + naggs <= num_aggs, "batched restriction: unsupported shape");
     const RestrictParts parts = whole_aggregates((size_t)naggs * agg_sites, agg_sites);
     hipLaunchKernelGGL(restrict_mfma_kernel<8>, dim3(naggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
-                       agg0, parts, (const unsigned short*)nullptr, 1, num_aggs);
+                       agg0, parts, (const unsigned short*)nullptr, 1, num_aggs, (float*)nullptr, 0, (size_t)0, 0);
     DDAMG_HIP_CHECK(hipGetLastError());
   } else {
     DDAMG_REQUIRE(false, "batched restriction is an fp32 path");
@@ -321,7 +329,8 @@ void Interpolation<T>::restrict_batch_slab(T* phi_c, size_t out_stride, const T*
 // af.column_sites(naggs) sites, its self part over all sites of the aggregates [agg0, agg0 + naggs) followed by the four
 // forward parts over their face sites.  The five results of column c go to phi_c + (5c + part) * out_stride.
 template <typename T>
-void Interpolation<T>::restrict_batch_compact(T* phi_c, size_t out_stride, const T* W, int ncols, const AggFaces& af, int agg0, int naggs, hipStream_t st) const {
+void Interpolation<T>::restrict_batch_compact(T* phi_c, size_t out_stride, const T* W, int ncols, const AggFaces& af, int agg0, int naggs, hipStream_t st,
+                                              T* Mdirect, int nt2, size_t msize2, int col_base) const {
   if constexpr (sizeof(T) == 4) {
     DDAMG_REQUIRE(restrict_compact_available(agg_sites, nvec, af) && ncols >= 1 && ncols <= 64 && agg0 >= 0 && agg0 + naggs <= num_aggs,
                   "compact batched restriction: unsupported shape");
@@ -336,9 +345,9 @@ void Interpolation<T>::restrict_batch_compact(T* phi_c, size_t out_stride, const
     const size_t wstride = (size_t)24 * af.column_sites(naggs);
     const dim3 grid((unsigned)((naggs + 7) / 8 * 8 * 5));
     if (ncols <= 32) hipLaunchKernelGGL(restrict_mfma_kernel<1>, grid, dim3(256), 0, st, phi_c, 5 * out_stride, W, wstride, ncols, P, pstride, nvec, V, agg_sites, agg_csite,
-                                        agg0, parts, af.list, 5, naggs);
+                                        agg0, parts, af.list, 5, naggs, (float*)Mdirect, nt2, msize2, col_base);
     else hipLaunchKernelGGL(restrict_mfma_kernel<2>, grid, dim3(256), 0, st, phi_c, 5 * out_stride, W, wstride, ncols, P, pstride, nvec, V, agg_sites, agg_csite,
-                            agg0, parts, af.list, 5, naggs);
+                            agg0, parts, af.list, 5, naggs, (float*)Mdirect, nt2, msize2, col_base);
     DDAMG_HIP_CHECK(hipGetLastError());
   } else {
     DDAMG_REQUIRE(false, "batched restriction is an fp32 path");

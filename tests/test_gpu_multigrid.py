@@ -414,11 +414,12 @@ def test_face_compacted_galerkin_fields_give_the_same_operator(gold_b4, gold8, m
     """the four forward parts of D P are zero away from the aggregate faces; the Galerkin construction keeps and restricts them
     on the face sites only, and builds them on 256-site tiles through LDS.  Against the five full fields per column
     (DDAMG_GALERKIN_FULL_FIELDS) and against the gather form of the field kernel (DDAMG_AGGREGATE_DIRAC_GATHER): the same
-    coarse operator up to the rounding of another summation order, the same solve"""
+    coarse operator up to the rounding of another summation order, the same solve; against the restriction's results passing
+    through coarse column vectors (DDAMG_GALERKIN_STORE_COLUMNS): identical"""
     if slabs:
         monkeypatch.setenv("DDAMG_GALERKIN_SLAB_AGGS", slabs)
     res = []
-    for knob in (None, "DDAMG_GALERKIN_FULL_FIELDS", "DDAMG_AGGREGATE_DIRAC_GATHER"):
+    for knob in (None, "DDAMG_GALERKIN_FULL_FIELDS", "DDAMG_AGGREGATE_DIRAC_GATHER", "DDAMG_GALERKIN_STORE_COLUMNS"):
         if knob:
             monkeypatch.setenv(knob, "1")
         ctx = make_ctx_b4(gold_b4, gold8)
@@ -430,10 +431,12 @@ def test_face_compacted_galerkin_fields_give_the_same_operator(gold_b4, gold8, m
         ctx.close()
         if knob:
             monkeypatch.delenv(knob)
-    for other in res[1:]:
+    for other in res[1:3]:
         assert relerr(res[0][0], other[0]) < 2e-5 and relerr(res[0][1], other[1]) < 2e-5
         assert not np.array_equal(res[0][0], other[0])        # another code path did run
         assert res[0][3] == other[3] and other[4] < 1e-10 and relerr(res[0][2], other[2]) < 1e-8
+    # the restriction writes straight into the coarse matrices; through coarse column vectors and store launches: the same bits
+    assert np.array_equal(res[0][0], res[3][0]) and np.array_equal(res[0][1], res[3][1]) and np.array_equal(res[0][2], res[3][2])
 
 
 def test_bootstrap_with_one_restriction_and_one_interpolation_for_all_test_vectors(gold_b4, gold8, monkeypatch):
