@@ -425,6 +425,16 @@ def run_solve(q, G, grid, coords, world, rank, transport, group):
     if world == 1 and not any(g == -1 for g in grid):
         x, it2, _, _ = ctx.solve(b, 1e-10)
         t0 = time.perf_counter(); ctx.solve(b, 1e-10, out=x); res["seconds_per_solve_host_vectors"] = time.perf_counter() - t0
+    if world == 1 and not any(g == -1 for g in grid):
+        # The same setup once more in this context (what every later setup of a process costs, e.g. one per HMC trajectory):
+        # `setup_seconds` above is the first setup of the context and, on a freshly started box, also pays for device memory no
+        # process has allocated before (13-30 ms per GB) -- the two are reported side by side.
+        try:
+            t0 = time.perf_counter(); ctx.setup(q.setup_iter[0]); ctx.sync(); res["setup_seconds_repeated"] = time.perf_counter() - t0
+            it3, cit3, rr3 = ctx.solve_vec(xv, bv, 1e-10)
+            res["repeated_setup_solve"] = {"iterations": it3, "coarse_iterations": cit3, "true_relres": rr3}
+        except Exception as e:
+            res["setup_seconds_repeated"] = None; res["repeated_setup_solve"] = {"error": str(e)[:200]}
     if world == 1:
         # seconds per GMRES iteration of the coarsest-level solve (for the rehearsal's correction: on N GPUs the gathered
         # coarsest level is the GLOBAL one, the rehearsal's is 1/N of it)

@@ -43,6 +43,10 @@ def test_single_gpu_line():
     assert c["kind"] in ("reference", "port") and c["value"] > 0 and c["cores"] >= 1 and c["sample"]
     s = d["solve"]
     assert s["true_relres"] < 1e-10 and s["seconds_per_solve"] > 0
+    # the same setup once more in the same context (a second rand() stream: the count may move by one)
+    assert s["setup_seconds_repeated"] > 0 and abs(s["repeated_setup_solve"]["iterations"] - s["iterations"]) <= 1
+    assert s["repeated_setup_solve"]["true_relres"] < 1e-10
+    assert len(r.stdout.strip().splitlines()) == 1           # stdout is the one JSON line (RCCL's banner and the like go to stderr)
     if "iterations_reference" in s:                          # the reference's run of the same 32^4 case (committed fixture)
         assert abs(s["iterations"] - s["iterations_reference"]) <= 1
     if c["kind"] == "reference":
