@@ -154,7 +154,8 @@ Multigrid<T>::Multigrid(const ddamg_hip_params& par, const std::vector<const Geo
   DDAMG_HIP_CHECK(device_alloc(&d_lex0_, sizeof(int) * g0.V));
   DDAMG_HIP_CHECK(hipMemcpy(d_lex0_, g0.lex_of_site.data(), sizeof(int) * g0.V, hipMemcpyHostToDevice));
   DDAMG_HIP_CHECK(device_alloc(&d_stage_, sizeof(double) * std::max(lv_[0]->nel, max_coarse)));
-  DDAMG_HIP_CHECK(device_alloc(&W_, sizeof(T) * lv_[0]->nel * 5));
+  // (W_, the five full fields of the column-by-column Galerkin construction, is allocated when that path first runs: 8 GB at
+  // 64^4 that the batched construction never touches)
   DDAMG_HIP_CHECK(device_alloc(&cwork_, sizeof(T) * max_coarse * 5));
   if (par.gather_coarsest && lv_.back()->g->distributed()) setup_gathered_coarsest();
 }
@@ -663,6 +664,7 @@ void Multigrid<T>::build_coarse_operator(int l) {
   } else if (l == 0) {
     for (int chir = 0; chir < 2; chir++)
       for (int j = 0; j < N; j++) {
+        if (!W_) DDAMG_HIP_CHECK(device_alloc(&W_, sizeof(T) * lv_[0]->nel * 5));
         aggregate_dirac<T>(W_, lv.fip.interp_vector(j), chir, *lv.fop, lv.d_agg_face, st_);
         galerkin_column<T>(nx.cop, lv.fip, W_, chir * N + j, cwork_, st_);
       }
