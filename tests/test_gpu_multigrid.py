@@ -433,8 +433,10 @@ def test_face_compacted_galerkin_fields_give_the_same_operator(gold_b4, gold8, m
             monkeypatch.delenv(knob)
     for other in res[1:3]:
         assert relerr(res[0][0], other[0]) < 2e-5 and relerr(res[0][1], other[1]) < 2e-5
-        assert not np.array_equal(res[0][0], other[0])        # another code path did run
         assert res[0][3] == other[3] and other[4] < 1e-10 and relerr(res[0][2], other[2]) < 1e-8
+    # another code path did run: the full fields are summed in another order (the gather form of the field kernel differs from
+    # the tiled one only through the two-row links it does not use -- on full link storage the two agree bit for bit)
+    assert not np.array_equal(res[0][0], res[1][0])
     # the restriction writes straight into the coarse matrices; through coarse column vectors and store launches: the same bits
     assert np.array_equal(res[0][0], res[3][0]) and np.array_equal(res[0][1], res[3][1]) and np.array_equal(res[0][2], res[3][2])
 
