@@ -23,24 +23,31 @@ __device__ __forceinline__ void mfma_product(const float2* __restrict__ M, int n
   const int half = n >> 1;
   for (int ks = 0; ks < n; ks += 4) {
     const int k = ks + kq;                       // k < n because n % 4 == 0
+    // every load of the step is issued before the first matrix instruction: the rows beyond n (padding of the last row tile) read
+    // row n - 1 and are zeroed by a select afterwards.  With the loads inside `if (i < n)` the compiler put each of them in its
+    // own exec-mask region with a full s_waitcnt behind it -- three memory round trips per step instead of one (ls_hop_kernel:
+    // 193 us, matrix cores busy 0.31; SQ_WAIT_ANY 73 % of the wavefronts' cycles, profiles/r03_pmc_lockstep.json).  Requesting
+    // the operands of step k+1 before the matrix instructions of step k on top of that changes nothing (137 us either way).
     const float2 b = By[(size_t)k * NC + col0 + r16];
+    float2 a[NRT];
 #pragma unroll
     for (int rt = 0; rt < NRT; rt++) {
-      const int i = rt * 16 + r16;
-      float2 a = make_float2(0.f, 0.f);
-      if (i < n) {
-        if constexpr (!DAG) a = M[tile_at(nt, i, k)];
-        else {
-          const float2 m = M[tile_at(nt, k, i)];
-          const float s = ((i >= half) != (k >= half)) ? -1.f : 1.f;   // G5 M^H G5
-          a = make_float2(s * m.x, -s * m.y);
-        }
+      const int i = rt * 16 + r16, ic = i < n ? i : n - 1;
+      if constexpr (!DAG) a[rt] = M[tile_at(nt, ic, k)];
+      else {
+        const float2 m = M[tile_at(nt, k, ic)];
+        const float s = ((ic >= half) != (k >= half)) ? -1.f : 1.f;   // G5 A^H G5
+        a[rt] = make_float2(s * m.x, -s * m.y);
       }
-      a.x *= sign; a.y *= sign;
-      accR[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.x, accR[rt], 0, 0, 0);
-      accR[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-a.y, b.y, accR[rt], 0, 0, 0);
-      accI[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b.y, accI[rt], 0, 0, 0);
-      accI[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b.x, accI[rt], 0, 0, 0);
+      const float keep = i < n ? sign : 0.f;
+      a[rt].x *= keep; a[rt].y *= keep;
+    }
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) {
+      accR[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].x, b.x, accR[rt], 0, 0, 0);
+      accR[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-a[rt].y, b.y, accR[rt], 0, 0, 0);
+      accI[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].x, b.y, accI[rt], 0, 0, 0);
+      accI[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].y, b.x, accI[rt], 0, 0, 0);
     }
   }
 }

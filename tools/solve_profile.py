@@ -26,7 +26,7 @@ ctx.set_gauge(synth.synth_gauge([ext] * 4, bench.GAUGE_EPS, bench.GAUGE_SEED), a
 t0 = time.time(); ctx.setup(p.setup_iter[0]); ctx.sync(); t_setup = time.time() - t0
 b = np.zeros((V, 12, 2)); b[..., 0] = 1.0
 bv = ctx.vector(0, 64).upload(b); xv = ctx.vector(0, 64); del b
-ctx.solve_vec(xv, bv, 1e-10)
+it, cit, rr = ctx.solve_vec(xv, bv, 1e-10)
 t0 = time.time()
 for _ in range(N):
     it, cit, rr = ctx.solve_vec(xv, bv, 1e-10)
