@@ -22,12 +22,12 @@ __device__ __forceinline__ void wave_mv(const T* __restrict__ Mbase, const T* __
   T xr[NT], xi[NT];  // input entries this lane needs
 #pragma unroll
   for (int t = 0; t < NT; t++) {
-    const int k = (DAG ? a : b) + 8 * t;
-    if (k < n) {
-      c2 z = *reinterpret_cast<const c2*>(v + 2 * k);
-      const T sg = (DAG && k >= half) ? (T)-1 : (T)1;
-      xr[t] = sg * z.x; xi[t] = sg * z.y;
-    } else { xr[t] = 0; xi[t] = 0; }
+    // (unconditional loads with a clamped index, the padding entries zeroed by a select: inside `if (k < n)` every one of them got
+    // its own exec-mask region and a full s_waitcnt -- NT memory round trips in a row in front of the matrix stream)
+    const int k = (DAG ? a : b) + 8 * t, kc = k < n ? k : n - 1;
+    const c2 z = *reinterpret_cast<const c2*>(v + 2 * kc);
+    const T sg = k >= n ? (T)0 : (DAG && k >= half) ? (T)-1 : (T)1;
+    xr[t] = sg * z.x; xi[t] = sg * z.y;
   }
   T ar[NT], ai[NT];
 #pragma unroll
@@ -74,8 +74,9 @@ __device__ __forceinline__ void wave_mv_reg(const typename C2<T>::t (&m)[NT * NT
 #pragma unroll
   for (int t = 0; t < NT; t++) {
     const int k = b + 8 * t;
-    if (k < n) { c2 z = *reinterpret_cast<const c2*>(v + 2 * k); xr[t] = z.x; xi[t] = z.y; }
-    else { xr[t] = 0; xi[t] = 0; }
+    const int kc = k < n ? k : n - 1;                  // unconditional load, see wave_mv
+    const c2 z = *reinterpret_cast<const c2*>(v + 2 * kc);
+    xr[t] = k < n ? z.x : (T)0; xi[t] = k < n ? z.y : (T)0;
   }
   T ar[NT], ai[NT];
 #pragma unroll
@@ -191,13 +192,13 @@ __device__ __forceinline__ void wave_mv2(const T* __restrict__ Mbase, const T* _
   T xr[NT], xi[NT], wr[NT], wi[NT];
 #pragma unroll
   for (int t = 0; t < NT; t++) {
-    const int k = b + 8 * t;
-    if (k < n) { xr[t] = vj[2 * k]; xi[t] = vj[2 * k + 1]; } else { xr[t] = 0; xi[t] = 0; }
-    const int k2 = a + 8 * t;
-    if (k2 < n) {
-      const T sg = k2 >= half ? (T)-1 : (T)1;
-      wr[t] = sg * vi[2 * k2]; wi[t] = sg * vi[2 * k2 + 1];
-    } else { wr[t] = 0; wi[t] = 0; }
+    const int k = b + 8 * t, kc = k < n ? k : n - 1;   // unconditional loads, see wave_mv
+    const c2 zj = *reinterpret_cast<const c2*>(vj + 2 * kc);
+    xr[t] = k < n ? zj.x : (T)0; xi[t] = k < n ? zj.y : (T)0;
+    const int k2 = a + 8 * t, k2c = k2 < n ? k2 : n - 1;
+    const c2 zi = *reinterpret_cast<const c2*>(vi + 2 * k2c);
+    const T sg = k2 >= n ? (T)0 : k2 >= half ? (T)-1 : (T)1;
+    wr[t] = sg * zi.x; wi[t] = sg * zi.y;
   }
   T ar[NT], ai[NT], br[NT], bi[NT];
 #pragma unroll
