@@ -55,17 +55,21 @@ __device__ __forceinline__ void mfma_product(const float2* __restrict__ M, int n
 template <int NRT>
 __device__ __forceinline__ void store_rows(float2* __restrict__ out, int n, int col0, const f32x4 (&accR)[NRT], const f32x4 (&accI)[NRT], bool accumulate) {
   const int l = threadIdx.x & 63, r16 = l & 15, kq = l >> 4;
+  // (accumulate: all old values are requested before the first of them is used -- clamped row index, as in mfma_product)
+  float2 old[NRT][4];
+#pragma unroll
+  for (int rt = 0; rt < NRT; rt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int i = rt * 16 + 4 * kq + r, ic = i < n ? i : n - 1;
+      old[rt][r] = accumulate ? out[(size_t)ic * NC + col0 + r16] : make_float2(0.f, 0.f);
+    }
 #pragma unroll
   for (int rt = 0; rt < NRT; rt++)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int i = rt * 16 + 4 * kq + r;      // result row held in register r
-      if (i < n) {
-        float2* p = out + (size_t)i * NC + col0 + r16;
-        float2 v = make_float2(accR[rt][r], accI[rt][r]);
-        if (accumulate) { const float2 o = *p; v.x += o.x; v.y += o.y; }
-        *p = v;
-      }
+      if (i < n) out[(size_t)i * NC + col0 + r16] = make_float2(accR[rt][r] + old[rt][r].x, accI[rt][r] + old[rt][r].y);
     }
 }
 

@@ -8,5 +8,5 @@ for cfg in "32 2 5" "64 3 2"; do set -- $cfg
   rocprofv3 --kernel-trace --stats -d gpurun_out/ck -o s$1 -- python3 tools/solve_profile.py $3 1 $1 $2 > gpurun_out/ck/run$1.log 2>&1
   python3 tools/rocpd_export.py stats gpurun_out/ck/s$1_results.db gpurun_out/ck/stats$1.csv; rm -f gpurun_out/ck/s$1_results.db
   tail -1 gpurun_out/ck/run$1.log | cut -c1-170
-  grep -E "coarse_site_kernel|coarse_block_minres|coarse_apply_once" gpurun_out/ck/stats$1.csv | sed 's/(float\*.*)"/"/' | cut -c1-140
+  grep -E "coarse_site_kernel|coarse_block_minres|coarse_apply_once|restrict_kernel|interpolate_kernel|ls_hop|ls_self" gpurun_out/ck/stats$1.csv | sed 's/(float\*.*)"/"/' | cut -c1-140
 done
