@@ -251,6 +251,13 @@ __global__ __launch_bounds__(BLOCK_MINRES_THREADS) void coarse_block_minres_kern
     rl[e] = k < 2 * n ? r[(s0 + i) * n * 2 + k] : (T)0;
     lphi[e] = 0;
   }
+  // the item table in LDS: read from global memory it put a memory round trip in front of the matrix stream of every item in
+  // every MinRes step (index, then address)
+  constexpr int ITEMS_MAX = 128;
+  __shared__ int sitems[3 * ITEMS_MAX];
+  const bool items_in_lds = nitems <= ITEMS_MAX;
+  if (items_in_lds) for (int e = tid; e < 3 * nitems; e += NTH) sitems[e] = items[e];
+  const int* __restrict__ itab = items_in_lds ? sitems : items;
   __syncthreads();
   // The self couplings of the block (the first BS items) stay in registers across the MinRes steps when every wavefront owns
   // one of them per wavefront (the register budget of 8 wavefronts per workgroup allows no more: two per wavefront spill 169
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(BLOCK_MINRES_THREADS) void coarse_block_minres_kern
       }
     }
     for (int item = (resident ? RES * nw : 0) + w; item < nitems; item += nw) {
-      const int i = items[3 * item], mu = items[3 * item + 1], j = items[3 * item + 2];
+      const int i = itab[3 * item], mu = itab[3 * item + 1], j = itab[3 * item + 2];
       const T* Mx = op.M + (s0 + i) * 5 * op.msize * 2;
       if (mu < 0) wave_mv<T, NT, false>(Mx, rl + (size_t)i * 2 * np, n, slots + (size_t)(2 * item) * 2 * np);
       else wave_mv2<T, NT>(Mx + (size_t)(1 + mu) * op.msize * 2, rl + (size_t)j * 2 * np, rl + (size_t)i * 2 * np, n,
