@@ -545,10 +545,11 @@ void Multigrid<T>::define_interpolation(int l) {
     random_vector(l, tv);
     t0 = tick("random test vectors", t0);
     // three smoother passes with 1, 2, 3 cycles -- one cycle each with the GMRES smoother (src/setup_generic.c:215-231)
-    for (int c = 1; c <= 3; c++) {
-      smoother(l, lv.buf[2], nullptr, tv, par_.method >= 4 ? 1 : c, NO_RES);
-      vec_copy<T>(tv, lv.buf[2], all, st_);
-    }
+    // (the three passes alternate between the test vector and a work vector: one copy at the end instead of one per pass)
+    smoother(l, lv.buf[2], nullptr, tv, 1, NO_RES);
+    smoother(l, tv, nullptr, lv.buf[2], par_.method >= 4 ? 1 : 2, NO_RES);
+    smoother(l, lv.buf[2], nullptr, tv, par_.method >= 4 ? 1 : 3, NO_RES);
+    vec_copy<T>(tv, lv.buf[2], all, st_);
     tick("initial smoothing", t0);
   }
   for (int k = 0; k < lv.nvec; k++) {
