@@ -57,7 +57,7 @@ def busy(fname, key):
         return {"error": str(e)}
 mf = {"formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)",
       "lockstep_hop": busy(R + "_pmc_mfma_lockstep32.json", "ls_hop_kernel"), "lockstep_self": busy(R + "_pmc_mfma_lockstep32.json", "ls_self_kernel"),
-      "galerkin_coarse_apply": busy(R + "_pmc_mfma.json", "coarse_batch_apply_kernel"), "galerkin_restrict": busy(R + "_pmc_mfma.json", "restrict_mfma_kernel<2>"),
+      "galerkin_coarse_apply": busy(R + "_pmc_mfma.json", "coarse_batch_apply_kernel"), "galerkin_restrict": busy(R + "_pmc_mfma.json", "restrict_mfma_kernel<2"),
       "galerkin_coarse_restrict": busy(R + "_pmc_mfma.json", "coarse_batch_restrict_store_mfma_kernel"),
       "commit": commit, "kernel_source_sha16": bench.mfma_source_hash()}
 json.dump(mf, open(os.path.join(dst, R + "_mfma_busy.json"), "w"), indent=1)
