@@ -151,9 +151,9 @@ __global__ __launch_bounds__(256) void coarse_batch_restrict_store_kernel(float*
 // One workgroup of 4 wavefronts per aggregate, wavefront w the 16 columns 16 w .. 16 w + 15 and both row tiles of all five
 // parts (80 accumulator registers).  conj(P) of the aggregate and one chirality is staged in LDS in two halves of K (50 KB
 // for N <= 32, 2^4 aggregates, n = 48) and serves the five parts; Y is read once.
-// (The kernel above is bound by its dependent scalar loads of P -- 9.8 ms per build at 12^4 x 48 -> 6^4 x 56, 28.9 ms at
-// 16^4 -> 8^4; a matrix-core form that gathered P straight from global memory was slower still, and one with the whole K range
-// of P in 86 KB of dynamic LDS ran in 3.0 ms but cost 13 ms of host time per launch.)
+// (The kernel above is bound by its dependent scalar loads of P -- 9.9 ms per build at 12^4 x 48 -> 6^4 x 56, 28.9 ms at
+// 16^4 -> 8^4; a first matrix-core form with the whole K range of P in 86 KB of dynamic LDS, one workgroup of 8 wavefronts per
+// CU, took 3.0 ms; this one 1.95 ms.)
 constexpr int RS_LDP_MAX = 232;
 __global__ __launch_bounds__(256) void coarse_batch_restrict_store_mfma_kernel(float* __restrict__ Mnext, int nt2, size_t msize2, const float2* __restrict__ Y,
                                                                                size_t y_stride, const float* __restrict__ P, size_t pstride, int n, int N,
