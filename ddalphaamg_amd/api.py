@@ -105,6 +105,14 @@ def load_library():
         "ddamg_hip_get_test_vectors": [vp, dp],
         "ddamg_hip_get_coarse_operator": [vp, dp, dp],
         "ddamg_hip_set_coarse_operator": [vp, dp, dp],
+        "ddamg_hip_get_coarse_operator_level": [vp, ctypes.c_int, dp, dp],
+        "ddamg_hip_set_coarse_operator_level": [vp, ctypes.c_int, dp, dp],
+        "ddamg_hip_set_interpolation_level": [vp, ctypes.c_int, dp],
+        "ddamg_hip_kcycle": [vp, vp, vp, ctypes.POINTER(ctypes.c_int)],
+        "ddamg_hip_coarse_apply_many": [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp)],
+        "ddamg_hip_smoother_many": [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.c_int, ctypes.c_int],
+        "ddamg_hip_vcycle_many": [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp)],
+        "ddamg_hip_kcycle_many": [vp, ctypes.c_int, ctypes.POINTER(vp), ctypes.POINTER(vp), ctypes.POINTER(ctypes.c_int)],
         "ddamg_hip_smoother": [vp, vp, vp, ctypes.c_int, ctypes.c_int],
         "ddamg_hip_restrict": [vp, vp, vp],
         "ddamg_hip_interpolate": [vp, vp, vp, ctypes.c_int],
@@ -366,18 +374,51 @@ class Context:
         _check(self._lib.ddamg_hip_get_test_vectors(self._h, _dp(out)))
         return out
 
-    def get_coarse_operator(self):
-        n = self.ndof(1); Vc = self.volume(1)
+    def get_coarse_operator(self, level=1):
+        n = self.ndof(level); Vc = self.volume(level)
         D = np.empty((Vc, 4, n * n, 2)); cl = np.empty((Vc, n * (n + 1) // 2, 2))
-        _check(self._lib.ddamg_hip_get_coarse_operator(self._h, _dp(D), _dp(cl)))
+        _check(self._lib.ddamg_hip_get_coarse_operator_level(self._h, int(level), _dp(D), _dp(cl)))
         return D, cl
 
-    def set_coarse_operator(self, D, cl):
-        n = self.ndof(1); Vc = self.volume(1)
+    def set_coarse_operator(self, D, cl, level=1):
+        n = self.ndof(level); Vc = self.volume(level)
         D = np.ascontiguousarray(D, dtype=np.float64); cl = np.ascontiguousarray(cl, dtype=np.float64)
         if D.size != Vc * 4 * n * n * 2 or cl.size != Vc * n * (n + 1):
             raise DDAMGError("set_coarse_operator: wrong array sizes")
-        _check(self._lib.ddamg_hip_set_coarse_operator(self._h, _dp(D), _dp(cl)))
+        _check(self._lib.ddamg_hip_set_coarse_operator_level(self._h, int(level), _dp(D), _dp(cl)))
+
+    def set_interpolation(self, P_lex, level=0):
+        """interpolation vectors of `level` as they are ([num_vect][V][ndof][2], lexicographic sites of that level); builds the
+        operator of level + 1 and runs the initial setup of the levels below"""
+        P = np.ascontiguousarray(P_lex, dtype=np.float64)
+        if P.size != self.params.num_vect[level] * self.volume(level) * self.ndof(level) * 2:
+            raise DDAMGError("set_interpolation: wrong array size")
+        _check(self._lib.ddamg_hip_set_interpolation_level(self._h, int(level), _dp(P)))
+
+    def kcycle(self, x, b):
+        it = ctypes.c_int(0)
+        _check(self._lib.ddamg_hip_kcycle(self._h, x._h, b._h, ctypes.byref(it)))
+        return it.value
+
+    def _many(self, fn, outs, ins, *extra):
+        n = len(ins)
+        VP = ctypes.c_void_p * n
+        _check(fn(self._h, n, VP(*[v._h for v in outs]), VP(*[v._h for v in ins]), *extra))
+
+    def coarse_apply_many(self, outs, ins):
+        """the coarse operator of the vectors' level for up to 32 right-hand sides at once (matrix cores)"""
+        self._many(self._lib.ddamg_hip_coarse_apply_many, outs, ins)
+
+    def smoother_many(self, phis, etas, cycles, initial_guess_zero=True):
+        self._many(self._lib.ddamg_hip_smoother_many, phis, etas, int(cycles), int(bool(initial_guess_zero)))
+
+    def vcycle_many(self, phis, etas):
+        self._many(self._lib.ddamg_hip_vcycle_many, phis, etas)
+
+    def kcycle_many(self, xs, bs):
+        its = (ctypes.c_int * len(bs))()
+        self._many(self._lib.ddamg_hip_kcycle_many, xs, bs, its)
+        return list(its)
 
     def smoother(self, phi, eta, cycles, initial_guess_zero=True):
         _check(self._lib.ddamg_hip_smoother(self._h, phi._h, eta._h, int(cycles), int(bool(initial_guess_zero))))

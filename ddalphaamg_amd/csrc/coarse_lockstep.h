@@ -22,6 +22,18 @@ namespace ddamg {
 
 constexpr int LOCKSTEP_COLS = 32;
 
+// BLAS-1 on batches [row][c] (c < LOCKSTEP_COLS), every column with its own coefficients; deterministic two-stage fp64 sums.
+//   batch_dots:      d_out[(i * 32 + c) * 2 ..] = <V_i, w>_c for i < m (V_i = basis + i * vstride); d_partial: batch_dots_workspace() doubles
+//   batch_axpy:      w[.][c] += sign * sum_i coef[i][c] V_i[.][c]
+//   batch_scale_inv: out[.][c] = w[.][c] / sqrt(n2[c]) (a column of norm <= 1e-15 is copied)
+//   batch_gather / batch_scatter: ordinary vectors (column c at src + c * sstride, `rows` complex numbers) <-> the batch
+void batch_gather(float2* Wb, const float* src, size_t sstride, int ncols, size_t rows, hipStream_t st);
+void batch_scatter(float* dst, size_t dstride, const float2* Wb, int ncols, size_t rows, hipStream_t st);
+size_t batch_dots_workspace();
+void batch_dots(const float2* basis, size_t vstride, int m, const float2* w, size_t rows, double* d_partial, double* d_out, hipStream_t st);
+void batch_axpy(float2* w, const float2* basis, size_t vstride, int m, const double* d_coef, double sign, size_t elems, hipStream_t st);
+void batch_scale_inv(float2* out, const float2* w, const double* d_norm2, size_t elems, hipStream_t st);
+
 class LockstepCoarseSolver {
  public:
   ~LockstepCoarseSolver();
@@ -33,6 +45,10 @@ class LockstepCoarseSolver {
   // iters[c] = GMRES iterations of column c, or -1 if the column did not converge within max_steps (the caller then solves
   // it with the one-at-a-time solver: restarts are not advanced in lockstep).  Returns the sum of the iteration counts.
   int solve(float* X, size_t xstride, const float* B, size_t bstride, int ncols, int* iters);
+  // the same on batches (the level's site order): Bb -> batch(1), batch(0) -> Xb; active[c] == 0 leaves column c out (x = 0)
+  int solve_batch(float2* Xb, const float2* Bb, int ncols, int* iters, const unsigned char* active);
+  // out = D in on the whole level for all columns (batches): ls_self_kernel + ls_hop_kernel
+  void apply(float2* out, const float2* in);
   // out = S in (even sites) for all columns: exposed for tests and measurements (batch layout)
   void schur(float2* out, const float2* in);
   float2* batch(int i) { return W_[i]; }     // work batches (whole lattice), i < 4

@@ -1,55 +1,22 @@
 // coarse_lockstep.hip -- see coarse_lockstep.h
 #include "coarse_lockstep.h"
+#include "mfma_tile.h"
 #include <complex>
 #include <cmath>
 
 namespace ddamg {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef mfma_f32x4 f32x4;
 constexpr int NC = LOCKSTEP_COLS;
 constexpr int DOT_BLOCKS = 128, DOT_CHUNK = 8;
 
 namespace {
 
-__device__ __forceinline__ size_t tile_at(int nt, int i, int j) { return ((size_t)((i >> 3) * nt + (j >> 3)) * 64 + (i & 7) * 8 + (j & 7)); }
-
-// acc += sign * A B,  A = the n x n coupling matrix M (tile layout of coarse_op.h) or G5 M^H G5 (DAG: the backward coupling
-// from the neighbour's forward matrix), B = the batch of one site ([k][c], NC columns).  One wavefront: 16 columns
-// (col0 .. col0+15) and NRT row tiles of 16; a complex product is four real v_mfma_f32_16x16x4_f32.
+// the complex (n x n) x (n x 16) product of one wavefront: mfma_tile.h
 template <int NRT, bool DAG>
 __device__ __forceinline__ void mfma_product(const float2* __restrict__ M, int nt, int n, const float2* __restrict__ By, int col0, float sign,
                                              f32x4 (&accR)[NRT], f32x4 (&accI)[NRT]) {
-  const int l = threadIdx.x & 63, r16 = l & 15, kq = l >> 4;
-  const int half = n >> 1;
-  for (int ks = 0; ks < n; ks += 4) {
-    const int k = ks + kq;                       // k < n because n % 4 == 0
-    // every load of the step is issued before the first matrix instruction: the rows beyond n (padding of the last row tile) read
-    // row n - 1 and are zeroed by a select afterwards.  With the loads inside `if (i < n)` the compiler put each of them in its
-    // own exec-mask region with a full s_waitcnt behind it -- three memory round trips per step instead of one (ls_hop_kernel:
-    // 193 us, matrix cores busy 0.31; SQ_WAIT_ANY 73 % of the wavefronts' cycles, profiles/r03_pmc_lockstep.json).  Requesting
-    // the operands of step k+1 before the matrix instructions of step k on top of that changes nothing (137 us either way).
-    const float2 b = By[(size_t)k * NC + col0 + r16];
-    float2 a[NRT];
-#pragma unroll
-    for (int rt = 0; rt < NRT; rt++) {
-      const int i = rt * 16 + r16, ic = i < n ? i : n - 1;
-      if constexpr (!DAG) a[rt] = M[tile_at(nt, ic, k)];
-      else {
-        const float2 m = M[tile_at(nt, k, ic)];
-        const float s = ((ic >= half) != (k >= half)) ? -1.f : 1.f;   // G5 A^H G5
-        a[rt] = make_float2(s * m.x, -s * m.y);
-      }
-      const float keep = i < n ? sign : 0.f;
-      a[rt].x *= keep; a[rt].y *= keep;
-    }
-#pragma unroll
-    for (int rt = 0; rt < NRT; rt++) {
-      accR[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].x, b.x, accR[rt], 0, 0, 0);
-      accR[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-a[rt].y, b.y, accR[rt], 0, 0, 0);
-      accI[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].x, b.y, accI[rt], 0, 0, 0);
-      accI[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].y, b.x, accI[rt], 0, 0, 0);
-    }
-  }
+  mfma_cproduct<NRT, DAG>(M, nt, n, By + col0, NC, sign, accR, accI);
 }
 
 template <int NRT>
@@ -211,6 +178,35 @@ void launch_nrt(int nrt, K k1, K k2, K k3, K k4, dim3 grid, dim3 block, hipStrea
 
 }  // namespace
 
+// ---- BLAS-1 on batches, every column with its own coefficients (shared with coarse_multi.hip) ----------------------------
+void batch_gather(float2* Wb, const float* src, size_t sstride, int ncols, size_t rows, hipStream_t st) {
+  const size_t tot = rows * NC;
+  hipLaunchKernelGGL(ls_gather_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, Wb, src, sstride, ncols, rows);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+void batch_scatter(float* dst, size_t dstride, const float2* Wb, int ncols, size_t rows, hipStream_t st) {
+  const size_t tot = rows * ncols;
+  hipLaunchKernelGGL(ls_scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, dst, dstride, Wb, ncols, rows);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+size_t batch_dots_workspace() { return (size_t)2 * DOT_BLOCKS * DOT_CHUNK * NC; }
+void batch_dots(const float2* basis, size_t vstride, int m, const float2* w, size_t rows, double* d_partial, double* d_out, hipStream_t st) {
+  for (int i0 = 0; i0 < m; i0 += DOT_CHUNK) {
+    const int mc = std::min(DOT_CHUNK, m - i0);
+    hipLaunchKernelGGL(ls_dot_kernel, dim3(DOT_BLOCKS), dim3(256), 0, st, d_partial, basis + (size_t)i0 * vstride, vstride, mc, w, rows);
+    hipLaunchKernelGGL(ls_dot_final_kernel, dim3((mc * NC + 255) / 256), dim3(256), 0, st, d_out + (size_t)i0 * NC * 2, d_partial, DOT_BLOCKS, mc);
+  }
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+void batch_axpy(float2* w, const float2* basis, size_t vstride, int m, const double* d_coef, double sign, size_t elems, hipStream_t st) {
+  hipLaunchKernelGGL(ls_axpy_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, w, basis, vstride, m, d_coef, sign, elems);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+void batch_scale_inv(float2* out, const float2* w, const double* d_norm2, size_t elems, hipStream_t st) {
+  hipLaunchKernelGGL(ls_scale_inv_kernel, dim3((unsigned)((elems + 255) / 256)), dim3(256), 0, st, out, w, d_norm2, elems);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
 bool LockstepCoarseSolver::available(const CoarseOp<float>& cop, int ncols, bool odd_even) {
   static const bool off = getenv("DDAMG_BOOTSTRAP_NO_LOCKSTEP") != nullptr;
   return !off && odd_even && !cop.distributed() && ncols >= 2 && ncols <= NC && cop.n() <= 64 && cop.n() % 4 == 0 && cop.V() % 2 == 0;
@@ -241,16 +237,8 @@ void LockstepCoarseSolver::init(const CoarseOp<float>* cop, int max_steps, doubl
   DDAMG_HIP_CHECK(hipHostMalloc(&h_coef_, sizeof(double) * 2 * (max_steps_ + 2) * NC));
 }
 
-void LockstepCoarseSolver::gather(float2* Wb, const float* src, size_t sstride, int ncols) {
-  const size_t rows = (size_t)V_ * n_, tot = rows * NC;
-  hipLaunchKernelGGL(ls_gather_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st_, Wb, src, sstride, ncols, rows);
-  DDAMG_HIP_CHECK(hipGetLastError());
-}
-void LockstepCoarseSolver::scatter(float* dst, size_t dstride, const float2* Wb, int ncols) {
-  const size_t rows = (size_t)V_ * n_, tot = rows * ncols;
-  hipLaunchKernelGGL(ls_scatter_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st_, dst, dstride, Wb, ncols, rows);
-  DDAMG_HIP_CHECK(hipGetLastError());
-}
+void LockstepCoarseSolver::gather(float2* Wb, const float* src, size_t sstride, int ncols) { batch_gather(Wb, src, sstride, ncols, (size_t)V_ * n_, st_); }
+void LockstepCoarseSolver::scatter(float* dst, size_t dstride, const float2* Wb, int ncols) { batch_scatter(dst, dstride, Wb, ncols, (size_t)V_ * n_, st_); }
 void LockstepCoarseSolver::self(float2* out, const float2* in, int s0, int s1, bool inverse) {
   launch_nrt((n_ + 15) / 16, ls_self_kernel<1>, ls_self_kernel<2>, ls_self_kernel<3>, ls_self_kernel<4>, dim3(s1 - s0), dim3(128), st_, out, in, cop_->dev(), s0,
              inverse ? 1 : 0);
@@ -258,6 +246,11 @@ void LockstepCoarseSolver::self(float2* out, const float2* in, int s0, int s1, b
 void LockstepCoarseSolver::hop(float2* out, const float2* in, int s0, int s1, float sign, bool accumulate) {
   launch_nrt((n_ + 15) / 16, ls_hop_kernel<1>, ls_hop_kernel<2>, ls_hop_kernel<3>, ls_hop_kernel<4>, dim3(s1 - s0), dim3(128), st_, out, in, cop_->dev(), s0, sign,
              accumulate ? 1 : 0);
+}
+// apply_coarse_operator_PRECISION (src/coarse_operator_generic.c:383-394) for all columns
+void LockstepCoarseSolver::apply(float2* out, const float2* in) {
+  self(out, in, 0, V_, false);                 // out = D_self in
+  hop(out, in, 0, V_, -1.f, true);             // out -= H in
 }
 // coarse_apply_schur_complement_PRECISION (src/coarse_oddeven_generic.c:1162-1189) for all columns
 void LockstepCoarseSolver::schur(float2* out, const float2* in) {
@@ -267,31 +260,30 @@ void LockstepCoarseSolver::schur(float2* out, const float2* in) {
   hop(out, W_[3], 0, Ve_, +1.f, true);         // out_e += H_eo t1_o  (= -D_eo t1_o)
 }
 void LockstepCoarseSolver::dots(const float2* basis, int m, const float2* w, double* d_out) {
-  const size_t rows = (size_t)Ve_ * n_;
-  for (int i0 = 0; i0 < m; i0 += DOT_CHUNK) {
-    const int mc = std::min(DOT_CHUNK, m - i0);
-    hipLaunchKernelGGL(ls_dot_kernel, dim3(DOT_BLOCKS), dim3(256), 0, st_, d_partial_, basis + (size_t)i0 * even_elems(), even_elems(), mc, w, rows);
-    hipLaunchKernelGGL(ls_dot_final_kernel, dim3((mc * NC + 255) / 256), dim3(256), 0, st_, d_out + (size_t)i0 * NC * 2, d_partial_, DOT_BLOCKS, mc);
-  }
-  DDAMG_HIP_CHECK(hipGetLastError());
+  batch_dots(basis, even_elems(), m, w, (size_t)Ve_ * n_, d_partial_, d_out, st_);
 }
 void LockstepCoarseSolver::axpy(float2* w, const float2* basis, int m, const double* d_coef, double sign) {
-  const size_t el = even_elems();
-  hipLaunchKernelGGL(ls_axpy_kernel, dim3((unsigned)((el + 255) / 256)), dim3(256), 0, st_, w, basis, el, m, d_coef, sign, el);
-  DDAMG_HIP_CHECK(hipGetLastError());
+  batch_axpy(w, basis, even_elems(), m, d_coef, sign, even_elems(), st_);
 }
-void LockstepCoarseSolver::scale_inv(float2* out, const float2* w, const double* d_norm) {
-  const size_t el = even_elems();
-  hipLaunchKernelGGL(ls_scale_inv_kernel, dim3((unsigned)((el + 255) / 256)), dim3(256), 0, st_, out, w, d_norm, el);
-  DDAMG_HIP_CHECK(hipGetLastError());
-}
+void LockstepCoarseSolver::scale_inv(float2* out, const float2* w, const double* d_norm) { batch_scale_inv(out, w, d_norm, even_elems(), st_); }
 
 int LockstepCoarseSolver::solve(float* X, size_t xstride, const float* B, size_t bstride, int ncols, int* iters) {
+  DDAMG_REQUIRE(ready() && ncols <= NC, "lockstep coarse solver not set up");
+  gather(W_[1], B, bstride, ncols);
+  const int total = solve_batch(nullptr, nullptr, ncols, iters, nullptr);
+  scatter(X, xstride, W_[0], ncols);
+  DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
+  return total;
+}
+
+// the same on batches ([x][k][c], the level's site order): Bb -> batch(1), the solution batch(0) -> Xb (null: the caller filled
+// batch(1) and reads batch(0) itself).  active[c] == 0: column c is not solved (x = 0, no iterations counted).
+int LockstepCoarseSolver::solve_batch(float2* Xb, const float2* Bb, int ncols, int* iters, const unsigned char* active) {
   typedef std::complex<double> cd;
   DDAMG_REQUIRE(ready() && ncols <= NC, "lockstep coarse solver not set up");
   float2 *x = W_[0], *b = W_[1];
   const size_t el = even_elems();
-  gather(b, B, bstride, ncols);
+  if (Bb) DDAMG_HIP_CHECK(hipMemcpyAsync(b, Bb, sizeof(float2) * batch_elems(), hipMemcpyDeviceToDevice, st_));
   DDAMG_HIP_CHECK(hipMemsetAsync(x, 0, sizeof(float2) * batch_elems(), st_));
   // coarse_solve_odd_even_PRECISION (src/coarse_oddeven_generic.c:1139-1159): right-hand side of the even-site system
   self(x, b, Ve_, V_, true);                   // x_o = D_oo^-1 b_o
@@ -309,7 +301,7 @@ int LockstepCoarseSolver::solve(float* X, size_t xstride, const float* B, size_t
   for (int c = 0; c < ncols; c++) {
     cols[c].norm_r0 = std::sqrt(std::max(h_h_[2 * c], 0.0));
     cols[c].gamma[0] = cols[c].norm_r0;
-    if (!(cols[c].norm_r0 > 0)) { cols[c].done = true; cols[c].ok = true; }   // zero right-hand side: x = 0
+    if (!(cols[c].norm_r0 > 0) || (active && !active[c])) { cols[c].done = true; cols[c].ok = true; }   // zero right-hand side: x = 0
     else open++;
   }
   steps_taken = 0;
@@ -371,7 +363,7 @@ int LockstepCoarseSolver::solve(float* X, size_t xstride, const float* B, size_t
   }
   hop(b, x, Ve_, V_, +1.f, true);              // b_o <- b_o - D_oe x_e
   self(x, b, Ve_, V_, true);                   // x_o = D_oo^-1 b_o
-  scatter(X, xstride, x, ncols);
+  if (Xb) DDAMG_HIP_CHECK(hipMemcpyAsync(Xb, x, sizeof(float2) * batch_elems(), hipMemcpyDeviceToDevice, st_));
   DDAMG_HIP_CHECK(hipStreamSynchronize(st_));  // h_coef_ / h_h_ are reused by the next call
   return total;
 }

@@ -264,7 +264,9 @@ __global__ __launch_bounds__(BLOCK_MINRES_THREADS) void coarse_block_minres_kern
   // registers): a 2^4 block streams 48 matrices per step, from the second step on 40 (885 -> 737 KB per step at n = 48)
   using c2 = typename C2<T>::t;
   constexpr int RES = 1;
-  const bool resident = NT <= 6;   // the first RES * nw self items; the others are streamed like the links
+  // the first RES * nw self items; the others are streamed like the links.  Blocks with fewer sites than that (a 2x2x1x1
+  // block) have hopping items among the first RES * nw: everything is streamed there
+  const bool resident = NT <= 6 && BS >= RES * nw;
   c2 mres[RES][NT * NT];
   if (resident) {
 #pragma unroll
@@ -438,7 +440,7 @@ void CoarseOp<T>::free_block_plan(BlockPlan& p) {
 
 template <typename T>
 bool CoarseOp<T>::block_minres(T* x, T* r, T* latest, const int* blocks, int nblocks, const BlockPlan& plan, int iters, double eps, hipStream_t st) const {
-  static const bool off = getenv("DDAMG_COARSE_SAP_UNFUSED") != nullptr;
+  const bool off = getenv("DDAMG_COARSE_SAP_UNFUSED") != nullptr;   // read at every call: tests switch it within one process
   const int np = 8 * nt_, BS = plan.block_sites;
   size_t lds = 48 * sizeof(double) + sizeof(T) * 2 * np * ((size_t)2 * BS + (size_t)2 * plan.nitems);
   // workgroups per CU (experiment knob): the couplings of a block are streamed once per MinRes step; with fewer blocks in flight

@@ -447,6 +447,117 @@ bool Multigrid<T>::coarse_solve_many(T* X, size_t xstride, const T* B, size_t bs
   return false;
 }
 
+template <typename T>
+bool Multigrid<T>::coarsest_apply_many(T* out, size_t ostride, const T* in, size_t istride, int ncols) {
+  if constexpr (sizeof(T) == 4) {
+    MGLevel<T>& lv = *lv_.back();
+    if (gath_.on || !LockstepCoarseSolver::available(lv.cop, ncols, par_.odd_even != 0)) return false;
+    ensure_lockstep();
+    lockstep_.gather(lockstep_.batch(2), in, istride, ncols);
+    lockstep_.apply(lockstep_.batch(3), lockstep_.batch(2));
+    lockstep_.scatter(out, ostride, lockstep_.batch(3), ncols);
+    return true;
+  }
+  return false;
+}
+
+// ---- the intermediate level of a three-level hierarchy for many right-hand sides (coarse_multi.h) -------------------------
+template <typename T>
+void Multigrid<T>::ensure_lockstep() {
+  if constexpr (sizeof(T) == 4) {
+    MGLevel<T>& lc = *lv_.back();
+    if (!lockstep_.ready()) lockstep_.init(&lc.cop, std::min(lc.gm.restart_length, 24), lc.gm.tol, st_);
+  }
+}
+template <typename T>
+bool Multigrid<T>::level1_multi_ready(int ncols) {
+  if constexpr (sizeof(T) == 4) {
+    // mixed precision 2: the K-cycle takes D*phi out of the smoother's residual (src/linsolve_generic.c:757,828-835), which the
+    // batched smoother does not return -- one vector at a time there
+    if (num_levels() != 3 || gath_.on || comm_ != nullptr || par_.mixed_precision == 2 || !par_.odd_even || ncols < 2 || ncols > LOCKSTEP_COLS) return false;
+    MGLevel<T>& l1 = *lv_[1];
+    if (l1.nvec > 32 || !CoarseMulti::available(*l1.g, l1.cop, par_.method) || !LockstepCoarseSolver::available(lv_[2]->cop, ncols, true)) return false;
+    if (!multi1_.ready()) multi1_.init(*l1.g, &l1.cop, &l1.cip, par_.block_iter[1], st_);
+    ensure_lockstep();
+    return true;
+  }
+  return false;
+}
+template <typename T>
+int Multigrid<T>::multi1_vcycle(float2* phi, const float2* eta, int ncols) {
+  if constexpr (sizeof(T) == 4) {
+    MGLevel<T>& lc = *lv_.back();
+    const int it = multi1_.vcycle(phi, eta, ncols, par_.post_smooth_iter[1], lockstep_, [this] { this->coarse_solve(); }, lc.gm.x, lc.gm.b, nullptr);
+    coarse_iter_count += it;
+    return it;
+  }
+  return 0;
+}
+template <typename T>
+int Multigrid<T>::multi1_kcycle(float2* X, const float2* B, int ncols, int* iters) {
+  if constexpr (sizeof(T) == 4) {
+    MGLevel<T>& l1 = *lv_[1];
+    MGLevel<T>& lc = *lv_.back();
+    const int it = multi1_.kcycle(X, B, ncols, l1.gm.restart_length, l1.gm.num_restart, l1.gm.tol, par_.post_smooth_iter[1], lockstep_,
+                                  [this] { this->coarse_solve(); }, lc.gm.x, lc.gm.b, iters);
+    coarse_iter_count += it;
+    return it;
+  }
+  return 0;
+}
+template <typename T>
+bool Multigrid<T>::level1_apply_many(T* out, size_t ostride, const T* in, size_t istride, int ncols) {
+  if constexpr (sizeof(T) == 4) {
+    if (!level1_multi_ready(ncols)) return false;
+    multi1_.gather(multi1_.work(0), in, istride, ncols);
+    multi1_.apply(multi1_.work(1), multi1_.work(0));
+    multi1_.scatter(out, ostride, multi1_.work(1), ncols);
+    return true;
+  }
+  return false;
+}
+template <typename T>
+bool Multigrid<T>::level1_smooth_many(T* phi, size_t pstride, const T* eta, size_t estride, int ncols, int cycles, int res) {
+  if constexpr (sizeof(T) == 4) {
+    if (!level1_multi_ready(ncols)) return false;
+    multi1_.gather(multi1_.work(0), eta, estride, ncols);
+    if (res == RES) multi1_.gather(multi1_.work(1), phi, pstride, ncols);
+    multi1_.smooth(multi1_.work(1), multi1_.work(0), cycles, res);
+    multi1_.scatter(phi, pstride, multi1_.work(1), ncols);
+    return true;
+  }
+  return false;
+}
+template <typename T>
+bool Multigrid<T>::level1_vcycle_many(T* phi, size_t pstride, const T* eta, size_t estride, int ncols) {
+  if constexpr (sizeof(T) == 4) {
+    if (!level1_multi_ready(ncols)) return false;
+    multi1_.gather(multi1_.work(0), eta, estride, ncols);
+    multi1_vcycle(multi1_.work(1), multi1_.work(0), ncols);
+    multi1_.scatter(phi, pstride, multi1_.work(1), ncols);
+    return true;
+  }
+  return false;
+}
+template <typename T>
+bool Multigrid<T>::level1_kcycle_many(T* x, size_t xstride, const T* b, size_t bstride, int ncols, int* iters) {
+  if constexpr (sizeof(T) == 4) {
+    if (!level1_multi_ready(ncols) || !par_.kcycle) return false;
+    multi1_.gather(multi1_.work(0), b, bstride, ncols);
+    multi1_kcycle(multi1_.work(1), multi1_.work(0), ncols, iters);
+    multi1_.scatter(x, xstride, multi1_.work(1), ncols);
+    return true;
+  }
+  return false;
+}
+template <typename T>
+int Multigrid<T>::kcycle_solve(int l) {
+  MGLevel<T>& lv = *lv_[l];
+  DDAMG_REQUIRE(l > 0 && !lv.coarsest && par_.kcycle, "kcycle_solve: an intermediate level with the K-cycle switched on");
+  lv.gm.initial_guess_zero = true;
+  return lv.gm.solve();
+}
+
 // ---- V-cycle / K-cycle (post-smoothing only) --------------------------------------------------------
 template <typename T>
 void Multigrid<T>::vcycle(int l, T* phi, T* Dphi, const T* eta, int res) {
@@ -539,7 +650,25 @@ template <typename T>
 void Multigrid<T>::define_interpolation(int l) {
   MGLevel<T>& lv = *lv_[l];
   const View all = whole(lv.nel);
-  for (int k = 0; k < lv.nvec; k++) {
+  bool batched = false;
+  if constexpr (sizeof(T) == 4) {
+    if (l == 1 && par_.method == 2 && level1_multi_ready(lv.nvec)) {
+      // the three smoother passes of all test vectors of the level at once (coarse_multi.h); the random numbers in the
+      // reference's order first
+      double t0 = tick(nullptr, 0);
+      for (int k = 0; k < lv.nvec; k++) random_vector(l, test_vector(l, k));
+      t0 = tick("random test vectors", t0);
+      float2 *A = multi1_.work(0), *Bt = multi1_.work(1);
+      multi1_.gather(A, tv_base(l), tv_stride(l), lv.nvec);
+      multi1_.smooth(Bt, A, 1, NO_RES);
+      multi1_.smooth(A, Bt, 2, NO_RES);
+      multi1_.smooth(Bt, A, 3, NO_RES);
+      multi1_.scatter(tv_base(l), tv_stride(l), Bt, lv.nvec);
+      tick("initial smoothing", t0);
+      batched = true;
+    }
+  }
+  for (int k = 0; k < lv.nvec && !batched; k++) {
     T* tv = test_vector(l, k);
     double t0 = tick(nullptr, 0);
     random_vector(l, tv);
@@ -632,6 +761,9 @@ void Multigrid<T>::build_coarse_operator(int l) {
     }
     const int batch = gal_batch_;
     DDAMG_REQUIRE(direct || gal_C_elems_ >= (size_t)5 * gal_batch_ * cs, "Galerkin construction: the workspace of this context was sized for the direct store of the restriction");
+    // ... and for face-compacted or full fields: the knobs are read at every build, the workspace is sized at the first one of a setup
+    DDAMG_REQUIRE(gal_W_elems_ >= (gal_slab_aggs_ > 0 ? (size_t)2 * N * wcol_agg * std::min(gal_slab_aggs_, nagg) : (size_t)batch * wcol),
+                  "Galerkin construction: the workspace of this context was sized for another field layout (DDAMG_GALERKIN_FULL_FIELDS changed between two builds of one setup)");
     T *Wb = gal_W_, *Cb = gal_C_;
     if (gal_slab_aggs_ > 0) {
       for (int a0 = 0; a0 < nagg; a0 += gal_slab_aggs_) {
@@ -711,6 +843,7 @@ void Multigrid<T>::release_setup_workspace() {
   if (gal_C_) { DDAMG_HIP_CHECK(hipFree(gal_C_)); gal_C_ = nullptr; gal_C_elems_ = 0; }
   if (gal_cwork_) { DDAMG_HIP_CHECK(hipFree(gal_cwork_)); gal_cwork_ = nullptr; }
   lockstep_.release();
+  multi1_.release();
 }
 
 template <typename T>
@@ -786,6 +919,22 @@ bool Multigrid<T>::bootstrap_vcycles_batched() {
       in_lockstep = true;
     }
   }
+  if constexpr (sizeof(T) == 4) {
+    if (!nx.coarsest && par_.kcycle && level1_multi_ready(N)) {
+      // three levels: the N K-cycles of the intermediate level in lockstep -- operator, Schwarz smoother, transfers and the
+      // coarsest solves for all columns at once (coarse_multi.h), every column with its own FGMRES recurrence
+      float2 *B1 = multi1_.work(0), *X1 = multi1_.work(1);
+      std::vector<int> its(N);
+      multi1_.gather(B1, Cb, cs, N);
+      multi1_kcycle(X1, B1, N, its.data());
+      multi1_.scatter(Cx, cs, X1, N);
+      // test_vector_PRECISION_update of the intermediate level from the K-cycle iterates
+      const int nup = std::min(N, nx.nvec);
+      multi1_.normalize_columns(X1);
+      multi1_.scatter(tv_base(1), tv_stride(1), X1, nup);
+      in_lockstep = true;
+    }
+  }
   for (int i = 0; i < N && !in_lockstep; i++) {
     vec_copy<T>(nx.gm.b, Cb + (size_t)i * cs, call, st_);
     if (nx.coarsest) {
@@ -836,7 +985,19 @@ void Multigrid<T>::bootstrap(int l, int iters) {
         bootstrap(1, std::max(1, (int)std::lround((double)((j + 1) * par_.setup_iter[1]) / (double)iters)));
       continue;
     }
-    for (int i = 0; i < lv.nvec; i++) {
+    bool level_batched = false;
+    if constexpr (sizeof(T) == 4) {
+      if (l == 1 && level1_multi_ready(lv.nvec)) {
+        // the V-cycles of all test vectors of the intermediate level at once (coarse_multi.h)
+        float2 *E = multi1_.work(0), *Phi = multi1_.work(1);
+        multi1_.gather(E, tv_base(1), tv_stride(1), lv.nvec);
+        multi1_vcycle(Phi, E, lv.nvec);
+        multi1_.normalize_columns(Phi);
+        multi1_.scatter(tv_base(1), tv_stride(1), Phi, lv.nvec);
+        level_batched = true;
+      }
+    }
+    for (int i = 0; i < lv.nvec && !level_batched; i++) {
       T* out = l == 0 ? lv.buf[2] : lv.gm.x;   // the reference writes into l->p_PRECISION.x
       vcycle(l, out, nullptr, test_vector(l, i), NO_RES);
       // test_vector_PRECISION_update: deeper intermediate levels first, from their K-cycle iterate
@@ -902,6 +1063,25 @@ void Multigrid<T>::import_interpolation(const double* P_lex_host) {
   }
   build_coarse_operator(0);
   initial_setup_from(1);   // deeper levels get their own initial setup on the new level-1 operator
+}
+
+template <typename T>
+void Multigrid<T>::import_interpolation_level(int l, const double* P_lex_host) {
+  if (l == 0) { import_interpolation(P_lex_host); return; }
+  MGLevel<T>& lv = *lv_[l];
+  DDAMG_REQUIRE(l > 0 && l + 1 < num_levels(), "import_interpolation_level: the level has no coarser level below it");
+  int* d_lex = nullptr;
+  DDAMG_HIP_CHECK(device_alloc(&d_lex, sizeof(int) * lv.g->V));
+  DDAMG_HIP_CHECK(hipMemcpy(d_lex, lv.g->lex_of_site.data(), sizeof(int) * lv.g->V, hipMemcpyHostToDevice));
+  for (int k = 0; k < lv.nvec; k++) {
+    DDAMG_HIP_CHECK(hipMemcpyAsync(d_stage_, P_lex_host + (size_t)k * lv.nel, sizeof(double) * lv.nel, hipMemcpyHostToDevice, st_));
+    aos_from_lex<T>(lv.cip.interp_vector(k), d_stage_, d_lex, lv.g->V, lv.n, st_);
+    aos_from_lex<T>(lv.cip.test_vector(k), d_stage_, d_lex, lv.g->V, lv.n, st_);
+    DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
+  }
+  DDAMG_HIP_CHECK(hipFree(d_lex));
+  build_coarse_operator(l);
+  initial_setup_from(l + 1);
 }
 
 template class Multigrid<float>;

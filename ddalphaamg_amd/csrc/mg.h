@@ -15,6 +15,7 @@
 #include "coarse_op.h"
 #include "coarse_mg.h"
 #include "coarse_lockstep.h"
+#include "coarse_multi.h"
 #include "krylov.h"
 #include "../../include/ddamg_hip.h"
 #include <memory>
@@ -101,7 +102,18 @@ class Multigrid {
   int coarse_solve();                                            // coarsest level, vectors coarse_x()/coarse_b()
   // ncols right-hand sides in lockstep (coarse_lockstep.h); X, B: columns of ordinary coarsest-level vectors; false if the shape is not covered
   bool coarse_solve_many(T* X, size_t xstride, const T* B, size_t bstride, int ncols, int* iters);
+  bool coarsest_apply_many(T* out, size_t ostride, const T* in, size_t istride, int ncols);   // the coarsest operator itself, all columns (ls_self_kernel + ls_hop_kernel)
+  void release_many_workspace() { lockstep_.release(); multi1_.release(); }                   // what the *_many entry points allocate lazily
+  void import_interpolation_level(int l, const double* P_lex_host);                           // level-l interpolation vectors as they are, then the operators below
   void vcycle(int l, T* phi, T* Dphi, const T* eta, int res);
+  // ---- many right-hand sides on the intermediate level of a three-level hierarchy (coarse_multi.h; fp32, single process) ------
+  // columns: ordinary level-1 vectors, column c at base + c * stride.  false if the shape is not covered.
+  bool level1_multi_ready(int ncols);
+  bool level1_apply_many(T* out, size_t ostride, const T* in, size_t istride, int ncols);
+  bool level1_smooth_many(T* phi, size_t pstride, const T* eta, size_t estride, int ncols, int cycles, int res);
+  bool level1_vcycle_many(T* phi, size_t pstride, const T* eta, size_t estride, int ncols);
+  bool level1_kcycle_many(T* x, size_t xstride, const T* b, size_t bstride, int ncols, int* iters);
+  int kcycle_solve(int l);                                       // the K-cycle FGMRES of level l on level(l).gm.b -> gm.x, one vector
 
   int num_levels() const { return (int)lv_.size(); }
   MGLevel<T>& level(int l) { return *lv_[l]; }
@@ -133,6 +145,10 @@ class Multigrid {
 
   GatheredCoarsest<T> gath_;
   LockstepCoarseSolver lockstep_;   // the bootstrap's coarsest-level solves, all test vectors at once (fp32, single process)
+  CoarseMulti multi1_;              // three levels: the intermediate level for all test vectors at once (coarse_multi.h)
+  void ensure_lockstep();
+  int multi1_vcycle(float2* phi, const float2* eta, int ncols);
+  int multi1_kcycle(float2* X, const float2* B, int ncols, int* iters);
   void setup_gathered_coarsest();
   void schur(T* out, const T* in);
   void schur_on(const CoarseOp<T>& cop, int V, T* t0, T* t1, T* out, const T* in);

@@ -320,23 +320,39 @@ int ddamg_hip_get_test_vectors(ddamg_hip_ctx* c, double* tv_lex) {
   DDAMG_API_END
 }
 
-int ddamg_hip_get_coarse_operator(ddamg_hip_ctx* c, double* D_lex, double* clover_lex) {
+int ddamg_hip_get_coarse_operator_level(ddamg_hip_ctx* c, int level, double* D_lex, double* clover_lex) {
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c && c->setup_done, "setup has not been run");
+  DDAMG_REQUIRE(level >= 1 && level < c->par.num_levels, "coarse operator: 1 <= level < num_levels");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
-  if (c->mg32) c->mg32->level(1).cop.export_reference(c->levels[1]->geom, D_lex, clover_lex, c->stream);
-  else c->mg64->level(1).cop.export_reference(c->levels[1]->geom, D_lex, clover_lex, c->stream);
+  if (c->mg32) c->mg32->level(level).cop.export_reference(c->levels[level]->geom, D_lex, clover_lex, c->stream);
+  else c->mg64->level(level).cop.export_reference(c->levels[level]->geom, D_lex, clover_lex, c->stream);
   DDAMG_API_END
 }
+int ddamg_hip_get_coarse_operator(ddamg_hip_ctx* c, double* D_lex, double* clover_lex) { return ddamg_hip_get_coarse_operator_level(c, 1, D_lex, clover_lex); }
 
-int ddamg_hip_set_coarse_operator(ddamg_hip_ctx* c, const double* D_lex, const double* clover_lex) {
+int ddamg_hip_set_coarse_operator_level(ddamg_hip_ctx* c, int level, const double* D_lex, const double* clover_lex) {
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c && D_lex && clover_lex, "null argument");
+  DDAMG_REQUIRE(level >= 1 && level < c->par.num_levels, "coarse operator: 1 <= level < num_levels");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
   ensure_mg(c);
-  if (c->mg32) c->mg32->level(1).cop.import_reference(c->levels[1]->geom, D_lex, clover_lex, c->stream);
-  else c->mg64->level(1).cop.import_reference(c->levels[1]->geom, D_lex, clover_lex, c->stream);
-  if (c->par.num_levels == 2) { if (c->mg32) c->mg32->regather_coarsest_operator(); else c->mg64->regather_coarsest_operator(); }
+  if (c->mg32) c->mg32->level(level).cop.import_reference(c->levels[level]->geom, D_lex, clover_lex, c->stream);
+  else c->mg64->level(level).cop.import_reference(c->levels[level]->geom, D_lex, clover_lex, c->stream);
+  if (level == c->par.num_levels - 1) { if (c->mg32) c->mg32->regather_coarsest_operator(); else c->mg64->regather_coarsest_operator(); }
+  DDAMG_API_END
+}
+int ddamg_hip_set_coarse_operator(ddamg_hip_ctx* c, const double* D_lex, const double* clover_lex) { return ddamg_hip_set_coarse_operator_level(c, 1, D_lex, clover_lex); }
+
+int ddamg_hip_set_interpolation_level(ddamg_hip_ctx* c, int level, const double* P_lex) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && P_lex, "null argument");
+  DDAMG_REQUIRE(level >= 0 && level + 1 < c->par.num_levels, "interpolation vectors: 0 <= level < num_levels - 1");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  ensure_mg(c);
+  if (c->mg32) { c->mg32->import_interpolation_level(level, P_lex); c->mg32->release_setup_workspace(); }
+  else { c->mg64->import_interpolation_level(level, P_lex); c->mg64->release_setup_workspace(); }
+  c->setup_done = true;
   DDAMG_API_END
 }
 
@@ -347,14 +363,45 @@ static void check_vec(ddamg_hip_ctx* c, const ddamg_hip_vec* v, int level) {
   DDAMG_REQUIRE(v->precision == (c->mg32 ? 32 : 64), "vector precision does not match the V-cycle precision");
 }
 
+// helpers of the many-right-hand-side entry points below
+namespace {
+// columns next to each other in one device buffer, as the bootstrap holds them
+struct Columns {
+  float* p = nullptr; size_t cs = 0;
+  Columns(size_t cs_, int ncols) : cs(cs_) { DDAMG_HIP_CHECK(device_alloc(&p, sizeof(float) * cs * ncols)); }
+  ~Columns() { if (p) (void)hipFree(p); }
+  Columns(const Columns&) = delete; Columns& operator=(const Columns&) = delete;
+};
+int many_level(ddamg_hip_ctx* c, int ncols, ddamg_hip_vec* const* a, const ddamg_hip_vec* const* b) {
+  DDAMG_REQUIRE(c && c->mg32 && a && b, "the many-right-hand-side entry points need the fp32 hierarchy (mixed_precision >= 1)");
+  DDAMG_REQUIRE(ncols >= 2 && ncols <= 32, "2 <= ncols <= 32");
+  const int lvl = a[0]->level;
+  DDAMG_REQUIRE(lvl >= 1 && lvl < c->par.num_levels, "coarse-level vectors expected");
+  for (int k = 0; k < ncols; k++) {
+    check_vec(c, a[k], lvl); check_vec(c, b[k], lvl);
+    DDAMG_REQUIRE(a[k]->precision == 32 && b[k]->precision == 32, "fp32 vectors expected");
+  }
+  return lvl;
+}
+void pack(ddamg_hip_ctx* c, Columns& C, const ddamg_hip_vec* const* v, int ncols) {
+  for (int k = 0; k < ncols; k++) DDAMG_HIP_CHECK(hipMemcpyAsync(C.p + (size_t)k * C.cs, v[k]->data, v[k]->bytes, hipMemcpyDeviceToDevice, c->stream));
+}
+void unpack(ddamg_hip_ctx* c, ddamg_hip_vec* const* v, const Columns& C, int ncols) {
+  for (int k = 0; k < ncols; k++) DDAMG_HIP_CHECK(hipMemcpyAsync(v[k]->data, C.p + (size_t)k * C.cs, v[k]->bytes, hipMemcpyDeviceToDevice, c->stream));
+  DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
+}
+}  // namespace
+
 int ddamg_hip_smoother(ddamg_hip_ctx* c, ddamg_hip_vec* phi, const ddamg_hip_vec* eta, int cycles, int initial_guess_zero) {
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c, "null context");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
   ensure_mg(c);
-  check_vec(c, phi, 0); check_vec(c, eta, 0);
-  if (c->mg32) c->mg32->smoother(0, (float*)phi->data, nullptr, (const float*)eta->data, cycles, initial_guess_zero ? NO_RES : RES);
-  else c->mg64->smoother(0, (double*)phi->data, nullptr, (const double*)eta->data, cycles, initial_guess_zero ? NO_RES : RES);
+  DDAMG_REQUIRE(phi && phi->level >= 0 && phi->level + 1 < c->par.num_levels, "smoother: the coarsest level has none");
+  const int lvl = phi->level;
+  check_vec(c, phi, lvl); check_vec(c, eta, lvl);
+  if (c->mg32) c->mg32->smoother(lvl, (float*)phi->data, nullptr, (const float*)eta->data, cycles, initial_guess_zero ? NO_RES : RES);
+  else c->mg64->smoother(lvl, (double*)phi->data, nullptr, (const double*)eta->data, cycles, initial_guess_zero ? NO_RES : RES);
   DDAMG_API_END
 }
 
@@ -420,16 +467,14 @@ int ddamg_hip_coarse_solve_many(ddamg_hip_ctx* c, int ncols, ddamg_hip_vec* cons
   for (int k = 0; k < ncols; k++) { check_vec(c, x[k], lc); check_vec(c, b[k], lc); DDAMG_REQUIRE(x[k]->precision == 32 && b[k]->precision == 32, "fp32 vectors expected"); }
   // columns next to each other in one buffer, as the bootstrap holds them
   const size_t cs = b[0]->bytes / sizeof(float);
-  float *B = nullptr, *X = nullptr;
-  DDAMG_HIP_CHECK(device_alloc(&B, sizeof(float) * cs * ncols));
-  DDAMG_HIP_CHECK(device_alloc(&X, sizeof(float) * cs * ncols));
-  for (int k = 0; k < ncols; k++) DDAMG_HIP_CHECK(hipMemcpyAsync(B + (size_t)k * cs, b[k]->data, b[k]->bytes, hipMemcpyDeviceToDevice, c->stream));
-  const bool ok = c->mg32->coarse_solve_many(X, cs, B, cs, ncols, iterations);
+  Columns B(cs, ncols), X(cs, ncols);     // freed on every path out of here
+  pack(c, B, b, ncols);
+  const bool ok = c->mg32->coarse_solve_many(X.p, cs, B.p, cs, ncols, iterations);
   if (ok)
     for (int k = 0; k < ncols; k++)
-      if (iterations[k] >= 0) DDAMG_HIP_CHECK(hipMemcpyAsync(x[k]->data, X + (size_t)k * cs, x[k]->bytes, hipMemcpyDeviceToDevice, c->stream));
+      if (iterations[k] >= 0) DDAMG_HIP_CHECK(hipMemcpyAsync(x[k]->data, X.p + (size_t)k * cs, x[k]->bytes, hipMemcpyDeviceToDevice, c->stream));
   DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
-  DDAMG_HIP_CHECK(hipFree(B)); DDAMG_HIP_CHECK(hipFree(X));
+  c->mg32->release_many_workspace();      // the lockstep batches are setup workspace: not kept next to the production solves
   DDAMG_REQUIRE(ok, "coarse_solve_many: shape not covered (fp32, single process, odd-even, at most 64 dof per site)");
   DDAMG_API_END
 }
@@ -438,9 +483,88 @@ int ddamg_hip_vcycle(ddamg_hip_ctx* c, ddamg_hip_vec* phi, const ddamg_hip_vec* 
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c && c->setup_done, "setup has not been run");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
-  check_vec(c, phi, 0); check_vec(c, eta, 0);
-  if (c->mg32) c->mg32->vcycle(0, (float*)phi->data, nullptr, (const float*)eta->data, NO_RES);
-  else c->mg64->vcycle(0, (double*)phi->data, nullptr, (const double*)eta->data, NO_RES);
+  DDAMG_REQUIRE(phi && phi->level >= 0 && phi->level + 1 < c->par.num_levels, "vcycle: the coarsest level has none");
+  const int lvl = phi->level;
+  check_vec(c, phi, lvl); check_vec(c, eta, lvl);
+  if (c->mg32) c->mg32->vcycle(lvl, (float*)phi->data, nullptr, (const float*)eta->data, NO_RES);
+  else c->mg64->vcycle(lvl, (double*)phi->data, nullptr, (const double*)eta->data, NO_RES);
+  DDAMG_API_END
+}
+
+int ddamg_hip_kcycle(ddamg_hip_ctx* c, ddamg_hip_vec* x, const ddamg_hip_vec* b, int* iterations) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && c->setup_done && x && b, "setup has not been run");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  const int lvl = x->level;
+  DDAMG_REQUIRE(lvl >= 1 && lvl + 1 < c->par.num_levels, "kcycle: an intermediate level");
+  check_vec(c, x, lvl); check_vec(c, b, lvl);
+  int it;
+  if (c->mg32) {
+    DDAMG_HIP_CHECK(hipMemcpyAsync(c->mg32->level(lvl).gm.b, b->data, b->bytes, hipMemcpyDeviceToDevice, c->stream));
+    it = c->mg32->kcycle_solve(lvl);
+    DDAMG_HIP_CHECK(hipMemcpyAsync(x->data, c->mg32->level(lvl).gm.x, x->bytes, hipMemcpyDeviceToDevice, c->stream));
+  } else {
+    DDAMG_HIP_CHECK(hipMemcpyAsync(c->mg64->level(lvl).gm.b, b->data, b->bytes, hipMemcpyDeviceToDevice, c->stream));
+    it = c->mg64->kcycle_solve(lvl);
+    DDAMG_HIP_CHECK(hipMemcpyAsync(x->data, c->mg64->level(lvl).gm.x, x->bytes, hipMemcpyDeviceToDevice, c->stream));
+  }
+  DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (iterations) *iterations = it;
+  DDAMG_API_END
+}
+
+// ---- many right-hand sides on a coarse level: the kernels of the batched setup through the boundary (tests, measurements) ----
+int ddamg_hip_coarse_apply_many(ddamg_hip_ctx* c, int ncols, ddamg_hip_vec* const* out, const ddamg_hip_vec* const* in) {
+  DDAMG_API_BEGIN
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  const int lvl = many_level(c, ncols, out, in);
+  Columns I(in[0]->bytes / sizeof(float), ncols), O(in[0]->bytes / sizeof(float), ncols);
+  pack(c, I, in, ncols);
+  const bool ok = lvl == c->par.num_levels - 1 ? c->mg32->coarsest_apply_many(O.p, O.cs, I.p, I.cs, ncols) : (lvl == 1 && c->mg32->level1_apply_many(O.p, O.cs, I.p, I.cs, ncols));
+  if (ok) unpack(c, out, O, ncols);
+  c->mg32->release_many_workspace();
+  DDAMG_REQUIRE(ok, "coarse_apply_many: shape not covered (fp32, single process; the coarsest level, or the intermediate level of three)");
+  DDAMG_API_END
+}
+
+int ddamg_hip_smoother_many(ddamg_hip_ctx* c, int ncols, ddamg_hip_vec* const* phi, const ddamg_hip_vec* const* eta, int cycles, int initial_guess_zero) {
+  DDAMG_API_BEGIN
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  const int lvl = many_level(c, ncols, phi, eta);
+  Columns E(eta[0]->bytes / sizeof(float), ncols), P(eta[0]->bytes / sizeof(float), ncols);
+  pack(c, E, eta, ncols); pack(c, P, phi, ncols);
+  const bool ok = lvl == 1 && c->mg32->level1_smooth_many(P.p, P.cs, E.p, E.cs, ncols, cycles, initial_guess_zero ? NO_RES : RES);
+  if (ok) unpack(c, phi, P, ncols);
+  c->mg32->release_many_workspace();
+  DDAMG_REQUIRE(ok, "smoother_many: shape not covered (the intermediate level of a three-level hierarchy, red-black Schwarz, fp32, single process)");
+  DDAMG_API_END
+}
+
+int ddamg_hip_vcycle_many(ddamg_hip_ctx* c, int ncols, ddamg_hip_vec* const* phi, const ddamg_hip_vec* const* eta) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && c->setup_done, "setup has not been run");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  const int lvl = many_level(c, ncols, phi, eta);
+  Columns E(eta[0]->bytes / sizeof(float), ncols), P(eta[0]->bytes / sizeof(float), ncols);
+  pack(c, E, eta, ncols);
+  const bool ok = lvl == 1 && c->mg32->level1_vcycle_many(P.p, P.cs, E.p, E.cs, ncols);
+  if (ok) unpack(c, phi, P, ncols);
+  c->mg32->release_many_workspace();
+  DDAMG_REQUIRE(ok, "vcycle_many: shape not covered (the intermediate level of a three-level hierarchy, red-black Schwarz, fp32, single process)");
+  DDAMG_API_END
+}
+
+int ddamg_hip_kcycle_many(ddamg_hip_ctx* c, int ncols, ddamg_hip_vec* const* x, const ddamg_hip_vec* const* b, int* iterations) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && c->setup_done && iterations, "setup has not been run");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  const int lvl = many_level(c, ncols, x, b);
+  Columns B(b[0]->bytes / sizeof(float), ncols), X(b[0]->bytes / sizeof(float), ncols);
+  pack(c, B, b, ncols);
+  const bool ok = lvl == 1 && c->mg32->level1_kcycle_many(X.p, X.cs, B.p, B.cs, ncols, iterations);
+  if (ok) unpack(c, x, X, ncols);
+  c->mg32->release_many_workspace();
+  DDAMG_REQUIRE(ok, "kcycle_many: shape not covered (the intermediate level of a three-level hierarchy with the K-cycle, red-black Schwarz, fp32, single process)");
   DDAMG_API_END
 }
 

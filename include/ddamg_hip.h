@@ -140,10 +140,20 @@ int ddamg_hip_get_test_vectors(ddamg_hip_ctx* ctx, double* tv_lex);
  * src/coarse_operator_generic.c:109-111) */
 int ddamg_hip_get_coarse_operator(ddamg_hip_ctx* ctx, double* D_lex, double* clover_lex);
 int ddamg_hip_set_coarse_operator(ddamg_hip_ctx* ctx, const double* D_lex, const double* clover_lex);
+/* the same for the operator of any coarse level 1 <= level < num_levels (l->next_level->...->op_PRECISION, built by
+ * coarse_operator_PRECISION_setup src/coarse_operator_generic.c:53-100 on every level) */
+int ddamg_hip_get_coarse_operator_level(ddamg_hip_ctx* ctx, int level, double* D_lex, double* clover_lex);
+int ddamg_hip_set_coarse_operator_level(ddamg_hip_ctx* ctx, int level, const double* D_lex, const double* clover_lex);
+/* interpolation vectors of level `level` < num_levels - 1 as they are (l->is_PRECISION.interpolation[] of that level after
+ * gram_schmidt_on_aggregates, src/setup_generic.c:268-273): P_lex = [num_vect[level]][V_level][ndof_level] complex fp64,
+ * lexicographic sites of that level.  Builds the operator of level + 1 from them (coarse_operator_PRECISION_setup) and
+ * runs the initial setup of the levels below. */
+int ddamg_hip_set_interpolation_level(ddamg_hip_ctx* ctx, int level, const double* P_lex);
 
 /* ---- hot-path pieces, vectors in the V-cycle precision (32 unless mixed_precision == 0) ------ */
 /* replaces smoother_PRECISION / red_black_schwarz_PRECISION (src/vcycle_generic.c:25-88,
- * src/schwarz_generic.c:1260-1431); initial_guess_zero != 0 is the reference's _NO_RES */
+ * src/schwarz_generic.c:1260-1431); initial_guess_zero != 0 is the reference's _NO_RES.  The vectors' level selects the
+ * smoother (any level but the coarsest). */
 int ddamg_hip_smoother(ddamg_hip_ctx* ctx, ddamg_hip_vec* phi, const ddamg_hip_vec* eta, int cycles, int initial_guess_zero);
 /* replaces restrict_PRECISION / interpolate3_PRECISION (add == 0) / interpolate_PRECISION (add != 0)
  * (src/interpolation_generic.c:93-207) */
@@ -159,8 +169,22 @@ int ddamg_hip_coarse_solve(ddamg_hip_ctx* ctx, ddamg_hip_vec* x, const ddamg_hip
  * process, odd-even.  iterations[c]: GMRES iterations of column c, -1 if it needed more steps than the lockstep basis holds
  * (x[c] is then not written). */
 int ddamg_hip_coarse_solve_many(ddamg_hip_ctx* ctx, int ncols, ddamg_hip_vec* const* x, const ddamg_hip_vec* const* b, int* iterations);
-/* replaces vcycle_PRECISION(phi, NULL, eta, _NO_RES) (src/vcycle_generic.c:91-141) */
+/* replaces vcycle_PRECISION(phi, NULL, eta, _NO_RES) (src/vcycle_generic.c:91-141) on the level of the vectors */
 int ddamg_hip_vcycle(ddamg_hip_ctx* ctx, ddamg_hip_vec* phi, const ddamg_hip_vec* eta);
+/* the K-cycle of an intermediate level: fgmres_PRECISION(&l->p_PRECISION) with the V-cycle of that level as preconditioner,
+ * initial guess zero (src/vcycle_generic.c:110-114) */
+int ddamg_hip_kcycle(ddamg_hip_ctx* ctx, ddamg_hip_vec* x, const ddamg_hip_vec* b, int* iterations);
+/* Many right-hand sides (2 <= ncols <= 32) on a coarse level, as the bootstrap setup runs its Nvec independent V-cycles
+ * (the reference: one test vector at a time, src/setup_generic.c:191-275,441-503): every coupling of a site becomes a complex
+ * (n x n) x (n x 32) product on the matrix cores (v_mfma_f32_16x16x4_f32), the coupling matrices read once for all columns;
+ * every column keeps its own MinRes coefficients, Hessenberg matrix and stopping test.  fp32 V-cycle, single process.
+ *   coarse_apply_many: apply_coarse_operator_PRECISION on the coarsest level or on the intermediate level of three levels;
+ *   smoother_many / vcycle_many / kcycle_many: red-black Schwarz smoother, V-cycle and K-cycle (iterations[c] per column) of
+ *   the intermediate level of a three-level hierarchy. */
+int ddamg_hip_coarse_apply_many(ddamg_hip_ctx* ctx, int ncols, ddamg_hip_vec* const* out, const ddamg_hip_vec* const* in);
+int ddamg_hip_smoother_many(ddamg_hip_ctx* ctx, int ncols, ddamg_hip_vec* const* phi, const ddamg_hip_vec* const* eta, int cycles, int initial_guess_zero);
+int ddamg_hip_vcycle_many(ddamg_hip_ctx* ctx, int ncols, ddamg_hip_vec* const* phi, const ddamg_hip_vec* const* eta);
+int ddamg_hip_kcycle_many(ddamg_hip_ctx* ctx, int ncols, ddamg_hip_vec* const* x, const ddamg_hip_vec* const* b, int* iterations);
 
 /* replaces wilson_driver -> fgmres_double + preconditioner (src/top_level.c:64-104,
  * src/linsolve_generic.c:219-413): host vectors lexicographic fp64.  tol <= 0: params.tol.

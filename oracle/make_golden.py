@@ -46,6 +46,11 @@ randomize test vectors: 0
 
 CASE_3LVL_EXTRA = "d1 global lattice: 4 4 4 4\nd1 post smooth iter: 2\nd1 block iter: 4\nd1 test vectors: 28\nd1 setup iter: 3"
 
+THREE_LEVEL_KEEP = ["meta_int", "meta_f64", "meta3_int", "coarse_D", "coarse_clover", "l1_interp_vectors", "l2_coarse_D", "l2_coarse_clover",
+                    "l1_apply_in", "l1_apply_out", "l2_apply_in", "l2_apply_out", "l1_restrict_in", "l1_restrict_out", "l1_interpolate_in",
+                    "l1_interpolate_out", "l1_smoother_eta", "l1_smoother_nores_out_c1", "l1_smoother_nores_out_c2", "l1_smoother_nores_out_c3",
+                    "l1_smoother_phi0", "l1_smoother_res_out_c2", "l1_vcycle_eta", "l1_vcycle_out", "ones_solve_iters", "ones_solve_norm_res"]
+
 CASES = {
     # BASELINE.md explicit 2-level 4^4 case (11 iterations, 2.44e-11)
     "4x4": dict(conf="conf/4x4x4x4b6.0000id3n1", levels=2, L="4 4 4 4", B="2 2 2 2", nvec=20, setup=4,
@@ -110,6 +115,18 @@ CASES = {
                       extra="d1 global lattice: 2 2 2 2\nd1 local lattice: 2 2 2 2", method=4, mp=1, keep=["meta_int", "meta_f64", "smoother_nores_out_c1", "smoother_nores_out_c2", "smoother_nores_out_c3", "smoother_res_out_c2", "solve_iters", "solve_norm_res", "ones_solve_iters", "ones_solve_norm_res"]),
     "8x8_3lvl_m4": dict(conf="conf/8x8x8x8b6.0000id3n1", levels=3, L="8 8 8 8", B="2 2 2 2", nvec=28, setup=4,
                         extra=CASE_3LVL_EXTRA, method=4, mp=1, keep=["meta_int", "meta_f64", "ones_solve_iters", "ones_solve_norm_res"]),
+    # three levels, every level's data small enough to commit: the reference's 8^4 configuration, 8^4 -> 4^4 -> 2^4, 8 / 10 test
+    # vectors (16 / 20 dof per coarse site).  Dumps of the level-0 AND level-1 interpolation vectors, both coarse operators, and the
+    # intermediate level's hot-path functions (operator, restriction / interpolation, Schwarz smoother, V-cycle)
+    "8x8_3lvl_small": dict(conf="conf/8x8x8x8b6.0000id3n1", levels=3, L="8 8 8 8", B="2 2 2 2", nvec=8, setup=3,
+                           extra="d1 global lattice: 4 4 4 4\nd1 local lattice: 4 4 4 4\nd1 block lattice: 2 2 2 2\nd1 post smooth iter: 2\nd1 block iter: 4\nd1 test vectors: 10\nd1 setup iter: 2\nd2 global lattice: 2 2 2 2\nd2 local lattice: 2 2 2 2",
+                           method=2, mp=1, keep=THREE_LEVEL_KEEP + ["interp_vectors"]),
+    # the production dof counts (24 -> 48 dof, 28 -> 56 dof per site) on the smallest lattices that carry them: 16 x 8^3 with 4^4
+    # aggregates -> 4 x 2^3 (blocks and aggregates of 2 x 1^3 sites) -> 2^4; seeded random links (the test regenerates them:
+    # conftest.random_su3(V*4, 1618)); the fine level's vectors are not kept -- the level-1 operator is
+    "16x8_3lvl_prod": dict(conf="", synthetic=1618, levels=3, L="16 8 8 8", B="4 4 4 4", nvec=24, setup=2, m0=0.3,
+                           extra="d1 global lattice: 4 2 2 2\nd1 local lattice: 4 2 2 2\nd1 block lattice: 2 1 1 1\nd1 post smooth iter: 2\nd1 block iter: 4\nd1 test vectors: 28\nd1 setup iter: 2\nd2 global lattice: 2 2 2 2\nd2 local lattice: 2 2 2 2",
+                           method=2, mp=1, keep=THREE_LEVEL_KEEP),
     # pure CGN (method -1): conjugate gradients on the normal equations, needs D^dagger = g5 D g5
     "4x4_cgn": dict(conf="conf/4x4x4x4b6.0000id3n1", levels=2, L="4 4 4 4", B="2 2 2 2", nvec=20, setup=0, extra="", method=-1, mp=1,
                     keep=["meta_int", "meta_f64", "cgn_x"]),

@@ -109,18 +109,40 @@ def interpolation_matrix(L, Lc, interp_vectors):
     return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(12 * V, n * int(np.prod(Lc))))
 
 
+def coarse_interpolation_matrix(L1, L2, interp_vectors, n1):
+    """the same between two coarse levels: (n1 V1) x (n2 V2), n2 = 2 Nvec; coarse dof h*Nvec + j of aggregate a couples to
+    the dofs h*n1/2 .. (h+1)*n1/2 - 1 of interpolation vector j on the sites of a (src/interpolation_generic.c:111-120 is level
+    independent: the first half of a site's dofs is chirality 0)"""
+    P_ = cplx(interp_vectors)               # [N][V1][n1]
+    N, V = P_.shape[0], P_.shape[1]
+    n2 = 2 * N
+    a = aggregate_of(L1, L2)
+    rows, cols, vals = [], [], []
+    site = np.arange(V)
+    for j in range(N):
+        for d in range(n1):
+            h = d // (n1 // 2)
+            rows.append(n1 * site + d); cols.append(n2 * a + h * N + j); vals.append(P_[j, :, d])
+    return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n1 * V, n2 * int(np.prod(L2))))
+
+
 # ---- coarse operator --------------------------------------------------------------------------------
-def coarse_matrix(Lc, coarse_D, coarse_clover, n):
-    """(n Vc) x (n Vc) sparse matrix of  eta(x) = M(x) phi(x) - sum_mu [ U_mu(x) phi(x+mu) + G5 U_mu(x-mu)^H G5 phi(x-mu) ]"""
+def coarse_matrix(Lc, coarse_D, coarse_clover, n, parts=False):
+    """(n Vc) x (n Vc) sparse matrix of  eta(x) = M(x) phi(x) - sum_mu [ U_mu(x) phi(x+mu) + G5 U_mu(x-mu)^H G5 phi(x-mu) ];
+    parts=True: the tuple (self couplings, [forward hops of mu], [backward hops of mu]) whose sum it is"""
     Vc = int(np.prod(Lc)); N = n // 2
     Dc = cplx(coarse_D).reshape(Vc, 4, 4, N, N)      # [site][mu][block A,C,B,D][col][row]  (column-major blocks)
     cl = cplx(coarse_clover).reshape(Vc, -1)
     g5 = np.concatenate([np.ones(N), -np.ones(N)])
     c = coords(Lc)
     blocks = {}
+    pblocks = [dict() for _ in range(9)]      # 0 self, 1+mu forward, 5+mu backward
+    which = [0]
 
     def add(i, j, M):
         blocks[(i, j)] = blocks.get((i, j), 0) + M
+        d = pblocks[which[0]]
+        d[(i, j)] = d.get((i, j), 0) + M
     tri = N * (N + 1) // 2
     for x in range(Vc):
         M = np.zeros((n, n), dtype=complex)
@@ -136,19 +158,61 @@ def coarse_matrix(Lc, coarse_D, coarse_clover, n):
         B = cl[x, 2 * tri:2 * tri + N * N].reshape(N, N).T        # column-major -> B[i][j]
         M[:N, N:] = B
         M[N:, :N] = -B.conj().T
+        which[0] = 0
         add(x, x, M)
         for mu in range(4):
             A_, C_, B_, D_ = (Dc[x, mu, q].T for q in range(4))   # column-major blocks -> [row][col]
             U = np.block([[A_, B_], [C_, D_]])
             cc = c[x].copy(); cc[mu] = (cc[mu] + 1) % Lc[mu]
             y = int(lex(cc, Lc))
+            which[0] = 1 + mu
             add(x, y, -U)                                          # forward:  -U_mu(x) phi(x+mu)
+            which[0] = 5 + mu
             add(y, x, -(g5[:, None] * U.conj().T * g5[None, :]))   # backward at y = x+mu:  -G5 U_mu(x)^H G5 phi(x)
-    rows, cols, vals = [], [], []
     ii, jj = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
-    for (i, j), M in blocks.items():
-        rows.append((n * i + ii).ravel()); cols.append((n * j + jj).ravel()); vals.append(M.ravel())
-    return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n * Vc, n * Vc))
+
+    def assemble(bl):
+        rows, cols, vals = [], [], []
+        for (i, j), M in bl.items():
+            rows.append((n * i + ii).ravel()); cols.append((n * j + jj).ravel()); vals.append(M.ravel())
+        return sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n * Vc, n * Vc))
+    if parts:
+        return assemble(pblocks[0]), [assemble(pblocks[1 + mu]) for mu in range(4)], [assemble(pblocks[5 + mu]) for mu in range(4)]
+    return assemble(blocks)
+
+
+def galerkin_coarse_operator(L1, L2, parts1, P1, n2):
+    """The next level's operator in the reference's storage, (D [V2][4][n2*n2], clover [V2][n2(n2+1)/2]) complex, from the
+    parts of this level's operator and the interpolation matrix (coarse_operator_PRECISION_setup, set_coarse_self_coupling /
+    set_coarse_neighbor_coupling, src/coarse_operator_generic.c:53-205): the self coupling of aggregate X collects P_X^H (self
+    couplings + every hop that stays inside X) P_X, the forward link U_mu(X) = -P_X^H (forward hops in mu that leave X) P_{X+mu}."""
+    selfp, fwd, bwd = parts1
+    V2 = int(np.prod(L2)); N = n2 // 2; tri = N * (N + 1) // 2
+    c2 = coords(L2)
+    Ph = P1.conj().T.tocsr()
+    G_self = (Ph @ selfp @ P1).tocsr()
+    G_f = [(Ph @ fwd[mu] @ P1).tocsr() for mu in range(4)]
+    G_b = [(Ph @ bwd[mu] @ P1).tocsr() for mu in range(4)]
+    D = np.zeros((V2, 4, 4, N, N), dtype=complex)
+    cl = np.zeros((V2, 2 * tri + N * N), dtype=complex)
+    blk = lambda G, X, Y: G[n2 * X:n2 * (X + 1), n2 * Y:n2 * (Y + 1)].toarray()
+    for X in range(V2):
+        M = blk(G_self, X, X)
+        for mu in range(4):
+            M = M + blk(G_f[mu], X, X) + blk(G_b[mu], X, X)
+        for b in range(2):
+            k = 0
+            for j in range(N):
+                for i in range(j + 1):
+                    cl[X, b * tri + k] = M[b * N + i, b * N + j]; k += 1
+        cl[X, 2 * tri:] = M[:N, N:].T.ravel()
+        for mu in range(4):
+            cc = c2[X].copy(); cc[mu] = (cc[mu] + 1) % L2[mu]
+            Y = int(lex(cc, L2))
+            U = -blk(G_f[mu], X, Y)
+            for q, bq in enumerate((U[:N, :N], U[N:, :N], U[:N, N:], U[N:, N:])):   # blocks A, C, B, D, column-major
+                D[X, mu, q] = bq.T
+    return D.reshape(V2, 4, n2 * n2), cl
 
 
 # ---- Krylov -----------------------------------------------------------------------------------------
@@ -232,11 +296,12 @@ def coarse_solve(Mc, Lc, n, b, tol, restart, max_restart):
 class Schwarz:
     SIGMA = [0, 1, 3, 2, 6, 4, 5, 7, 15, 14, 12, 13, 9, 11, 10, 8]   # src/schwarz_generic.c:335
 
-    def __init__(self, L, B, A, block_iter, method=2):
-        """A: fine matrix; blocks of extent B; the 8 block lists of the reference (colour x {inner, -boundary only,
+    def __init__(self, L, B, A, block_iter, method=2, ndof=12, odd_even=True):
+        """A: matrix of the level's operator (ndof per site; odd_even=False: MinRes on the whole block, the smoother of an
+        intermediate level, coarse_block_operator src/coarse_operator_generic.c:208-235); blocks of extent B; the 8 block lists of the reference (colour x {inner, -boundary only,
         both boundaries, +boundary only}, src/schwarz_generic.c:383-428).  method: 1 additive, 2 red-black, 3 sixteen
         colours (src/schwarz_generic.c:318-333; an odd number of blocks in a direction falls back to two colours)"""
-        self.A = A.tocsr(); self.block_iter = block_iter; self.method = method
+        self.A = A.tocsr(); self.block_iter = block_iter; self.method = method; self.odd_even = odd_even
         self.sixteen = method == 3 and all((L[mu] // B[mu]) % 2 == 0 for mu in range(4))
         c = coords(L)
         nblk = [L[mu] // B[mu] for mu in range(4)]
@@ -258,7 +323,7 @@ class Schwarz:
             else:
                 lst = 2 + 4 * col
             ev = sites[sitepar[sites] == 0]; od = sites[sitepar[sites] == 1]
-            dofs = lambda s: (12 * s[:, None] + np.arange(12)[None, :]).ravel()
+            dofs = lambda s: (ndof * s[:, None] + np.arange(ndof)[None, :]).ravel()
             I = dofs(sites); Ie = dofs(ev); Io = dofs(od)
             Abb_e_e = self.A[Ie][:, Ie]; Aeo = self.A[Ie][:, Io]; Aoe = self.A[Io][:, Ie]; Aoo = self.A[Io][:, Io]
             corner = 8 * (gb[0] % 2) + 4 * (gb[1] % 2) + 2 * (gb[2] % 2) + (gb[3] % 2)
@@ -267,7 +332,8 @@ class Schwarz:
             elif self.sixteen:
                 col = self.SIGMA.index(int(corner))
             self.blocks.append(dict(colour=col, list=lst, I=I, Ie=Ie, Io=Io, Dee=Abb_e_e, Deo=Aeo, Doe=Aoe,
-                                    Doo_inv=spla.splu(Aoo.tocsc()), rows=self.A[I]))
+                                    Doo_inv=spla.splu(Aoo.tocsc()) if odd_even else None, rows=self.A[I],
+                                    Dbb=None if odd_even else self.A[I][:, I]))
 
     def _outside(self, blk, v):
         """(couplings from other blocks into this block) * v"""
@@ -276,6 +342,18 @@ class Schwarz:
         return full - inside
 
     def _block_solve(self, blk, x, r, latest):
+        if not self.odd_even:
+            # local_minres_PRECISION (src/linsolve_generic.c:985-1029) on the block operator itself
+            I, Dbb = blk["I"], blk["Dbb"]
+            rb = r[I].copy(); d = np.zeros_like(rb)
+            for _ in range(self.block_iter):
+                Dr = Dbb @ rb
+                dn = np.vdot(Dr, Dr).real
+                alpha = np.vdot(Dr, rb) / dn if dn > 0 else 0.0
+                d = d + alpha * rb
+                rb = rb - alpha * Dr
+            x[I] += d; latest[I] = d; r[I] = rb
+            return
         Ie, Io = blk["Ie"], blk["Io"]
         Dee, Deo, Doe, Dinv = blk["Dee"], blk["Deo"], blk["Doe"], blk["Doo_inv"]
         ro = r[Io].copy()

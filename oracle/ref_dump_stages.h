@@ -61,6 +61,18 @@ static int *level_order(level_struct *lv)
   int n = lv->num_inner_lattice_sites, *ord = malloc(sizeof(int) * n);
   if (lv->depth == 0) {
     for (int i = 0; i < n; i++) ord[i] = lv->s_float.op.translation_table[i];
+  } else if (lv->level > 0) {
+    /* intermediate level: aggregate -> Schwarz block -> lexicographic inside the block (src/gathering_generic.c:126-157) */
+    int *le = lv->local_lattice, as[4], bs[4], i = 0, a[4], b[4], c[4];
+    for (int mu = 0; mu < 4; mu++) { as[mu] = le[mu] / lv->coarsening[mu]; bs[mu] = lv->coarsening[mu] / lv->block_lattice[mu]; }
+    for (a[0] = 0; a[0] < as[0]; a[0]++) for (a[1] = 0; a[1] < as[1]; a[1]++) for (a[2] = 0; a[2] < as[2]; a[2]++) for (a[3] = 0; a[3] < as[3]; a[3]++)
+      for (b[0] = 0; b[0] < bs[0]; b[0]++) for (b[1] = 0; b[1] < bs[1]; b[1]++) for (b[2] = 0; b[2] < bs[2]; b[2]++) for (b[3] = 0; b[3] < bs[3]; b[3]++)
+        for (c[0] = 0; c[0] < lv->block_lattice[0]; c[0]++) for (c[1] = 0; c[1] < lv->block_lattice[1]; c[1]++)
+          for (c[2] = 0; c[2] < lv->block_lattice[2]; c[2]++) for (c[3] = 0; c[3] < lv->block_lattice[3]; c[3]++) {
+            int x[4];
+            for (int mu = 0; mu < 4; mu++) x[mu] = (a[mu] * bs[mu] + b[mu]) * lv->block_lattice[mu] + c[mu];
+            ord[((x[T] * le[Z] + x[Z]) * le[Y] + x[Y]) * le[X] + x[X]] = i++;
+          }
   } else {
     int *le = lv->local_lattice, i = 0;
     for (int par = 0; par < 2; par++)
@@ -216,6 +228,113 @@ static void dump_two_level(level_struct *l, struct Thread *threading)
   free(buf); free(buf2); free(ord0); free(ordc);
 }
 
+/* ---- stage 2b: three-level hierarchy: the second coarse level and the intermediate level's hot-path functions -------- */
+static void dump_coarse_op(const char *prefix, level_struct *lv)
+{
+  /* lv->op_float: the coarse operator in lexicographic site order (src/coarse_operator_generic.c:53-205) */
+  char sh[100], nm[100];
+  const int nc = lv->num_inner_lattice_sites, m = lv->num_lattice_site_var;
+  size_t nD = (size_t)4 * m * m * nc, nC = (size_t)(m * (m + 1) / 2) * nc;
+  double *t = malloc(sizeof(double) * 2 * nD);
+  for (size_t i = 0; i < nD; i++) { t[2 * i] = crealf(lv->op_float.D[i]); t[2 * i + 1] = cimagf(lv->op_float.D[i]); }
+  sprintf(sh, "%d,4,%d,2", nc, m * m); sprintf(nm, "%scoarse_D", prefix); dump(nm, "f8", t, sizeof(double) * 2 * nD, sh);
+  for (size_t i = 0; i < nC; i++) { t[2 * i] = crealf(lv->op_float.clover[i]); t[2 * i + 1] = cimagf(lv->op_float.clover[i]); }
+  sprintf(sh, "%d,%d,2", nc, m * (m + 1) / 2); sprintf(nm, "%scoarse_clover", prefix); dump(nm, "f8", t, sizeof(double) * 2 * nC, sh);
+  free(t);
+}
+static void dump_coarse_apply(const char *prefix, level_struct *lv, uint64_t seed, struct Thread *threading)
+{
+  /* apply_coarse_operator_float (src/coarse_operator_generic.c:383-394) with the lexicographic operator of the level */
+  char sh[100], nm[100];
+  const int nc = lv->num_inner_lattice_sites, m = lv->num_lattice_site_var;
+  vector_float c1 = NULL, c2 = NULL;
+  MALLOC(c1, complex_float, lv->vector_size); MALLOC(c2, complex_float, lv->vector_size);
+  double *buf = malloc(sizeof(double) * 2 * (size_t)nc * m);
+  for (size_t i = 0; i < (size_t)nc * m; i++) { double re = urand(seed, 2 * i), im = urand(seed, 2 * i + 1); c1[i] = (float)re + I * (float)im; buf[2 * i] = (float)re; buf[2 * i + 1] = (float)im; }
+  sprintf(sh, "%d,%d,2", nc, m); sprintf(nm, "%sapply_in", prefix); dump(nm, "f8", buf, sizeof(double) * 2 * nc * m, sh);
+  apply_coarse_operator_float(c2, c1, &(lv->op_float), lv, threading);
+  for (size_t i = 0; i < (size_t)nc * m; i++) { buf[2 * i] = crealf(c2[i]); buf[2 * i + 1] = cimagf(c2[i]); }
+  sprintf(nm, "%sapply_out", prefix); dump(nm, "f8", buf, sizeof(double) * 2 * nc * m, sh);
+  FREE(c1, complex_float, lv->vector_size); FREE(c2, complex_float, lv->vector_size);
+  free(buf);
+}
+static void dump_three_level(level_struct *l, struct Thread *threading)
+{
+  if (!(g.method >= 1 && g.method <= 3 && g.mixed_precision == 1 && g.num_levels == 3 && l->next_level && l->next_level->next_level)) return;
+  char sh[100];
+  level_struct *l1 = l->next_level, *l2 = l1->next_level;
+  const int n0 = l->num_inner_lattice_sites, n1 = l1->num_inner_lattice_sites, n2 = l2->num_inner_lattice_sites;
+  const int nvec0 = l->num_eig_vect, nvec1 = l1->num_eig_vect, m1 = l1->num_lattice_site_var, m2 = l2->num_lattice_site_var;
+  int *ord0 = level_order(l), *ord1 = level_order(l1), *ord2 = level_order(l2);
+  int meta[16] = {0};
+  for (int mu = 0; mu < 4; mu++) { meta[mu] = l1->local_lattice[mu]; meta[4 + mu] = l1->block_lattice[mu]; meta[8 + mu] = l2->local_lattice[mu]; }
+  meta[12] = nvec0; meta[13] = nvec1; meta[14] = l1->post_smooth_iter; meta[15] = l1->block_iter;
+  dump("meta3_int", "i4", meta, sizeof meta, "16");
+  /* level-0 interpolation vectors (only kept by fixtures that replay the whole hierarchy) */
+  {
+    double *P = malloc(sizeof(double) * 2 * (size_t)nvec0 * n0 * 12);
+    for (int j = 0; j < nvec0; j++) to_lex_f(P + 2 * (size_t)j * n0 * 12, l->is_float.interpolation[j], ord0, n0, 12);
+    sprintf(sh, "%d,%d,12,2", nvec0, n0); dump("interp_vectors", "f8", P, sizeof(double) * 2 * (size_t)nvec0 * n0 * 12, sh);
+    free(P);
+  }
+  dump_coarse_op("", l1);          /* coarse_D, coarse_clover: level 1 */
+  {
+    double *P = malloc(sizeof(double) * 2 * (size_t)nvec1 * n1 * m1), *Tv = malloc(sizeof(double) * 2 * (size_t)nvec1 * n1 * m1);
+    for (int j = 0; j < nvec1; j++) {
+      to_lex_f(P + 2 * (size_t)j * n1 * m1, l1->is_float.interpolation[j], ord1, n1, m1);
+      to_lex_f(Tv + 2 * (size_t)j * n1 * m1, l1->is_float.test_vector[j], ord1, n1, m1);
+    }
+    sprintf(sh, "%d,%d,%d,2", nvec1, n1, m1);
+    dump("l1_interp_vectors", "f8", P, sizeof(double) * 2 * (size_t)nvec1 * n1 * m1, sh);
+    dump("l1_test_vectors", "f8", Tv, sizeof(double) * 2 * (size_t)nvec1 * n1 * m1, sh);
+    free(P); free(Tv);
+  }
+  dump_coarse_op("l2_", l2);
+  dump_coarse_apply("l1_", l1, 3001, threading);
+  dump_coarse_apply("l2_", l2, 3002, threading);
+
+  size_t big = (size_t)n1 * m1 > (size_t)n2 * m2 ? (size_t)n1 * m1 : (size_t)n2 * m2;
+  double *buf = malloc(sizeof(double) * 2 * big), *buf2 = malloc(sizeof(double) * 2 * big);
+  vector_float f1 = NULL, f2 = NULL, c1 = NULL;
+  MALLOC(f1, complex_float, l1->schwarz_vector_size); MALLOC(f2, complex_float, l1->schwarz_vector_size);
+  MALLOC(c1, complex_float, l2->vector_size);
+  /* restrict / interpolate between levels 1 and 2 (src/interpolation_generic.c:93-207) */
+  from_lex_f(f1, 3003, ord1, n1, m1, buf);
+  sprintf(sh, "%d,%d,2", n1, m1); dump("l1_restrict_in", "f8", buf, sizeof(double) * 2 * n1 * m1, sh);
+  restrict_float(c1, f1, l1, threading);
+  to_lex_f(buf, c1, ord2, n2, m2);
+  sprintf(sh, "%d,%d,2", n2, m2); dump("l1_restrict_out", "f8", buf, sizeof(double) * 2 * n2 * m2, sh);
+  from_lex_f(c1, 3004, ord2, n2, m2, buf);
+  dump("l1_interpolate_in", "f8", buf, sizeof(double) * 2 * n2 * m2, sh);
+  interpolate3_float(f1, c1, l1, threading);
+  to_lex_f(buf, f1, ord1, n1, m1);
+  sprintf(sh, "%d,%d,2", n1, m1); dump("l1_interpolate_out", "f8", buf, sizeof(double) * 2 * n1 * m1, sh);
+  /* the Schwarz smoother of the intermediate level (src/schwarz_generic.c:1260-1431 on coarse_block_operator,
+     src/coarse_operator_generic.c:208-235): from zero and with an initial guess */
+  from_lex_f(f1, 3005, ord1, n1, m1, buf);
+  dump("l1_smoother_eta", "f8", buf, sizeof(double) * 2 * n1 * m1, sh);
+  for (int cyc = 1; cyc <= 3; cyc++) {
+    char nm[64];
+    smoother_float(f2, NULL, f1, cyc, _NO_RES, _NO_SHIFT, l1, threading);
+    to_lex_f(buf, f2, ord1, n1, m1);
+    sprintf(nm, "l1_smoother_nores_out_c%d", cyc); dump(nm, "f8", buf, sizeof(double) * 2 * n1 * m1, sh);
+  }
+  from_lex_f(f2, 3006, ord1, n1, m1, buf2);
+  dump("l1_smoother_phi0", "f8", buf2, sizeof(double) * 2 * n1 * m1, sh);
+  smoother_float(f2, NULL, f1, 2, _RES, _NO_SHIFT, l1, threading);
+  to_lex_f(buf, f2, ord1, n1, m1);
+  dump("l1_smoother_res_out_c2", "f8", buf, sizeof(double) * 2 * n1 * m1, sh);
+  /* the V-cycle of the intermediate level: restriction, coarsest solve, interpolation, smoother */
+  from_lex_f(f1, 3007, ord1, n1, m1, buf);
+  dump("l1_vcycle_eta", "f8", buf, sizeof(double) * 2 * n1 * m1, sh);
+  vcycle_float(f2, NULL, f1, _NO_RES, l1, threading);
+  to_lex_f(buf, f2, ord1, n1, m1);
+  dump("l1_vcycle_out", "f8", buf, sizeof(double) * 2 * n1 * m1, sh);
+  FREE(f1, complex_float, l1->schwarz_vector_size); FREE(f2, complex_float, l1->schwarz_vector_size);
+  FREE(c1, complex_float, l2->vector_size);
+  free(buf); free(buf2); free(ord0); free(ord1); free(ord2);
+}
+
 /* ---- stage 3: full solve with rhs = ones on any hierarchy (src/top_level.c:31-104) --------- */
 static void dump_solve_ones(level_struct *l, struct Thread *threading)
 {
@@ -247,5 +366,6 @@ static void dump_all(level_struct *l, struct Thread *threading)
 {
   dump_fine_operator(l, threading);
   dump_two_level(l, threading);
+  dump_three_level(l, threading);
   dump_solve_ones(l, threading);
 }

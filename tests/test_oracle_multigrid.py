@@ -101,3 +101,64 @@ def test_schwarz_schedules_with_initial_guess(schedule):
     g, gm, sap = schedule
     out = sap.smooth(vec(g["smoother_eta"]), 2, phi0=vec(g["smoother_phi0"]))
     assert relerr(mo.reim(out), np.asarray(gm["smoother_res_out_c2"]).reshape(-1, 2)) < 5e-5
+
+
+# ---- three levels: the intermediate level's hot-path functions and the SECOND coarse operator -------------------------------------------------
+# dumps of the reference on 8^4 -> 4^4 -> 2^4 with 16 / 20 dof per coarse site (its own configuration) and on 16 x 8^3 -> 4 x 2^3 -> 2^4
+# with the production 48 / 56 dof (oracle/ref_dump_stages.h dump_three_level)
+@pytest.fixture(scope="module", params=["ref_8x8_3lvl_small.npz", "ref_16x8_3lvl_prod.npz"], ids=["8x8-16-20dof", "16x8-48-56dof"])
+def hier3(request):
+    g = load_golden(request.param)
+    m3 = [int(x) for x in g["meta3_int"]]
+    L1, B1, L2, n1, n2 = m3[0:4], m3[4:8], m3[8:12], 2 * m3[12], 2 * m3[13]
+    A1 = mo.coarse_matrix(L1, g["coarse_D"], g["coarse_clover"], n1)
+    A2 = mo.coarse_matrix(L2, g["l2_coarse_D"], g["l2_coarse_clover"], n2)
+    P1 = mo.coarse_interpolation_matrix(L1, L2, g["l1_interp_vectors"], n1)
+    sap = mo.Schwarz(L1, B1, A1, m3[15], 2, ndof=n1, odd_even=False)
+    return dict(g=g, L1=L1, L2=L2, n1=n1, n2=n2, A1=A1, A2=A2, P1=P1, sap=sap, post=m3[14])
+
+
+def test_coarse_operators_of_three_levels(hier3):
+    h = hier3; g = h["g"]
+    assert relerr(mo.reim(h["A1"] @ vec(g["l1_apply_in"])), np.asarray(g["l1_apply_out"]).reshape(-1, 2)) < 2e-6
+    assert relerr(mo.reim(h["A2"] @ vec(g["l2_apply_in"])), np.asarray(g["l2_apply_out"]).reshape(-1, 2)) < 2e-6
+
+
+def test_transfer_between_coarse_levels(hier3):
+    h = hier3; g = h["g"]
+    assert relerr(mo.reim(h["P1"].conj().T @ vec(g["l1_restrict_in"])), np.asarray(g["l1_restrict_out"]).reshape(-1, 2)) < 2e-6
+    assert relerr(mo.reim(h["P1"] @ vec(g["l1_interpolate_in"])), np.asarray(g["l1_interpolate_out"]).reshape(-1, 2)) < 2e-6
+    PhP = (h["P1"].conj().T @ h["P1"]).toarray()
+    assert np.abs(PhP - np.eye(PhP.shape[0])).max() < 5e-6
+
+
+def test_second_coarse_operator_element_by_element(hier3):
+    """set_coarse_self_coupling / set_coarse_neighbor_coupling (src/coarse_operator_generic.c:103-205) on a coarse level: every
+    entry of the level-2 self couplings and forward links from the level-1 operator and interpolation vectors"""
+    h = hier3; g = h["g"]
+    parts = mo.coarse_matrix(h["L1"], g["coarse_D"], g["coarse_clover"], h["n1"], parts=True)
+    D2, cl2 = mo.galerkin_coarse_operator(h["L1"], h["L2"], parts, h["P1"], h["n2"])
+    rd, rc = mo.cplx(g["l2_coarse_D"]), mo.cplx(g["l2_coarse_clover"])
+    assert np.abs(D2 - rd).max() / np.abs(rd).max() < 5e-6
+    assert np.abs(cl2 - rc).max() / np.abs(rc).max() < 5e-6
+
+
+@pytest.mark.parametrize("cycles", [1, 2, 3])
+def test_schwarz_on_the_intermediate_level_from_zero(hier3, cycles):
+    h = hier3; g = h["g"]
+    out = h["sap"].smooth(vec(g["l1_smoother_eta"]), cycles)
+    assert relerr(mo.reim(out), np.asarray(g[f"l1_smoother_nores_out_c{cycles}"]).reshape(-1, 2)) < 1e-4
+
+
+def test_schwarz_on_the_intermediate_level_with_initial_guess(hier3):
+    h = hier3; g = h["g"]
+    out = h["sap"].smooth(vec(g["l1_smoother_eta"]), 2, phi0=vec(g["l1_smoother_phi0"]))
+    assert relerr(mo.reim(out), np.asarray(g["l1_smoother_res_out_c2"]).reshape(-1, 2)) < 1e-4
+
+
+def test_vcycle_of_the_intermediate_level(hier3):
+    h = hier3; g = h["g"]
+    eta = vec(g["l1_vcycle_eta"])
+    xc, _ = mo.coarse_solve(h["A2"], h["L2"], h["n2"], h["P1"].conj().T @ eta, 5e-2, 100, 5)
+    out = h["sap"].smooth(eta, h["post"], phi0=h["P1"] @ xc)
+    assert relerr(mo.reim(out), np.asarray(g["l1_vcycle_out"]).reshape(-1, 2)) < 2e-4
