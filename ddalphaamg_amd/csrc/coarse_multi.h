@@ -89,6 +89,11 @@ class CoarseMulti {
   double *d_h_ = nullptr, *d_coef_ = nullptr, *h_h_ = nullptr, *h_coef_ = nullptr;
   int ld_h_ = 0;
   void block_solve(int list, int mode, const float2* eta);
+  // the couplings in the A-operand order of the matrix instruction (mfma_tile.h), refreshed when the operator has changed
+  mutable float4* Mop_ = nullptr;
+  mutable unsigned Mop_version_ = 0;
+  mutable bool Mop_valid_ = false;
+  const float4* operands() const;
 };
 
 }  // namespace ddamg

@@ -51,22 +51,60 @@ __device__ __forceinline__ void store_lds(float2* __restrict__ rsite, int n, con
     }
 }
 
-// out(x) = M0(x) in(x) - sum_mu [ U_mu(x) in(x+mu) + G5 U_mu(x-mu)^H G5 in(x-mu) ]  for all columns; one workgroup of two
-// wavefronts (16 columns each) per site
+// a site's 16 columns out of the workgroup's LDS copy, accumulator layout
 template <int NRT>
-__global__ __launch_bounds__(128) void cm_apply_kernel(float2* __restrict__ out, const float2* __restrict__ in, CoarseOpDev<float> op) {
+__device__ __forceinline__ void load_lds(const float2* __restrict__ rsite, int n, f32x4 (&vR)[NRT], f32x4 (&vI)[NRT]) {
+  const int l = threadIdx.x & 63, r16 = l & 15, kq = l >> 4;
+#pragma unroll
+  for (int rt = 0; rt < NRT; rt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int i = rt * 16 + 4 * kq + r, ic = i < n ? i : n - 1;
+      const float2 v = rsite[ic * 16 + r16];
+      vR[rt][r] = i < n ? v.x : 0.f; vI[rt][r] = i < n ? v.y : 0.f;
+    }
+}
+
+// ---- the couplings in the A-operand order of the matrix instruction (mfma_tile.h) ---------------------------------------------
+// Mop[x][p]: p = 0 the self coupling, 1 + mu the forward link U_mu(x), 5 + mu its backward form G5 U_mu(x)^H G5 (what the site
+// x + mu multiplies its neighbour x with, src/coarse_operator_generic.h:152-171)
+__global__ __launch_bounds__(256) void cm_relayout_kernel(float4* __restrict__ Mop, CoarseOpDev<float> op, int nrt) {
+  const int x = blockIdx.x, p = blockIdx.y, n = op.n, nt = op.nt, npass = n >> 3, half = n >> 1;
+  const float2* M = reinterpret_cast<const float2*>(op.M) + ((size_t)x * 5 + (p == 0 ? 0 : 1 + (p - 1) % 4)) * op.msize;
+  float4* out = Mop + ((size_t)x * 9 + p) * mfma_op_matrix_elems(n);
+  const bool dag = p > 4;
+  for (int e = threadIdx.x; e < nrt * npass * 64; e += 256) {
+    const int lane = e & 63, P = (e >> 6) % npass, rt = (e >> 6) / npass;
+    const int i = rt * 16 + (lane & 15), k0 = 8 * P + (lane >> 4), k1 = k0 + 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n) {
+      if (!dag) {
+        const float2 m0 = M[mfma_tile_at(nt, i, k0)], m1 = M[mfma_tile_at(nt, i, k1)];
+        v = make_float4(m0.x, m0.y, m1.x, m1.y);
+      } else {
+        const float2 m0 = M[mfma_tile_at(nt, k0, i)], m1 = M[mfma_tile_at(nt, k1, i)];
+        const float s0 = ((i >= half) != (k0 >= half)) ? -1.f : 1.f, s1 = ((i >= half) != (k1 >= half)) ? -1.f : 1.f;
+        v = make_float4(s0 * m0.x, -s0 * m0.y, s1 * m1.x, -s1 * m1.y);
+      }
+    }
+    out[e] = v;
+  }
+}
+
+template <int NRT>
+__global__ __launch_bounds__(128) void cm_apply_op_kernel(float2* __restrict__ out, const float2* __restrict__ in, const float4* __restrict__ Mop, CoarseOpDev<float> op) {
   int bid = blockIdx.x;
   { const int chunk = gridDim.x >> 3; if (bid < chunk * 8) bid = (bid & 7) * chunk + (bid >> 3); }   // neighbouring sites on one XCD
-  const int x = bid, n = op.n, nt = op.nt;
+  const int x = bid, n = op.n;
   const int col0 = (threadIdx.x >> 6) * 16;
-  const float2* Mall = reinterpret_cast<const float2*>(op.M);
+  const size_t me = mfma_op_matrix_elems(n);
   f32x4 aR[NRT], aI[NRT];
   mfma_zero<NRT>(aR, aI);
-  mfma_cproduct<NRT, false>(Mall + (size_t)x * 5 * op.msize, nt, n, in + (size_t)x * n * NC + col0, NC, 1.f, aR, aI);
-  for (int mu = 0; mu < 4; mu++) {
-    const int yf = op.nb[(size_t)mu * op.V + x], yb = op.nb[(size_t)(4 + mu) * op.V + x];
-    mfma_cproduct<NRT, false>(Mall + ((size_t)x * 5 + 1 + mu) * op.msize, nt, n, in + (size_t)yf * n * NC + col0, NC, -1.f, aR, aI);
-    mfma_cproduct<NRT, true>(Mall + ((size_t)yb * 5 + 1 + mu) * op.msize, nt, n, in + (size_t)yb * n * NC + col0, NC, -1.f, aR, aI);
+#pragma nounroll
+  for (int p = 0; p < 9; p++) {
+    const size_t y = p == 0 ? (size_t)x : (size_t)op.nb[(size_t)(p - 1) * op.V + x];
+    const float4* A = Mop + ((p <= 4 ? (size_t)x : y) * 9 + p) * me;
+    mfma_cproduct_op<NRT>(A, n, in + y * n * NC + col0, NC, p == 0 ? 1.f : -1.f, aR, aI);
   }
   store_c<NRT>(out + (size_t)x * n * NC + col0, n, aR, aI);
 }
@@ -77,85 +115,93 @@ __global__ __launch_bounds__(128) void cm_apply_kernel(float2* __restrict__ out,
 // `iters` MinRes steps on the block operator (coarse_block_operator, local_minres): the residual of the block lives in LDS as the
 // B operand of the neighbours' products and in registers (accumulator layout) for the updates; Dr accumulates on the matrix
 // cores; <Dr,r> and <Dr,Dr> per column from a shuffle + LDS reduction in fp64.  Epilogue: r, latest = update, x += update.
+// ONE instance of the product loop (a list of products walked at run time, the in-block neighbour table in LDS), and the
+// residual in LDS only while the products run: with nine inlined product loops and three accumulator-layout vectors side by side
+// 64 of the 128 registers were spilled at n = 48 (8.0 ms per colour launch at 16^4 x 48 against 5.0 ms now, DESIGN).
 template <int NRT>
-__global__ __launch_bounds__(1024) void cm_block_minres_kernel(float2* __restrict__ x, float2* __restrict__ r, float2* __restrict__ latest,
-                                                               const float2* __restrict__ eta, CoarseOpDev<float> op, const int* __restrict__ blocks,
-                                                               const short* __restrict__ blk_nb, int BS, int iters, float eps, int mode) {
+__global__ __launch_bounds__(1024) void cm_block_minres_op_kernel(float2* __restrict__ x, float2* __restrict__ r, float2* __restrict__ latest,
+                                                                  const float2* __restrict__ eta, const float4* __restrict__ Mop, CoarseOpDev<float> op,
+                                                                  const int* __restrict__ blocks, const short* __restrict__ blk_nb, int BS, int iters, float eps, int mode) {
   extern __shared__ double cm_smem[];
-  double* red = cm_smem;                                         // [16 waves][16 columns][3]
-  float2* rl = reinterpret_cast<float2*>(cm_smem + 16 * 16 * 3);   // [BS][n][16]
-  const int n = op.n, nt = op.nt, w = threadIdx.x >> 6, l = threadIdx.x & 63, r16 = l & 15, kq = l >> 4;
-  const int col0 = blockIdx.y * 16;
-  const size_t s0 = (size_t)blocks[blockIdx.x] * BS, s = s0 + w;
-  const float2* Mall = reinterpret_cast<const float2*>(op.M);
-  int nbv[8];
-#pragma unroll
-  for (int d = 0; d < 8; d++) nbv[d] = __builtin_amdgcn_readfirstlane((int)blk_nb[d * BS + w]);
-  f32x4 rR[NRT], rI[NRT], pR[NRT], pI[NRT], aR[NRT], aI[NRT];
-  const size_t off = s * n * NC + col0;
-  if (mode == CM_NONE) {
-    load_c<NRT>(r + off, n, rR, rI);
-  } else {
-    mfma_zero<NRT>(aR, aI);
-    const float2* src = mode == CM_FULL ? x : latest;
-    if (mode == CM_FULL) mfma_cproduct<NRT, false>(Mall + s * 5 * op.msize, nt, n, src + off, NC, -1.f, aR, aI);
-    for (int mu = 0; mu < 4; mu++) {
-      if (mode == CM_FULL || nbv[mu] < 0) {
-        const int y = op.nb[(size_t)mu * op.V + s];
-        mfma_cproduct<NRT, false>(Mall + (s * 5 + 1 + mu) * op.msize, nt, n, src + (size_t)y * n * NC + col0, NC, 1.f, aR, aI);
-      }
-      if (mode == CM_FULL || nbv[4 + mu] < 0) {
-        const int y = op.nb[(size_t)(4 + mu) * op.V + s];
-        mfma_cproduct<NRT, true>(Mall + ((size_t)y * 5 + 1 + mu) * op.msize, nt, n, src + (size_t)y * n * NC + col0, NC, 1.f, aR, aI);
-      }
-    }
-    load_c<NRT>((mode == CM_FULL ? eta : r) + off, n, rR, rI);
-#pragma unroll
-    for (int rt = 0; rt < NRT; rt++) { rR[rt] += aR[rt]; rI[rt] += aI[rt]; }
+  double* red = cm_smem;                                           // [16 waves][16 columns][3]
+  int* nbl = reinterpret_cast<int*>(cm_smem + 16 * 16 * 3);         // [8][16] in-block neighbours
+  float2* rl = reinterpret_cast<float2*>(cm_smem + 16 * 16 * 3 + 64);   // [BS][n][16]
+  const int n = op.n, w = threadIdx.x >> 6, l = threadIdx.x & 63, r16 = l & 15, kq = l >> 4;
+  // The two workgroups of a block (one per half of the columns) stream the same couplings: they are dealt to the same XCD, eight
+  // workgroup ids apart (ids go round-robin over the 8 XCDs), so that they run side by side and the second finds the lines of the
+  // first in that XCD's L2.  (A grid of (blocks, 2) ran them half a launch apart: every coupling came from memory twice.)
+  int bi, hf;
+  {
+    const int id = blockIdx.x, nblk = gridDim.x >> 1, full = (nblk >> 3) << 4;
+    if (id < full) { bi = ((id >> 4) << 3) + (id & 7); hf = (id >> 3) & 1; }
+    else { bi = (nblk & ~7) + ((id - full) >> 1); hf = (id - full) & 1; }
   }
+  const int col0 = hf * 16;
+  const size_t s0 = (size_t)blocks[bi] * BS, s = s0 + w, me = mfma_op_matrix_elems(n);
+  if (threadIdx.x < 8 * BS) nbl[(threadIdx.x / BS) * 16 + threadIdx.x % BS] = blk_nb[threadIdx.x];
+  __syncthreads();
+  f32x4 vR[NRT], vI[NRT], pR[NRT], pI[NRT], aR[NRT], aI[NRT];
+  const size_t off = s * n * NC + col0;
+  mfma_zero<NRT>(aR, aI);
+  if (mode != CM_NONE) {
+    const float2* src = mode == CM_FULL ? x : latest;
+#pragma nounroll
+    for (int p = (mode == CM_FULL ? 0 : 1); p < 9; p++) {
+      if (p > 0 && mode != CM_FULL && __builtin_amdgcn_readfirstlane(nbl[(p - 1) * 16 + w]) >= 0) continue;     // CM_UPDATE: the couplings that leave the block
+      const size_t y = p == 0 ? s : (size_t)op.nb[(size_t)(p - 1) * op.V + s];
+      mfma_cproduct_op<NRT>(Mop + ((p <= 4 ? s : y) * 9 + p) * me, n, src + y * n * NC + col0, NC, p == 0 ? -1.f : 1.f, aR, aI);
+    }
+  }
+  load_c<NRT>((mode == CM_FULL ? eta : r) + off, n, vR, vI);
+#pragma unroll
+  for (int rt = 0; rt < NRT; rt++) { vR[rt] += aR[rt]; vI[rt] += aI[rt]; }
   mfma_zero<NRT>(pR, pI);
   float2* rmine = rl + (size_t)w * n * 16;
-  store_lds<NRT>(rmine, n, rR, rI);
+  store_lds<NRT>(rmine, n, vR, vI);
   __syncthreads();
   for (int it = 0; it < iters; it++) {
-    // Dr = D_block r
+    // Dr = D_block r: the self coupling, then the couplings to the neighbours inside the block
     mfma_zero<NRT>(aR, aI);
-    mfma_cproduct<NRT, false>(Mall + s * 5 * op.msize, nt, n, rmine, 16, 1.f, aR, aI);
-    for (int mu = 0; mu < 4; mu++) {
-      if (nbv[mu] >= 0) mfma_cproduct<NRT, false>(Mall + (s * 5 + 1 + mu) * op.msize, nt, n, rl + (size_t)nbv[mu] * n * 16, 16, -1.f, aR, aI);
-      if (nbv[4 + mu] >= 0)
-        mfma_cproduct<NRT, true>(Mall + ((s0 + nbv[4 + mu]) * 5 + 1 + mu) * op.msize, nt, n, rl + (size_t)nbv[4 + mu] * n * 16, 16, -1.f, aR, aI);
+#pragma nounroll
+    for (int p = 0; p < 9; p++) {
+      int j = w;
+      if (p > 0) { j = __builtin_amdgcn_readfirstlane(nbl[(p - 1) * 16 + w]); if (j < 0) continue; }
+      mfma_cproduct_op<NRT>(Mop + ((p <= 4 ? s : s0 + j) * 9 + p) * me, n, rl + (size_t)j * n * 16, 16, p == 0 ? 1.f : -1.f, aR, aI);
     }
+    load_lds<NRT>(rmine, n, vR, vI);
     // alpha_c = <Dr, r>_c / <Dr, Dr>_c over the block (local_xy_over_xx, src/linalg_generic.c:158-169)
     double sr = 0, si = 0, sn = 0;
 #pragma unroll
     for (int rt = 0; rt < NRT; rt++)
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const double dr = aR[rt][q], di = aI[rt][q], vr = rR[rt][q], vi = rI[rt][q];
-        sr += dr * vr + di * vi; si += dr * vi - di * vr; sn += dr * dr + di * di;
+        const double dr = aR[rt][q], di = aI[rt][q], ur = vR[rt][q], ui = vI[rt][q];
+        sr += dr * ur + di * ui; si += dr * ui - di * ur; sn += dr * dr + di * di;
       }
     sr += __shfl_xor(sr, 16, 64); si += __shfl_xor(si, 16, 64); sn += __shfl_xor(sn, 16, 64);
     sr += __shfl_xor(sr, 32, 64); si += __shfl_xor(si, 32, 64); sn += __shfl_xor(sn, 32, 64);
-    if (kq == 0) { double* p = red + (w * 16 + r16) * 3; p[0] = sr; p[1] = si; p[2] = sn; }
+    if (kq == 0) { double* q = red + (w * 16 + r16) * 3; q[0] = sr; q[1] = si; q[2] = sn; }
+    // (every wavefront has finished its products -- its reads of the block's residuals -- when it arrives here, so the residual
+    // rows may be overwritten right after the sums are read; the next step's sums are written only behind the barrier at the end
+    // of this step, which every wavefront reaches after it has read these)
     __syncthreads();
     sr = 0; si = 0; sn = 0;
-    for (int ww = 0; ww < BS; ww++) { const double* p = red + (ww * 16 + r16) * 3; sr += p[0]; si += p[1]; sn += p[2]; }
+    for (int ww = 0; ww < BS; ww++) { const double* q = red + (ww * 16 + r16) * 3; sr += q[0]; si += q[1]; sn += q[2]; }
     float ar = 0.f, ai = 0.f;
     if (fabs(sn) >= (double)eps) { ar = (float)(sr / sn); ai = (float)(si / sn); }
 #pragma unroll
     for (int rt = 0; rt < NRT; rt++)
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const float vr = rR[rt][q], vi = rI[rt][q], dr = aR[rt][q], di = aI[rt][q];
-        pR[rt][q] += ar * vr - ai * vi; pI[rt][q] += ar * vi + ai * vr;
-        rR[rt][q] = vr - (ar * dr - ai * di); rI[rt][q] = vi - (ar * di + ai * dr);
+        const float ur = vR[rt][q], ui = vI[rt][q], dr = aR[rt][q], di = aI[rt][q];
+        pR[rt][q] += ar * ur - ai * ui; pI[rt][q] += ar * ui + ai * ur;
+        vR[rt][q] = ur - (ar * dr - ai * di); vI[rt][q] = ui - (ar * di + ai * dr);
       }
-    __syncthreads();                 // every wavefront has read the old residuals and the sums
-    store_lds<NRT>(rmine, n, rR, rI);
+    store_lds<NRT>(rmine, n, vR, vI);
     __syncthreads();
   }
-  store_c<NRT>(r + off, n, rR, rI);
+  load_lds<NRT>(rmine, n, vR, vI);
+  store_c<NRT>(r + off, n, vR, vI);
   store_c<NRT>(latest + off, n, pR, pI);
   load_c<NRT>(x + off, n, aR, aI);
 #pragma unroll
@@ -277,6 +323,8 @@ void CoarseMulti::release() {
   work_.clear(); next_work_.clear();
   if (kslab_) (void)hipFree(kslab_);
   kslab_ = nullptr; kslab_m_ = 0;
+  if (Mop_) (void)hipFree(Mop_);
+  Mop_ = nullptr; Mop_valid_ = false;
   if (d_partial_) (void)hipFree(d_partial_);
   if (d_h_) (void)hipFree(d_h_);
   if (d_coef_) (void)hipFree(d_coef_);
@@ -330,10 +378,23 @@ float2* CoarseMulti::next_work(int i) {
 #define CM_NRT_SWITCH(nrt, CALL) \
   switch (nrt) { case 1: CALL(1); break; case 2: CALL(2); break; case 3: CALL(3); break; default: CALL(4); break; }
 
+// the copy of the couplings in A-operand order follows the operator: refreshed when CoarseOp::version() has moved
+const float4* CoarseMulti::operands() const {
+  const size_t elems = (size_t)V_ * 9 * mfma_op_matrix_elems(n_);
+  if (!Mop_) DDAMG_HIP_CHECK(device_alloc(&Mop_, sizeof(float4) * elems));
+  if (Mop_version_ != op_->version() || !Mop_valid_) {
+    hipLaunchKernelGGL(cm_relayout_kernel, dim3(V_, 9), dim3(256), 0, st_, Mop_, op_->dev(), (n_ + 15) / 16);
+    DDAMG_HIP_CHECK(hipGetLastError());
+    Mop_version_ = op_->version(); Mop_valid_ = true;
+  }
+  return Mop_;
+}
+
 void CoarseMulti::apply(float2* out, const float2* in) const {
   DDAMG_REQUIRE(out != in, "coarse apply cannot run in place");
   const CoarseOpDev<float> op = op_->dev();
-#define CM_CALL(NRTV) hipLaunchKernelGGL((cm_apply_kernel<NRTV>), dim3(V_), dim3(128), 0, st_, out, in, op)
+  const float4* Mop = operands();
+#define CM_CALL(NRTV) hipLaunchKernelGGL((cm_apply_op_kernel<NRTV>), dim3(V_), dim3(128), 0, st_, out, in, Mop, op)
   CM_NRT_SWITCH((n_ + 15) / 16, CM_CALL)
 #undef CM_CALL
   DDAMG_HIP_CHECK(hipGetLastError());
@@ -342,13 +403,14 @@ void CoarseMulti::apply(float2* out, const float2* in) const {
 void CoarseMulti::block_solve(int list, int mode, const float2* eta) {
   if (nblk_[list] == 0) return;
   const CoarseOpDev<float> op = op_->dev();
-  const size_t lds = sizeof(double) * 16 * 16 * 3 + sizeof(float2) * (size_t)BS_ * n_ * 16;
+  const float4* Mop = operands();
+  const size_t lds = sizeof(double) * (16 * 16 * 3 + 64) + sizeof(float2) * (size_t)BS_ * n_ * 16;
   const float eps = 1e-6f;
 #define CM_CALL(NRTV)                                                                                                                              \
   {                                                                                                                                                \
-    DDAMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cm_block_minres_kernel<NRTV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-    hipLaunchKernelGGL((cm_block_minres_kernel<NRTV>), dim3(nblk_[list], 2), dim3(64 * BS_), lds, st_, x_, r_, latest_, eta, op, d_blocks_[list], d_blk_nb_, BS_, \
-                       block_iter_, eps, mode);                                                                                                    \
+    DDAMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&cm_block_minres_op_kernel<NRTV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+    hipLaunchKernelGGL((cm_block_minres_op_kernel<NRTV>), dim3(2 * nblk_[list]), dim3(64 * BS_), lds, st_, x_, r_, latest_, eta, Mop, op, d_blocks_[list], d_blk_nb_, \
+                       BS_, block_iter_, eps, mode);                                                                                               \
   }
   CM_NRT_SWITCH((n_ + 15) / 16, CM_CALL)
 #undef CM_CALL

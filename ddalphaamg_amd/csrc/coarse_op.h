@@ -65,7 +65,11 @@ class CoarseOp {
   void halo_exchange(const T* in, hipStream_t st) const;
   int V() const { return V_; }
   int n() const { return n_; }
-  T* matrices() { return M_; }
+  // the non-const accessor is how the Galerkin constructions write the couplings: it counts as a change of the operator
+  // (version(): copies of the couplings in another layout -- coarse_multi.h -- know when to refresh themselves)
+  T* matrices() { version_++; return M_; }
+  const T* matrices() const { return M_; }
+  unsigned version() const { return version_; }
   size_t msize() const { return msize_; }
   int nt() const { return nt_; }
 
@@ -101,6 +105,7 @@ class CoarseOp {
   mutable T* bwd_ = nullptr;   // [4][V][n] backward products of apply()'s first phase
   int* nb_ = nullptr;
   int V_ = 0, n_ = 0, nt_ = 0;
+  unsigned version_ = 0;
   size_t msize_ = 0;
   mutable HaloArena arena_;
   mutable HaloArena wide_arena_;      // created at the first wide_halo_exchange

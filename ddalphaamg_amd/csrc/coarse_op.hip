@@ -719,6 +719,7 @@ __global__ void shift_self_diagonal_kernel(T* __restrict__ M, int V, int n, int 
 }
 template <typename T>
 void CoarseOp<T>::shift_diagonal(double diff, hipStream_t st) {
+  version_++;
   const size_t tot = (size_t)V_ * n_;
   hipLaunchKernelGGL(shift_self_diagonal_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, M_, V_, n_, nt_, msize_, (T)diff);
   DDAMG_HIP_CHECK(hipGetLastError());
@@ -815,6 +816,7 @@ void CoarseOp<T>::import_reference(const Geometry& g, const double* D_ref, const
   }
   DDAMG_HIP_CHECK(hipMemcpyAsync(M_, h.data(), sizeof(T) * h.size(), hipMemcpyHostToDevice, st));
   DDAMG_HIP_CHECK(hipStreamSynchronize(st));
+  version_++;
   compute_self_inverse(st);
 }
 

@@ -54,6 +54,70 @@ __device__ __forceinline__ void mfma_cproduct(const float2* __restrict__ M, int 
   }
 }
 
+// ---- couplings in the A-operand order of the matrix instruction -------------------------------------------------------------
+// A copy of a coupling matrix laid out the way the wavefront consumes it: pass P (eight k) of row tile rt is ONE contiguous
+// kilobyte, lane (kq, r16) holding the float4 { A[i][8P + kq], A[i][8P + 4 + kq] }, i = 16 rt + r16 -- a 16-byte load per lane
+// and row tile where the 8 x 8 tile layout of coarse_op.h costs two 8-byte loads whose 64 lanes touch 16 cache lines for 32 bytes
+// each.  Rows beyond n are stored as zeros, and the backward coupling G5 U^H G5 is stored as a matrix of its own (signs and
+// conjugation applied once at the copy), so a product has no clamps, selects or sign arithmetic left.
+//   A + ((rt * npass + P) * 64 + lane)            npass = n / 8, one matrix = NRT * npass * 64 float4
+__host__ __device__ inline size_t mfma_op_matrix_elems(int n) { return (size_t)((n + 15) / 16) * (n / 8) * 64; }
+
+// acc += sign * A B for one wavefront, A in the order above, B[k][j] = Bk[k * bstride + j]; software-pipelined by hand (the
+// operands of pass P + 1 requested before the matrix instructions of pass P; scheduling barriers keep the compiler from sinking
+// the loads to their first use).  n % 8 == 0.
+template <int NRT>
+__device__ __forceinline__ void mfma_cproduct_op(const float4* __restrict__ A, int n, const float2* __restrict__ Bk, int bstride, float sign,
+                                                 mfma_f32x4 (&accR)[NRT], mfma_f32x4 (&accI)[NRT]) {
+  const int l = threadIdx.x & 63, r16 = l & 15, kq = l >> 4;
+  const int npass = n >> 3;
+  const float4* Al = A + l;
+  const float2* Bl = Bk + (size_t)kq * bstride + r16;
+  auto load_pass = [&](int P, float4 (&a)[NRT], float2 (&b)[2]) {
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) a[rt] = Al[(size_t)(rt * npass + P) * 64];
+    b[0] = Bl[(size_t)(8 * P) * bstride]; b[1] = Bl[(size_t)(8 * P + 4) * bstride];
+  };
+  auto mfma_pass = [&](float4 (&a)[NRT], float2 (&b)[2]) {
+    const float b0x = sign * b[0].x, b0y = sign * b[0].y, b1x = sign * b[1].x, b1y = sign * b[1].y;
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) {
+      accR[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].x, b0x, accR[rt], 0, 0, 0);
+      accI[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].x, b0y, accI[rt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) {
+      accR[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-a[rt].y, b0y, accR[rt], 0, 0, 0);
+      accI[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].y, b0x, accI[rt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) {
+      accR[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].z, b1x, accR[rt], 0, 0, 0);
+      accI[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].z, b1y, accI[rt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int rt = 0; rt < NRT; rt++) {
+      accR[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(-a[rt].w, b1y, accR[rt], 0, 0, 0);
+      accI[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].w, b1x, accI[rt], 0, 0, 0);
+    }
+  };
+  float4 a0[NRT], a1[NRT];
+  float2 b0[2], b1[2];
+  load_pass(0, a0, b0);
+  for (int P = 0; P < npass; P += 2) {
+    if (P + 1 < npass) load_pass(P + 1, a1, b1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_pass(a0, b0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (P + 1 < npass) {
+      if (P + 2 < npass) load_pass(P + 2, a0, b0);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_pass(a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
 template <int NRT>
 __device__ __forceinline__ void mfma_zero(mfma_f32x4 (&accR)[NRT], mfma_f32x4 (&accI)[NRT]) {
 #pragma unroll
