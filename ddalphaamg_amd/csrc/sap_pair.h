@@ -33,7 +33,15 @@ struct SapPairArgs {
   // pointer to a block of zeros, a cached row + select -- took the kernel from 42 to 120-145 spilled registers and from 1020 to
   // 1245 us per smoother call.)
   int odd_r_store;
+#ifdef DDAMG_SAP_CHAIN_DIAG
+  unsigned long long* diag;      // diagnostic build: cycle stamps of the last MinRes step, [workgroup][wavefront][16]
+#endif
 };
+#ifdef DDAMG_SAP_CHAIN_DIAG
+constexpr int SAP_DIAG_STAMPS = 16;
+// device buffer the stamped launches write to ([gridDim.x][4 wavefronts][16] shader-clock values; allocated at first use)
+unsigned long long* sap_chain_diag_buffer(size_t workgroups);
+#endif
 
 // faces: [num_blocks][8][3][64] float4
 inline size_t sap_face_elems(int num_blocks) { return (size_t)num_blocks * 8 * 3 * 64; }

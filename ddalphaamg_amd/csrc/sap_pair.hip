@@ -20,10 +20,13 @@
 //    (src/dirac_generic.c:181-217) -- and the neighbour reads whole lines and needs no foreign link.
 //  * the full residual of the first sweep (block_op + boundary_op) takes its in-block part through the same LDS exchange
 //    and the resident operator instead of re-reading links and spinors through the cache.
-//  * four barriers per MinRes step instead of six (the reduction scratch is double-buffered).
+//  * a half hop in three phases -- plain projections out, link products on BOTH sides at once, finished products in -- so that
+//    the even and the odd wavefronts of a block work at the same time in the middle phase (round 4, profiles/r04_sap_chain.md);
+//    five barriers per MinRes step (the reduction scratch is double-buffered); the wavefront sums on the DPP path.
 #include "sap_pair.h"
 #include "sap_modes.h"
 #include "pk_device.h"
+#include <algorithm>
 
 namespace ddamg {
 
@@ -32,44 +35,76 @@ namespace sap_pair_detail {
 constexpr int HS = 128, BS = 256, FH = 32;   // sites per parity, per block, per parity class of a face (64-site faces)
 constexpr float EPS_F = 1e-6f;               // EPS_float (src/main.h:45)
 
-// in-block exchange of projected half spinors through LDS: slot (d, c) of sender j at sl[(d*6 + c)*HS + j]
+// in-block exchange of projected half spinors through LDS: slot (d, c) of sender j at sl[(d*6 + c)*HS + j].
+// A half hop (even -> odd or odd -> even) in THREE phases, so that both parities of a block work in the middle one
+// (profiles/r04_sap_chain.md: with send = project + link^H products + write on the one side and collect = read + link products
+// + reconstruct on the other, one after the other, a MinRes step was a chain of 12 500 cycles in which half of the block's
+// wavefronts waited at any time):
+//   1. the senders leave the plain projections (1 - gamma_mu) v for their -mu neighbours             emit_raw
+//   2. the senders multiply U_mu^dagger (1 + gamma_mu) v for their +mu neighbours                   emit_mul
+//      WHILE the receivers read the plain projections and multiply them with their own links        collect_raw
+//   3. the receivers read the finished products of phase 2                                           collect_mul
+// (The senders write their slots whether or not a neighbour inside the block will read them: a slot belongs to its sender, a
+// wavefront executes the instructions anyway as long as one of its lanes has the neighbour, and without the branch the four
+// directions are one basic block.)
 template <int MU>
-__device__ __forceinline__ void emit_dir(const cf (&v)[12], const cf (&U)[9], const int (&nbl)[8], cf* __restrict__ sl, int j) {
-  if (nbl[MU] >= 0) {   // my +mu neighbour is in the block: it needs U_mu(me)^dagger (1+gamma_mu) v
-    cf h[6], g[6];
-    pk_project<MU, +1>(v, h);
-    pk_su3_mul_dag(U, h, g);
+__device__ __forceinline__ void emit_raw_dir(const cf (&v)[12], const int (&nbl)[8], cf* __restrict__ sl, int j) {
+  cf h[6];      // my -mu neighbour multiplies (1-gamma_mu) v with its own link
+  pk_project<MU, -1>(v, h);
 #pragma unroll
-    for (int c = 0; c < 6; c++) sl[(MU * 6 + c) * HS + j] = g[c];
-  }
-  if (nbl[4 + MU] >= 0) {   // my -mu neighbour multiplies (1-gamma_mu) v with its own link
-    cf h[6];
-    pk_project<MU, -1>(v, h);
-#pragma unroll
-    for (int c = 0; c < 6; c++) sl[((4 + MU) * 6 + c) * HS + j] = h[c];
-  }
+  for (int c = 0; c < 6; c++) sl[((4 + MU) * 6 + c) * HS + j] = h[c];
 }
 template <int MU>
-__device__ __forceinline__ void collect_dir(cf (&acc)[12], const cf (&U)[9], const int (&nbl)[8], const cf* __restrict__ sl) {
-  {
-    const int n = nbl[4 + MU];   // from x-mu: already multiplied by its link
-    if (n >= 0) {
-      cf g[6];
+__device__ __forceinline__ void emit_mul_dir(const cf (&v)[12], const cf (&U)[9], const int (&nbl)[8], cf* __restrict__ sl, int j) {
+  cf h[6], g[6];   // my +mu neighbour needs U_mu(me)^dagger (1+gamma_mu) v
+  pk_project<MU, +1>(v, h);
+  pk_su3_mul_dag(U, h, g);
 #pragma unroll
-      for (int c = 0; c < 6; c++) g[c] = sl[(MU * 6 + c) * HS + n];
-      pk_reconstruct_sub<MU, +1>(g, acc);
-    }
-  }
-  {
-    const int n = nbl[MU];       // from x+mu: multiply with my own link
-    if (n >= 0) {
-      cf h[6], g[6];
+  for (int c = 0; c < 6; c++) sl[(MU * 6 + c) * HS + j] = g[c];
+}
+// (The receivers keep the branch: without it -- neighbour index clamped, the contribution of a neighbour outside the block zeroed
+// by a factor -- the reads of the four directions become one batch and this phase drops from 2020 to 1380 cycles, but the 48
+// registers of half spinors in flight next to the resident operator make the allocator spill parts of the clover matrix into the
+// loop: its products go from 700 to 1200-2100 cycles and the smoother call from 888 to 967 us; two directions per batch: 988 us.)
+template <int MU>
+__device__ __forceinline__ void collect_raw_dir(cf (&acc)[12], const cf (&U)[9], const int (&nbl)[8], const cf* __restrict__ sl) {
+  const int n = nbl[MU];       // from x+mu: multiply with my own link
+  if (n >= 0) {
+    cf h[6], g[6];
 #pragma unroll
-      for (int c = 0; c < 6; c++) h[c] = sl[((4 + MU) * 6 + c) * HS + n];
-      pk_su3_mul(U, h, g);
-      pk_reconstruct_sub<MU, -1>(g, acc);
-    }
+    for (int c = 0; c < 6; c++) h[c] = sl[((4 + MU) * 6 + c) * HS + n];
+    pk_su3_mul(U, h, g);
+    pk_reconstruct_sub<MU, -1>(g, acc);
   }
+}
+
+template <int MU>
+__device__ __forceinline__ void collect_mul_dir(cf (&acc)[12], const int (&nbl)[8], const cf* __restrict__ sl) {
+  const int n = nbl[4 + MU];   // from x-mu: already multiplied by its link
+  if (n >= 0) {
+    cf g[6];
+#pragma unroll
+    for (int c = 0; c < 6; c++) g[c] = sl[(MU * 6 + c) * HS + n];
+    pk_reconstruct_sub<MU, +1>(g, acc);
+  }
+}
+
+// sum over the 64 lanes of a wavefront, the same value in every lane afterwards: four row-local exchanges and two row broadcasts
+// on the data-parallel-primitive path of the vector unit (__shfl_xor goes through the LDS crossbar: 18 dependent ds_bpermute for
+// the three sums of a MinRes step were 825 cycles of its chain)
+__device__ __forceinline__ float dpp_add(float v, float w) { return v + w; }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_term(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_term<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+  v += dpp_term<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+  v += dpp_term<0x141, 0xF>(v);    // row_half_mirror
+  v += dpp_term<0x140, 0xF>(v);    // row_mirror: every lane of a row of 16 holds the row's sum
+  v += dpp_term<0x142, 0xA>(v);    // row_bcast:15 into rows 1 and 3
+  v += dpp_term<0x143, 0xC>(v);    // row_bcast:31 into rows 2 and 3: lane 63 holds the sum of the wavefront
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
 __device__ __forceinline__ void face_load(const float4* __restrict__ f, cf (&h)[6]) {
@@ -123,19 +158,33 @@ __device__ __forceinline__ void face_emit_dir(const cf (&v)[12], const cf (&U)[9
   }
 }
 
-#define DDAMG_EMIT(v)                                   \
+#define DDAMG_EMIT_RAW(v)                               \
   do {                                                  \
-    emit_dir<0>(v, U0, nbl, sl, j);                     \
-    emit_dir<1>(v, U1, nbl, sl, j);                     \
-    emit_dir<2>(v, U2, nbl, sl, j);                     \
-    emit_dir<3>(v, U3, nbl, sl, j);                     \
+    emit_raw_dir<0>(v, nbl, sl, j);                     \
+    emit_raw_dir<1>(v, nbl, sl, j);                     \
+    emit_raw_dir<2>(v, nbl, sl, j);                     \
+    emit_raw_dir<3>(v, nbl, sl, j);                     \
   } while (0)
-#define DDAMG_COLLECT(acc)                              \
+#define DDAMG_EMIT_MUL(v)                               \
   do {                                                  \
-    collect_dir<0>(acc, U0, nbl, sl);                   \
-    collect_dir<1>(acc, U1, nbl, sl);                   \
-    collect_dir<2>(acc, U2, nbl, sl);                   \
-    collect_dir<3>(acc, U3, nbl, sl);                   \
+    emit_mul_dir<0>(v, U0, nbl, sl, j);                 \
+    emit_mul_dir<1>(v, U1, nbl, sl, j);                 \
+    emit_mul_dir<2>(v, U2, nbl, sl, j);                 \
+    emit_mul_dir<3>(v, U3, nbl, sl, j);                 \
+  } while (0)
+#define DDAMG_COLLECT_RAW(acc)                          \
+  do {                                                  \
+    collect_raw_dir<0>(acc, U0, nbl, sl);               \
+    collect_raw_dir<1>(acc, U1, nbl, sl);               \
+    collect_raw_dir<2>(acc, U2, nbl, sl);               \
+    collect_raw_dir<3>(acc, U3, nbl, sl);               \
+  } while (0)
+#define DDAMG_COLLECT_MUL(acc)                          \
+  do {                                                  \
+    collect_mul_dir<0>(acc, nbl, sl);                   \
+    collect_mul_dir<1>(acc, nbl, sl);                   \
+    collect_mul_dir<2>(acc, nbl, sl);                   \
+    collect_mul_dir<3>(acc, nbl, sl);                   \
   } while (0)
 #define DDAMG_EXT_FETCH()                                                \
   do {                                                                   \
@@ -156,8 +205,32 @@ __device__ __forceinline__ void face_emit_dir(const cf (&v)[12], const cf (&U)[9
     ext_apply<3>(acc, U3, ext, fh[3], fh[7]);                            \
   } while (0)
 
+// Diagnostic build (-DDDAMG_SAP_CHAIN_DIAG; tools/gpu/run.sh sap_chain): every wavefront stamps the shader clock (s_memtime) at
+// the segment boundaries of its last MinRes step -- after its LDS traffic has drained, with scheduling barriers around the stamp
+// -- and leaves the stamps in SapPairArgs::diag.  Even wavefronts: 0 step start, 1 plain projections written, 2 past A1, 11 link^H
+// products written, 3 past A2, 4 D_ee product done, 5 past B1, 14 plain projections of the odd sites read and multiplied, 6 past
+// B2, 7 finished products read + partial sums, 8 wavefront sums + scratch written, 9 past B4, 10 alpha + update.  Odd wavefronts:
+// 0 step start, 2 past A1, 11 plain projections read and multiplied, 3 past A2, 12 finished products read + D_oo^-1 product,
+// 13 plain projections written, 5 past B1, 14 link^H products written, 6 past B2, 9 past B4.  Normal builds: nothing.
+#ifdef DDAMG_SAP_CHAIN_DIAG
+#define SAP_STAMP(k)                                                 \
+  do {                                                               \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    __builtin_amdgcn_s_waitcnt(0xc07f); /* lgkmcnt(0), vmcnt free */ \
+    stamp[k] = __builtin_amdgcn_s_memtime();                         \
+    __builtin_amdgcn_sched_barrier(0);                               \
+  } while (0)
+#else
+#define SAP_STAMP(k) do { } while (0)
+#endif
+
 template <bool DIST, int NB, bool CMP>
 __global__ __launch_bounds__(256 * NB, 2) void sap_pair_kernel(SapPairArgs a) {
+#ifdef DDAMG_SAP_CHAIN_DIAG
+  unsigned long long stamp[SAP_DIAG_STAMPS];
+#pragma unroll
+  for (int k = 0; k < SAP_DIAG_STAMPS; k++) stamp[k] = 0;
+#endif
   __shared__ cf slots[NB][8 * 6 * HS];
   __shared__ float red[2][NB][8];        // [generation][block of the workgroup][2 even wavefronts x 3 sums]
   const FineOpDev<float>& op = a.op;
@@ -270,14 +343,15 @@ __global__ __launch_bounds__(256 * NB, 2) void sap_pair_kernel(SapPairArgs a) {
       for (int k = 0; k < 6; k++) e[6 + k] += t[k];
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!odd) DDAMG_EMIT(xs);
+    if (!odd) DDAMG_EMIT_RAW(xs);
     __syncthreads();
-    if (odd) DDAMG_COLLECT(e);
+    if (!odd) DDAMG_EMIT_MUL(xs); else DDAMG_COLLECT_RAW(e);
     __syncthreads();
-    if (odd) DDAMG_EMIT(xs);
+    if (odd) { DDAMG_COLLECT_MUL(e); DDAMG_EMIT_RAW(xs); }
     __syncthreads();
-    if (!odd) DDAMG_COLLECT(e);
+    if (odd) DDAMG_EMIT_MUL(xs); else DDAMG_COLLECT_RAW(e);
     __syncthreads();
+    if (!odd) DDAMG_COLLECT_MUL(e);      // (the next write of these slots lies behind the first barrier of the block solve)
 #pragma unroll
     for (int k = 0; k < 12; k++) v0[k] -= e[k];
   } else {
@@ -301,27 +375,44 @@ __global__ __launch_bounds__(256 * NB, 2) void sap_pair_kernel(SapPairArgs a) {
   if (odd) {
     // t_o = D_oo^-1 r_o, sent to the even sites
     pk_clover(C, v0, v1);
-    DDAMG_EMIT(v1);
-    __syncthreads();                      // S1
-    __syncthreads();                      // S2
+    DDAMG_EMIT_RAW(v1);
+    __syncthreads();                      // P1
+    DDAMG_EMIT_MUL(v1);
+    __syncthreads();                      // P2
+    __syncthreads();                      // P3: the even sites have read every slot
     for (int it = 0; it < a.block_iter; it++) {
-      __syncthreads();                    // B1: the even sites' residual is in the slots
+      SAP_STAMP(0);
+      __syncthreads();                    // A1: the plain projections of the even sites' residual are in the slots
+      SAP_STAMP(2);
       cf acc[12];
 #pragma unroll
       for (int k = 0; k < 12; k++) acc[k] = cf_make(0.f, 0.f);
-      DDAMG_COLLECT(acc);                 // D_oe rm
+      DDAMG_COLLECT_RAW(acc);             // (while the even sites multiply)
+      SAP_STAMP(11);
+      __syncthreads();                    // A2: ... and their link products
+      SAP_STAMP(3);
+      DDAMG_COLLECT_MUL(acc);             // D_oe rm
       pk_clover(C, acc, v1);              // D_oo^-1 D_oe rm
-      __syncthreads();                    // B2: every odd site has read the slots
-      DDAMG_EMIT(v1);
-      __syncthreads();                    // B3
+      SAP_STAMP(12);
+      DDAMG_EMIT_RAW(v1);
+      SAP_STAMP(13);
+      __syncthreads();                    // B1
+      SAP_STAMP(5);
+      DDAMG_EMIT_MUL(v1);                 // (while the even sites read the plain projections and multiply)
+      SAP_STAMP(14);
+      __syncthreads();                    // B2
+      SAP_STAMP(6);
       __syncthreads();                    // B4: (the even sites' reduction)
+      SAP_STAMP(9);
     }
-    __syncthreads();                      // F1: delta_e is in the slots
+    __syncthreads();                      // F1: the plain projections of delta_e are in the slots
     // delta_o = D_oo^-1 ( r_o - D_oe delta_e )
     cf acc[12];
 #pragma unroll
     for (int k = 0; k < 12; k++) acc[k] = cf_make(0.f, 0.f);
-    DDAMG_COLLECT(acc);
+    DDAMG_COLLECT_RAW(acc);
+    __syncthreads();                      // F2
+    DDAMG_COLLECT_MUL(acc);
 #pragma unroll
     for (int k = 0; k < 12; k++) v0[k] -= acc[k];
     pk_clover(C, v0, v1);
@@ -329,26 +420,40 @@ __global__ __launch_bounds__(256 * NB, 2) void sap_pair_kernel(SapPairArgs a) {
     for (int k = 0; k < 12; k++) v0[k] = cf_make(0.f, 0.f);     // r_o = 0
   } else {
     cf lphi[12];   // MinRes iterate
-    __syncthreads();                      // S1
+    __syncthreads();                      // P1
     {
       // r_e <- r_e - D_eo t_o
       cf acc[12];
 #pragma unroll
       for (int k = 0; k < 12; k++) acc[k] = cf_make(0.f, 0.f);
-      DDAMG_COLLECT(acc);
+      DDAMG_COLLECT_RAW(acc);
+      __syncthreads();                    // P2
+      DDAMG_COLLECT_MUL(acc);
 #pragma unroll
       for (int k = 0; k < 12; k++) { v0[k] -= acc[k]; lphi[k] = cf_make(0.f, 0.f); }
     }
-    __syncthreads();                      // S2: the slots can be rewritten
+    __syncthreads();                      // P3: the slots can be rewritten
     for (int it = 0; it < a.block_iter; it++) {
-      DDAMG_EMIT(v0);
-      __syncthreads();                    // B1
-      __syncthreads();                    // B2
-      pk_clover(C, v0, v1);               // D_ee rm (while the odd sites send)
+      SAP_STAMP(0);
+      DDAMG_EMIT_RAW(v0);
+      SAP_STAMP(1);
+      __syncthreads();                    // A1
+      SAP_STAMP(2);
+      DDAMG_EMIT_MUL(v0);                 // (while the odd sites read the plain projections and multiply)
+      SAP_STAMP(11);
+      __syncthreads();                    // A2
+      SAP_STAMP(3);
+      pk_clover(C, v0, v1);               // D_ee rm (while the odd sites finish D_oo^-1 D_oe rm and send its plain projections)
 #pragma unroll
       for (int k = 0; k < 12; k++) v1[k] = -v1[k];
-      __syncthreads();                    // B3: D_oo^-1 D_oe rm is in the slots
-      DDAMG_COLLECT(v1);                  // v1 = -(D_ee rm) - H_e(..) = -Dr
+      SAP_STAMP(4);
+      __syncthreads();                    // B1: the plain projections of D_oo^-1 D_oe rm are in the slots
+      SAP_STAMP(5);
+      DDAMG_COLLECT_RAW(v1);              // (while the odd sites multiply)
+      SAP_STAMP(14);
+      __syncthreads();                    // B2
+      SAP_STAMP(6);
+      DDAMG_COLLECT_MUL(v1);              // v1 = -(D_ee rm) - H_e(..) = -Dr
       // alpha = <Dr,rm>/<Dr,Dr>   (local_xy_over_xx, src/linalg_generic.c:158-169)
       cf pr = cf_make(0.f, 0.f), pi = cf_make(0.f, 0.f), pd = cf_make(0.f, 0.f);
 #pragma unroll
@@ -359,13 +464,13 @@ __global__ __launch_bounds__(256 * NB, 2) void sap_pair_kernel(SapPairArgs a) {
         pd = __builtin_elementwise_fma(v1[k], v1[k], pd);
       }
       float nr = pr.x + pr.y, ni = pi.x - pi.y, dn = pd.x + pd.y;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        nr += __shfl_xor(nr, o, 64); ni += __shfl_xor(ni, o, 64); dn += __shfl_xor(dn, o, 64);
-      }
+      SAP_STAMP(7);
+      nr = wave_sum(nr); ni = wave_sum(ni); dn = wave_sum(dn);
       float* rd = red[it & 1][bw];
       if (lane == 0) { rd[hw * 3] = nr; rd[hw * 3 + 1] = ni; rd[hw * 3 + 2] = dn; }
+      SAP_STAMP(8);
       __syncthreads();                    // B4
+      SAP_STAMP(9);
       // both even wavefronts add the two partial sums in the same order: the same alpha on every site
       nr = rd[0] + rd[3]; ni = rd[1] + rd[4]; dn = rd[2] + rd[5];
       cf al = cf_make(0.f, 0.f);
@@ -375,13 +480,23 @@ __global__ __launch_bounds__(256 * NB, 2) void sap_pair_kernel(SapPairArgs a) {
         lphi[k] = cf_mac(lphi[k], al, v0[k]);
         v0[k] = cf_mac(v0[k], -al, v1[k]);
       }
+      SAP_STAMP(10);
     }
     // delta_e to the odd sites
 #pragma unroll
     for (int k = 0; k < 12; k++) v1[k] = lphi[k];
-    DDAMG_EMIT(v1);
+    DDAMG_EMIT_RAW(v1);
     __syncthreads();                      // F1
+    DDAMG_EMIT_MUL(v1);
+    __syncthreads();                      // F2
   }
+#ifdef DDAMG_SAP_CHAIN_DIAG
+  if (a.diag && lane == 0 && NB == 1) {
+    unsigned long long* d = a.diag + ((size_t)blockIdx.x * 4 + w) * SAP_DIAG_STAMPS;
+#pragma unroll
+    for (int k = 0; k < SAP_DIAG_STAMPS; k++) d[k] = stamp[k];
+  }
+#endif
   if (active) {
     // x += delta ; r_e = MinRes residual, r_o = 0 ; the faces of delta (and of the new x) for the neighbouring blocks
     if (!odd || a.odd_r_store) pk_store_site<12>(a.r, V, s, v0);
@@ -410,8 +525,10 @@ __global__ __launch_bounds__(256 * NB, 2) void sap_pair_kernel(SapPairArgs a) {
     }
   }
 }
-#undef DDAMG_EMIT
-#undef DDAMG_COLLECT
+#undef DDAMG_EMIT_RAW
+#undef DDAMG_EMIT_MUL
+#undef DDAMG_COLLECT_RAW
+#undef DDAMG_COLLECT_MUL
 #undef DDAMG_EXT_FETCH
 #undef DDAMG_EXT_APPLY
 
@@ -443,8 +560,33 @@ __global__ __launch_bounds__(256) void sap_face_pack_kernel(FineOpDev<float> op,
 }  // namespace sap_pair_detail
 using namespace sap_pair_detail;
 
-void sap_pair_launch(const SapPairArgs& a, bool dist, hipStream_t st) {
-  if (a.nblocks <= 0) return;
+#ifdef DDAMG_SAP_CHAIN_DIAG
+static unsigned long long* g_sap_diag = nullptr;
+static size_t g_sap_diag_wgs = 0;
+unsigned long long* sap_chain_diag_buffer(size_t workgroups) {
+  if (workgroups > g_sap_diag_wgs) {
+    if (g_sap_diag) (void)hipFree(g_sap_diag);
+    DDAMG_HIP_CHECK(device_alloc(&g_sap_diag, sizeof(unsigned long long) * workgroups * 4 * SAP_DIAG_STAMPS));
+    g_sap_diag_wgs = workgroups;
+  }
+  return g_sap_diag;
+}
+// the stamps of the last stamped launch: [workgroups][4][16]; returns the number of workgroups (0: nothing stamped yet)
+extern "C" int ddamg_hip_diag_sap_chain(unsigned long long* host, int max_workgroups) {
+  const int n = (int)std::min<size_t>(g_sap_diag_wgs, (size_t)max_workgroups);
+  if (n > 0 && hipMemcpy(host, g_sap_diag, sizeof(unsigned long long) * (size_t)n * 4 * SAP_DIAG_STAMPS, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+  return n;
+}
+#endif
+
+void sap_pair_launch(const SapPairArgs& a_in, bool dist, hipStream_t st) {
+  if (a_in.nblocks <= 0) return;
+#ifdef DDAMG_SAP_CHAIN_DIAG
+  SapPairArgs a = a_in;
+  a.diag = a.solve && a.block_iter > 0 ? sap_chain_diag_buffer((size_t)a.nblocks) : nullptr;
+#else
+  const SapPairArgs& a = a_in;
+#endif
   // blocks per workgroup: 2 (lockstep pair with complementary wavefront roles) or 1 (two independent workgroups per CU,
   // whose load and compute phases drift apart and overlap); DDAMG_SAP_BLOCKS_PER_WG selects, see DESIGN.md for the numbers
   static const int nb = [] { const char* e = getenv("DDAMG_SAP_BLOCKS_PER_WG"); return e ? atoi(e) : 1; }();
