@@ -89,6 +89,7 @@ def load_library():
         "ddamg_hip_set_gauge2": [vp, dp, dp, ctypes.c_int, dp],
         "ddamg_hip_set_operator": [vp, dp, dp],
         "ddamg_hip_shift_mass": [vp, ctypes.c_double],
+        "ddamg_hip_scale_clover": [vp, ctypes.c_double, ctypes.c_double],
         "ddamg_hip_get_operator": [vp, dp, dp],
         "ddamg_hip_vec_create": [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)],
         "ddamg_hip_vec_destroy": [vp, vp],
@@ -317,6 +318,10 @@ class Context:
     def shift_mass(self, m0):
         """shift_update of the reference: change the mass of the operator that is set, on the device, on every level"""
         _check(self._lib.ddamg_hip_shift_mass(self._h, float(m0)))
+
+    def scale_clover(self, scale_even, scale_odd):
+        """clover term times scale_even / scale_odd by global parity, on the device (absolute: (1, 1) restores the operator)"""
+        _check(self._lib.ddamg_hip_scale_clover(self._h, float(scale_even), float(scale_odd)))
 
     def get_operator(self):
         V = self.volume(0)

@@ -139,6 +139,7 @@ int ddamg_hip_destroy(ddamg_hip_ctx* c) {
   if (c->p32_out) (void)hipFree(c->p32_out);
   for (auto& lv : c->levels) if (lv->d_lex_of_site) (void)hipFree(lv->d_lex_of_site);
   if (c->d_stage) (void)hipFree(c->d_stage);
+  if (c->clover_base) (void)hipFree(c->clover_base);
   (void)hipEventDestroy(c->ev0);
   (void)hipEventDestroy(c->ev1);
   (void)hipStreamDestroy(c->stream);
@@ -146,7 +147,13 @@ int ddamg_hip_destroy(ddamg_hip_ctx* c) {
   DDAMG_API_END
 }
 
+static void drop_clover_base(ddamg_hip_ctx* c) {
+  if (c->clover_base) { (void)hipStreamSynchronize(c->stream); (void)hipFree(c->clover_base); c->clover_base = nullptr; }
+  c->scale_even = c->scale_odd = 1.0;
+}
+
 static void upload_operator(ddamg_hip_ctx* c) {
+  drop_clover_base(c);      // a new operator is unscaled
   const Geometry& g = c->levels[0]->geom;
   c->fop64.upload(g, c->D_host.data(), c->clover_host.data(), c->stream);
   c->fop32.upload(g, c->D_host.data(), c->clover_host.data(), c->stream);
@@ -204,9 +211,11 @@ int ddamg_hip_set_gauge2(ddamg_hip_ctx* c, const double* hopp_gauge_lex, const d
 int ddamg_hip_shift_mass(ddamg_hip_ctx* c, double new_m0) {
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c && c->have_operator, "no operator set");
+  DDAMG_REQUIRE(c->scale_even == 1.0 && c->scale_odd == 1.0, "shift_mass on a scaled operator: undo ddamg_hip_scale_clover first (scale 1, 1)");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
   const double diff = new_m0 - c->par.m0;
   if (diff != 0.0) {
+    drop_clover_base(c);
     const size_t V = c->levels[0]->geom.V;
     c->fop64.shift_diagonal(c->fop64.clover_field(), diff, c->stream);
     c->fop32.shift_diagonal(c->fop64.clover_field(), 0.0, c->stream);
@@ -219,6 +228,31 @@ int ddamg_hip_shift_mass(ddamg_hip_ctx* c, double new_m0) {
     c->par.m0 = new_m0;
     DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
   }
+  DDAMG_API_END
+}
+
+// scale_clover + operator_updates (src/dirac.c:624-644, src/dirac_generic.c:465-501; dd_alpha_amg_wilson_solve scales the clover term
+// around a solve, src/dd_alpha_amg.c:354-373): the clover term of both precisions times scale_even / scale_odd by global parity on
+// the device, the 6x6 inverses rebuilt, the coarse operators rebuilt from the interpolation operators that are there.  No host
+// loop, no upload.  (1, 1) restores the unscaled field bit for bit.  The host copy handed out by dd_alpha_amg_get_clover_pointer
+// keeps the unscaled field, as the reference's does after its solve.
+int ddamg_hip_scale_clover(ddamg_hip_ctx* c, double scale_even, double scale_odd) {
+  DDAMG_API_BEGIN
+  DDAMG_REQUIRE(c && c->have_operator, "no operator set");
+  DDAMG_HIP_CHECK(hipSetDevice(c->device));
+  if (scale_even == c->scale_even && scale_odd == c->scale_odd) return 0;
+  const size_t bytes = sizeof(double) * 72 * (size_t)c->levels[0]->geom.V;
+  if (!c->clover_base) {
+    DDAMG_HIP_CHECK(device_alloc(&c->clover_base, bytes));
+    DDAMG_HIP_CHECK(hipMemcpyAsync(c->clover_base, c->fop64.clover_field(), bytes, hipMemcpyDeviceToDevice, c->stream));
+  }
+  c->fop64.scale_clover(c->clover_base, scale_even, scale_odd, c->stream);
+  c->fop32.scale_clover(c->clover_base, scale_even, scale_odd, c->stream);
+  c->scale_even = scale_even; c->scale_odd = scale_odd;
+  if (c->mg32 && c->setup_done) { c->mg32->operator_changed(); c->mg32->release_setup_workspace(); }
+  if (c->mg64 && c->setup_done) { c->mg64->operator_changed(); c->mg64->release_setup_workspace(); }
+  DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
+  if (scale_even == 1.0 && scale_odd == 1.0) { (void)hipFree(c->clover_base); c->clover_base = nullptr; }
   DDAMG_API_END
 }
 

@@ -41,6 +41,9 @@ struct ddamg_hip_ctx {
   // fine operator in the reference's host storage (fp64) + device copies in both precisions
   std::vector<double> D_host, clover_host;
   bool have_operator = false;
+  // scale_clover: unscaled fp64 copy of the clover field on the device while the operator is scaled (ddamg_hip_scale_clover)
+  double* clover_base = nullptr;
+  double scale_even = 1.0, scale_odd = 1.0;
   ddamg::FineOp<float> fop32;
   ddamg::FineOp<double> fop64;
   ddamg::Comm* comm = nullptr;  // halo transport of a decomposed lattice (halo.h)

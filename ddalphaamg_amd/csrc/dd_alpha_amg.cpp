@@ -297,16 +297,11 @@ void scatter_vector(double* user, const std::vector<double>& lex) {
   }
 }
 
-// scale_clover (src/dirac.c:624-644) on a copy; returns true if anything was scaled
-bool scaled_operator(double se, double so, std::vector<double>& cl) {
+// scale_clover + operator_updates around a solve (src/dd_alpha_amg.c:354-373): on the device (ddamg_hip_scale_clover), no host
+// loop over the field and no upload; returns true if anything was scaled
+bool scale_operator(double se, double so) {
   if (se == 1.0 && so == 1.0) return false;
-  const int* L = S.hp.local_lattice[0];
-  cl = S.ctx->clover_host;
-  size_t s = 0;
-  for (int t = 0; t < L[0]; t++) for (int z = 0; z < L[1]; z++) for (int y = 0; y < L[2]; y++) for (int x = 0; x < L[3]; x++, s++) {
-    const double f = ((t + z + y + x + S.ctx->levels[0]->geom.oe_offset) % 2 == 1) ? so : se;   // global parity
-    for (int k = 0; k < 84; k++) cl[s * 84 + k] *= f;
-  }
+  check(ddamg_hip_scale_clover(S.ctx, se, so), "scale_clover");
   return true;
 }
 
@@ -416,17 +411,12 @@ double dd_alpha_amg_wilson_solve(double* vector_out, double* vector_in, double t
   if (!S.inited || !S.conf_set) fatal("dd_alpha_amg_wilson_solve: no configuration set");
   reupload_if_dirty();
   shift_mass_if_needed();
-  std::vector<double> src((size_t)S.V * 24), sol((size_t)S.V * 24), cl;
+  std::vector<double> src((size_t)S.V * 24), sol((size_t)S.V * 24);
   gather_vector(src, vector_in);
-  const bool scaled = scaled_operator(scale_even, scale_odd, cl);
-  std::vector<double> D_keep, cl_keep;
-  if (scaled) {
-    D_keep = S.ctx->D_host; cl_keep = S.ctx->clover_host;
-    check(ddamg_hip_set_operator(S.ctx, D_keep.data(), cl.data()), "scale_clover");
-  }
+  const bool scaled = scale_operator(scale_even, scale_odd);
   int it = 0, cit = 0; double rr = 0;
   check(ddamg_hip_solve(S.ctx, sol.data(), src.data(), tol, &it, &cit, &rr), "dd_alpha_amg_wilson_solve");
-  if (scaled) check(ddamg_hip_set_operator(S.ctx, D_keep.data(), cl_keep.data()), "restore clover");
+  if (scaled) check(ddamg_hip_scale_clover(S.ctx, 1.0, 1.0), "restore clover");
   scatter_vector(vector_out, sol);
   if (S.print > 0 && S.ctx->levels[0]->geom.rank == 0) {
     // what the reference prints per outer iteration with g.print > 0 (src/linsolve_generic.c:322-329) and at the end (:363-374)
@@ -444,16 +434,11 @@ double dd_alpha_amg_wilson_solve(double* vector_out, double* vector_in, double t
 void dd_alpha_amg_preconditioner(double* vector_out, double* vector_in, double scale_even, double scale_odd, int* status) {
   if (!S.inited || !S.setup_done) fatal("dd_alpha_amg_preconditioner: setup has not been run");
   reupload_if_dirty();
-  std::vector<double> src((size_t)S.V * 24), sol((size_t)S.V * 24), cl;
+  std::vector<double> src((size_t)S.V * 24), sol((size_t)S.V * 24);
   gather_vector(src, vector_in);
-  const bool scaled = scaled_operator(scale_even, scale_odd, cl);
-  std::vector<double> D_keep, cl_keep;
-  if (scaled) {
-    D_keep = S.ctx->D_host; cl_keep = S.ctx->clover_host;
-    check(ddamg_hip_set_operator(S.ctx, D_keep.data(), cl.data()), "scale_clover");
-  }
+  const bool scaled = scale_operator(scale_even, scale_odd);
   check(ddamg_hip_preconditioner(S.ctx, sol.data(), src.data()), "dd_alpha_amg_preconditioner");
-  if (scaled) check(ddamg_hip_set_operator(S.ctx, D_keep.data(), cl_keep.data()), "restore clover");
+  if (scaled) check(ddamg_hip_scale_clover(S.ctx, 1.0, 1.0), "restore clover");
   scatter_vector(vector_out, sol);
   if (status) { status[0] = 1; status[1] = S.ctx->last_coarse_iter; }
 }

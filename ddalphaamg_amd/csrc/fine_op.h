@@ -53,6 +53,9 @@ class FineOp {
   // place; the fp32 operator then follows with diff = 0), so both precisions stay what an upload of the shifted field gives.
   void shift_diagonal(const double* clover64, double diff, hipStream_t st);
   const T* clover_field() const { return clover_; }
+  // scale_clover (src/dirac.c:624-644): clover term = base64 (an unscaled fp64 copy of the field, 72 reals per site in this
+  // operator's layout) times scale_even / scale_odd by global parity; the 6x6 inverses follow
+  void scale_clover(const double* base64, double scale_even, double scale_odd, hipStream_t st);
   // eta = D_W phi; with a process grid: pack -> exchange (overlapped with the interior tiles) -> boundary tiles
   void apply(T* eta, const T* phi, hipStream_t st) const;
   FineOpDev<T> dev() const { return FineOpDev<T>{D_, clover_, clover_inv_, nb_, V_, halo_.recv(), halo_.dev(), tile_nb_, tnb_, parity_, Dc_, Dsgn_}; }

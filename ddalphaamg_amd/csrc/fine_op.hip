@@ -623,6 +623,49 @@ void FineOp<T>::shift_diagonal(const double* clover64, double diff, hipStream_t 
   DDAMG_HIP_CHECK(hipGetLastError());
 }
 
+// scale_clover (src/dirac.c:624-644): the clover term of every site times scale_even or scale_odd by the global parity of the
+// site, from an unscaled fp64 copy `base64` (so that scaling by (1, 1) restores the field bit for bit); the inverses of both 6x6
+// blocks rebuilt in fp64 from the scaled blocks
+template <typename T>
+__global__ __launch_bounds__(128) void clover_scale_kernel(T* clover, T* __restrict__ clover_inv, const double* base64, const unsigned char* __restrict__ parity,
+                                                           double scale_even, double scale_odd, int V) {
+  const size_t s = (size_t)blockIdx.x * 128 + threadIdx.x;
+  if (s >= (size_t)V) return;
+  const double f = parity[s] ? scale_odd : scale_even;
+#pragma unroll
+  for (int b = 0; b < 2; b++) {
+    double d[6], ur[15], ui[15], od[6], our[15], oui[15];
+    const int r0 = 36 * b;
+#pragma unroll
+    for (int i = 0; i < 6; i++) d[i] = f * base64[soa_index_dev<double>(72, V, s, r0 + i)];
+#pragma unroll
+    for (int k = 0; k < 15; k++) {
+      ur[k] = f * base64[soa_index_dev<double>(72, V, s, r0 + 6 + 2 * k)];
+      ui[k] = f * base64[soa_index_dev<double>(72, V, s, r0 + 6 + 2 * k + 1)];
+    }
+    invert_herm6(d, ur, ui, od, our, oui);
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+      clover[soa_index_dev<T>(72, V, s, r0 + i)] = (T)d[i];
+      clover_inv[soa_index_dev<T>(72, V, s, r0 + i)] = (T)od[i];
+    }
+#pragma unroll
+    for (int k = 0; k < 15; k++) {
+      clover[soa_index_dev<T>(72, V, s, r0 + 6 + 2 * k)] = (T)ur[k];
+      clover[soa_index_dev<T>(72, V, s, r0 + 6 + 2 * k + 1)] = (T)ui[k];
+      clover_inv[soa_index_dev<T>(72, V, s, r0 + 6 + 2 * k)] = (T)our[k];
+      clover_inv[soa_index_dev<T>(72, V, s, r0 + 6 + 2 * k + 1)] = (T)oui[k];
+    }
+  }
+}
+template <typename T>
+void FineOp<T>::scale_clover(const double* base64, double scale_even, double scale_odd, hipStream_t st) {
+  DDAMG_REQUIRE(clover_ != nullptr && base64 != nullptr && parity_ != nullptr, "scale_clover: no operator uploaded");
+  DDAMG_REQUIRE((const void*)base64 != (const void*)clover_, "scale_clover: the unscaled copy must be a buffer of its own");
+  hipLaunchKernelGGL(clover_scale_kernel<T>, dim3((unsigned)((V_ + 127) / 128)), dim3(128), 0, st, clover_, clover_inv_, base64, parity_, scale_even, scale_odd, (int)V_);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
 // two-row link storage from the reference's links (lexicographic fp64, U/2): rows 0 and 1 in fp32, the sign with which
 // 2 conj(row0 x row1) gives row 2, and -- in *bad -- whether any link is not of that form (then the full storage is used)
 template <typename T>

@@ -99,6 +99,12 @@ int ddamg_hip_set_operator(ddamg_hip_ctx* ctx, const double* D_lex, const double
  * without rebuilding the hierarchy: diagonal updates on the device on every level (shift_update_PRECISION
  * src/dirac_generic.c:504-551) and the inverses the odd-even kernels read.  ddamg_hip_get_operator shows the new clover field. */
 int ddamg_hip_shift_mass(ddamg_hip_ctx* ctx, double new_m0);
+/* scale_clover + operator_updates (src/dirac.c:624-644, src/dirac_generic.c:465-501), as dd_alpha_amg_wilson_solve applies them
+ * around a solve (src/dd_alpha_amg.c:354-373): the clover term of every site times scale_even or scale_odd by the GLOBAL parity of
+ * the site, on the device in both precisions, the 6x6 inverses of the odd-even kernels and the coarse operators following
+ * (Galerkin construction with the interpolation operators that are there).  Scaling is absolute, not cumulative: (1, 1) restores
+ * the unscaled operator bit for bit.  ddamg_hip_get_operator keeps showing the unscaled field. */
+int ddamg_hip_scale_clover(ddamg_hip_ctx* ctx, double scale_even, double scale_odd);
 /* read back the fp64 operator in the reference's storage (for parity tests) */
 int ddamg_hip_get_operator(ddamg_hip_ctx* ctx, double* D_lex, double* clover_lex);
 

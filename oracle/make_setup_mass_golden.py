@@ -53,7 +53,22 @@ def write_inputs(tmp, m0, setup_m0, setup_iter):
 
 
 def parse(out):
-    res = {"residual_history": [float(l.split(":")[1].split("|")[0]) for l in out.splitlines() if "approx. rel. res. after" in l]}
+    # the residual curves are printed by the library in front of the RESULT line of their solve
+    solves, cur = {}, []
+    for l in out.splitlines():
+        if "approx. rel. res. after" in l:
+            cur.append(float(l.split(":")[1].split("|")[0]))
+        m = re.match(r"RESULT (solve|second_solve|scaled_solve|after_scaled_solve) iterations (-?\d+) coarse_iterations (\d+) relres ([0-9.eE+-]+)", l)
+        if m:
+            solves[m.group(1)] = dict(iterations=int(m.group(2)), coarse_iterations=int(m.group(3)), relres=float(m.group(4)), residual_history=cur)
+            cur = []
+    res = {"residual_history": solves.get("solve", {}).get("residual_history", [])}
+    for k in ("scaled_solve", "after_scaled_solve"):
+        if k in solves:
+            res[k] = solves[k]
+    m = re.search(r"RESULT scaled_solution_checksum ([0-9.eE+-]+)", out)
+    if m:
+        res["scaled_solution_checksum"] = float(m.group(1))
     m = re.search(r"RESULT setup_coarse_iterations (\d+)", out); res["setup_coarse_iterations"] = int(m.group(1)) if m else None
     m = re.search(r"RESULT solve iterations (-?\d+) coarse_iterations (\d+) relres ([0-9.eE+-]+)", out)
     if m:
@@ -62,10 +77,12 @@ def parse(out):
     return res
 
 
-def run(exe, mode, m0, setup_m0, setup_iter):
+def run(exe, mode, m0, setup_m0, setup_iter, scale=None):
     with tempfile.TemporaryDirectory() as tmp:
         gauge, ini = write_inputs(tmp, m0, setup_m0, setup_iter)
         cmd = [exe, mode, repr(m0), repr(setup_m0), gauge, str(setup_iter)] + ([ini] if mode == "init" else [])
+        if scale is not None:
+            cmd += ["-", repr(scale[0]), repr(scale[1])]
         r = subprocess.run(cmd, capture_output=True, text=True, cwd=tmp, timeout=600)
         if r.returncode:
             raise RuntimeError(f"{cmd}: exit {r.returncode}\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}")
@@ -75,6 +92,9 @@ def run(exe, mode, m0, setup_m0, setup_iter):
 # init path only: the reference's struct path aborts in validate_parameters (uninitialised g.ncycle[], src/init.c:1034,1084;
 # see tests/mpi/setup_mass_driver.c), so it cannot produce a fixture
 CASES = [("init", -0.5, -0.35, 3), ("init", -0.5, -0.5, 3)]
+# ... and a solve with the clover term scaled by parity around it (scale_even, scale_odd of dd_alpha_amg_wilson_solve:
+# scale_clover + operator_updates, src/dirac.c:624-644, src/dd_alpha_amg.c:354-373), then an unscaled solve again
+SCALED_CASE = ("init", -0.5, -0.5, 3, (1.1, 0.9))
 
 if __name__ == "__main__":
     exe = os.path.join(HERE, "_ref", "setup_mass_driver_ref")
@@ -84,4 +104,8 @@ if __name__ == "__main__":
         res = run(exe, mode, m0, sm0, it)
         res.update(mode=mode, m0=m0, setup_m0=sm0, setup_iter=it)
         print(json.dumps(res)); out["cases"].append(res)
+    mode, m0, sm0, it, scale = SCALED_CASE
+    res = run(exe, mode, m0, sm0, it, scale)
+    res.update(mode=mode, m0=m0, setup_m0=sm0, setup_iter=it, scale_even=scale[0], scale_odd=scale[1])
+    print(json.dumps(res)); out["scaled_case"] = res
     json.dump(out, open(os.path.join(REPO, "tests", "golden", "ref_setup_mass.json"), "w"), indent=1)

@@ -5,12 +5,14 @@
  * (oracle/_ref/setup_mass_driver_ref, built by oracle/Makefile; its output is committed as tests/golden/ref_setup_mass.json)
  * and once against libddamg_hip.so (tests/mpi/setup_mass_driver): the GPU test compares the two outputs.
  *
- *   setup_mass_driver init   m0 setup_m0 gauge.bin setup_iter file.ini [m0_second_solve]
+ *   setup_mass_driver init   m0 setup_m0 gauge.bin setup_iter file.ini [m0_second_solve|- [scale_even scale_odd]]
  *   setup_mass_driver struct m0 setup_m0 gauge.bin setup_iter
  *
  * 4^4 lattice; gauge.bin: 256 x 4 x 18 doubles, lexicographic (t,z,y,x; mu = T,Z,Y,X), boundary sign already applied.
  * init: parameter-file path, setup + solve of b = 1 (the file asks for "print mode: 1", so the library prints the residual
- *   curve); with m0_second_solve a second solve at another mass through dd_alpha_amg_update_parameters (mass_for_next_solve).
+ *   curve); with m0_second_solve a second solve at another mass through dd_alpha_amg_update_parameters (mass_for_next_solve);
+ *   with scale_even scale_odd a solve with the clover term scaled by parity (scale_clover + operator_updates around the solve,
+ *   src/dd_alpha_amg.c:354-373) and one more unscaled solve after it (the operator must be back).
  * struct: the same through the parameter struct (dd_alpha_amg_init_external_threading and the _external_threading setup).
  *   Against the reference itself this mode cannot run: its struct path never sets g.ncycle[] (set_dd_alpha_amg_parameters,
  *   src/init.c:1163-1177), so l->n_cy is read from uninitialised memory (src/init.c:1084) and validate_parameters aborts on
@@ -72,11 +74,21 @@ int main(int argc, char** argv) {
     for (size_t i = 0; i < V * 12; i++) { b[2 * i] = 1.0; b[2 * i + 1] = 0.0; }
     double rr = dd_alpha_amg_wilson_solve(x, b, 1e-10, 1.0, 1.0, status);
     printf("RESULT solve iterations %d coarse_iterations %d relres %.6e\n", status[0], status[1], rr);
-    if (argc > 7) {
+    if (argc > 7 && strcmp(argv[7], "-") != 0) {
       a->solver_mass = atof(argv[7]);
       dd_alpha_amg_update_parameters(a);     /* g.mass_for_next_solve; applied by the next solve */
       rr = dd_alpha_amg_wilson_solve(x, b, 1e-10, 1.0, 1.0, status);
       printf("RESULT second_solve iterations %d coarse_iterations %d relres %.6e\n", status[0], status[1], rr);
+    }
+    if (argc > 9) {
+      const double se = atof(argv[8]), so = atof(argv[9]);
+      for (size_t i = 0; i < V * 24; i++) x[i] = 0.0;
+      rr = dd_alpha_amg_wilson_solve(x, b, 1e-10, se, so, status);
+      printf("RESULT scaled_solve iterations %d coarse_iterations %d relres %.6e\n", status[0], status[1], rr);
+      double cs = 0; for (size_t i = 0; i < V * 24; i++) cs += x[i] * (double)((i * 7919u) % 101 + 1);
+      printf("RESULT scaled_solution_checksum %.10e\n", cs);
+      rr = dd_alpha_amg_wilson_solve(x, b, 1e-10, 1.0, 1.0, status);
+      printf("RESULT after_scaled_solve iterations %d coarse_iterations %d relres %.6e\n", status[0], status[1], rr);
     }
     free(b); free(x);
   }

@@ -144,3 +144,88 @@ def test_mass_shift_of_the_operator_alone_with_and_without_a_clover_term(gold8, 
     assert relerr(a[2], b[2]) < 1e-6 and relerr(a[3], b[3]) < 1e-14 and relerr(a[4], b[4]) < 1e-5
     if csw == 0.0:
         assert np.all(a[1][:, 12:, :] == 0.0) and np.allclose(a[1][:, :12, 0], 4.15)
+
+
+# ---- scale_clover on the device (src/dirac.c:624-644 + operator_updates, as dd_alpha_amg_wilson_solve applies them around a solve) ---------
+def test_scaled_solve_against_the_reference_library(tmp_path):
+    """The reference LIBRARY through its own interface with scale_even = 1.1, scale_odd = 0.9 around a solve (tests/golden/
+    ref_setup_mass.json "scaled_case", oracle/make_setup_mass_golden.py): the same host program on libddamg_hip.so gives the same
+    iteration count and residual curve for the scaled solve (first entry 0.0878 against 0.0851 unscaled), the same solution, and the
+    unscaled solve after it is the one before it -- the operator is back bit for bit."""
+    import make_setup_mass_golden as mk
+    ref = json.load(open(os.path.join(GOLDEN, "ref_setup_mass.json")))["scaled_case"]
+    gauge, ini = mk.write_inputs(str(tmp_path), ref["m0"], ref["setup_m0"], ref["setup_iter"])
+    cmd = [DRIVER, "init", repr(ref["m0"]), repr(ref["setup_m0"]), gauge, str(ref["setup_iter"]), ini, "-", repr(ref["scale_even"]), repr(ref["scale_odd"])]
+    r = subprocess.run(cmd, capture_output=True, text=True, cwd=str(tmp_path), timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = mk.parse(r.stdout)
+    for key in ("scaled_solve", "after_scaled_solve"):
+        g, rf = got[key], ref[key]
+        assert g["iterations"] == rf["iterations"] and g["relres"] < 1e-10, (key, g, rf)
+        h, hr = np.array(g["residual_history"]), np.array(rf["residual_history"])
+        assert len(h) == len(hr) and abs(h[0] / hr[0] - 1.0) < 2e-5 and np.max(np.abs(h / hr - 1.0)) < 3e-2, (key, h, hr)
+        assert abs(g["coarse_iterations"] - rf["coarse_iterations"]) <= 3
+    assert abs(got["scaled_solution_checksum"] / ref["scaled_solution_checksum"] - 1.0) < 1e-8
+    # scaled and unscaled curves differ by 3 % in their first entry: the test tells them apart
+    assert abs(got["scaled_solve"]["residual_history"][0] / got["residual_history"][0] - 1.0) > 0.02
+    # the operator is back: the unscaled solve after the scaled one repeats the one before it digit for digit
+    assert got["after_scaled_solve"]["residual_history"] == got["residual_history"]
+    assert got["after_scaled_solve"]["relres"] == got["relres"]
+
+
+@pytest.mark.parametrize("levels", [2, 3])
+def test_scale_clover_on_the_device_equals_upload_and_rebuild(gold8, levels):
+    """ddamg_hip_scale_clover (parity-masked kernels on both precisions + the coarse Galerkin rebuild) against a context that got the
+    scaled field through a full upload: the same applied operator in both precisions bit for bit, the same coarse operator, the same
+    solve; and scaling back by (1, 1) restores the original operator bit for bit."""
+    L = [8, 8, 8, 8]; V = 4096
+    U = gold8["gauge"]
+    se, so = 1.1, 0.9
+    b = splitmix_uniform(V * 24, 3).reshape(V, 12, 2)
+    phi = splitmix_uniform(V * 24, 4).reshape(V, 12, 2)
+
+    def apply_both(ctx):
+        out = {}
+        for prec in (32, 64):
+            v = ctx.vector(0, prec).upload(phi); w = ctx.vector(0, prec); ctx.dirac_apply(w, v); out[prec] = w.download()
+        return out
+
+    A = dd.Context(hierarchy_params(L, levels, -0.5))
+    A.set_gauge(U, anti_pbc=True)
+    A.setup(2)
+    D0, cl0 = A.get_operator()
+    y0 = apply_both(A)
+    A.scale_clover(se, so)
+    ya = apply_both(A)
+    xa, ita, cita, rra = A.solve(b, 1e-10)
+    hist_a = np.array(A.residual_history())
+    DcA, clcA = A.get_coarse_operator()
+
+    # the scaled field the long way: host loop over the reference's storage, upload, Galerkin construction on every level
+    c = np.indices(L).reshape(4, -1).sum(axis=0) % 2          # lexicographic sites, global parity (one process: no offset)
+    cl_scaled = cl0 * np.where(c == 1, so, se)[:, None, None]
+    B = dd.Context(hierarchy_params(L, levels, -0.5))
+    B.set_gauge(U, anti_pbc=True)
+    B.setup(2)
+    B.set_operator(D0, cl_scaled)
+    yb = apply_both(B)
+    for prec in (32, 64):
+        assert np.array_equal(ya[prec], yb[prec]) and not np.array_equal(ya[prec], y0[prec])
+    xb, itb, citb, rrb = B.solve(b, 1e-10)
+    hist_b = np.array(B.residual_history())
+    DcB, clcB = B.get_coarse_operator()
+    assert np.array_equal(DcA, DcB) and np.array_equal(clcA, clcB)
+    assert ita == itb and cita == citb and max(rra, rrb) < 1e-10 and np.array_equal(hist_a, hist_b)
+    assert relerr(xa, xb) < 1e-12
+    # the true residual of the scaled system, by the oracle
+    from oracle import orc
+    Dh, clh, _ = orc.gauge_to_operator(L, U, 1, -0.5, 1.0)
+    assert relerr(orc.dirac_apply(L, Dh, cl_scaled, xa, 64), b) < 1e-9
+    # and back
+    A.scale_clover(1.0, 1.0)
+    yr = apply_both(A)
+    for prec in (32, 64):
+        assert np.array_equal(yr[prec], y0[prec])
+    _, cl_back = A.get_operator()
+    assert np.array_equal(cl_back, cl0)
+    A.close(); B.close()
