@@ -89,6 +89,7 @@ def load_library():
         "ddamg_hip_set_gauge2": [vp, dp, dp, ctypes.c_int, dp],
         "ddamg_hip_set_operator": [vp, dp, dp],
         "ddamg_hip_shift_mass": [vp, ctypes.c_double],
+        "ddamg_hip_setup_at_mass": [vp, ctypes.c_int, ctypes.c_double, ctypes.POINTER(ctypes.c_int)],
         "ddamg_hip_scale_clover": [vp, ctypes.c_double, ctypes.c_double],
         "ddamg_hip_get_operator": [vp, dp, dp],
         "ddamg_hip_vec_create": [vp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(vp)],

@@ -78,6 +78,9 @@ template <typename T> void vec_minus(T* z, const T* x, const T* y, View v, hipSt
 template <typename T> void vec_plus(T* z, const T* x, const T* y, View v, hipStream_t st);
 // w += sign * sum_{i<m} coef[i] * (X + i*xstride)   coefficients complex fp64 in device memory
 template <typename T> void vec_multi_axpy_dev(T* w, const T* X, size_t xstride, int m, const double* d_coef, double sign, View v, hipStream_t st);
+// the same with an fp64 w (V sites, nreal reals per site, its layout) and fp32 vectors X (theirs): the solution update of the outer
+// solver from the fp32 iterates of the V-cycle, x += sum_i y_i Z_i with the products and sums in fp64
+void vec_multi_axpy_f32basis(double* w, const float* X, size_t xstride, int m, const double* d_coef, double sign, size_t V, int nreal, hipStream_t st);
 // d_out[2i..2i+1] = < X+i*xstride , w >  for i<m  (conjugate-linear in the first argument)
 // local_only: leave the sum over the processes to the caller (comm_allreduce_begin / _end around other work)
 template <typename T> void vec_multi_dot(const T* X, size_t xstride, int m, const T* w, View v, ReduceWork& rw, double* d_out, hipStream_t st, bool local_only = false);

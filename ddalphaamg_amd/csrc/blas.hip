@@ -235,6 +235,31 @@ void vec_multi_axpy_dev(T* w, const T* X, size_t xstride, int m, const double* d
   DDAMG_HIP_CHECK(hipGetLastError());
 }
 
+// fp64 w, fp32 vectors: one thread per (site, float4 chunk) = two double2 chunks of w
+__global__ __launch_bounds__(BLK) void multi_axpy_f32basis_kernel(double* __restrict__ w, const float* __restrict__ X, size_t xstride, int m,
+                                                                  const double* __restrict__ coef, double sign, size_t V, int nchunk4) {
+  const size_t total = V * (size_t)nchunk4;
+  for (size_t c = (size_t)blockIdx.x * BLK + threadIdx.x; c < total; c += (size_t)gridDim.x * BLK) {
+    const size_t k = c / V, s = c - k * V;
+    double2* w0 = reinterpret_cast<double2*>(w + ((2 * k) * V + s) * 2);
+    double2* w1 = reinterpret_cast<double2*>(w + ((2 * k + 1) * V + s) * 2);
+    double2 a = *w0, b = *w1;
+    for (int i = 0; i < m; i++) {
+      const double cr = sign * coef[2 * i], ci = sign * coef[2 * i + 1];
+      const float4 x = *reinterpret_cast<const float4*>(X + (size_t)i * xstride + c * 4);
+      a.x += cr * (double)x.x - ci * (double)x.y; a.y += cr * (double)x.y + ci * (double)x.x;
+      b.x += cr * (double)x.z - ci * (double)x.w; b.y += cr * (double)x.w + ci * (double)x.z;
+    }
+    *w0 = a; *w1 = b;
+  }
+}
+void vec_multi_axpy_f32basis(double* w, const float* X, size_t xstride, int m, const double* d_coef, double sign, size_t V, int nreal, hipStream_t st) {
+  if (m <= 0 || V == 0) return;
+  DDAMG_REQUIRE(nreal % 4 == 0, "mixed multi-axpy: reals per site must be a multiple of 4");
+  hipLaunchKernelGGL(multi_axpy_f32basis_kernel, dim3(grid_for(V * (size_t)(nreal / 4))), dim3(BLK), 0, st, w, X, xstride, m, d_coef, sign, V, nreal / 4);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
 // ---- reductions -----------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double x) {
 #pragma unroll

@@ -48,7 +48,10 @@ class CoarseOp {
   void import_reference(const Geometry& g, const double* D_ref, const double* clover_ref, hipStream_t st);
   void export_reference(const Geometry& g, double* D_ref, double* clover_ref, hipStream_t st) const;
   void compute_self_inverse(hipStream_t st);  // Minv = M[0]^-1 on every site
-  void shift_diagonal(double diff, hipStream_t st);   // M[0] += diff * 1 on every site (mass shift; the caller redoes the inverse)
+  // M[0] += diff * 1 on every site (mass shift; the caller redoes the inverse).  Shifts are kept as ONE accumulated fp64 number on top
+  // of the diagonal as the last construction left it: a shift there and back returns the matrices bit for bit, however often an
+  // HMC stream repeats it (adding and subtracting fp32 numbers in place would let the diagonals random-walk)
+  void shift_diagonal(double diff, hipStream_t st);
   CoarseOpDev<T> dev() const {
     CoarseOpDev<T> d{M_, Minv_, nb_, V_, n_, nt_, msize_, reinterpret_cast<const T*>(arena_.recv()), {0, 0, 0, 0, 0, 0, 0, 0}};
     for (int k = 0; k < 8; k++) d.hoff[k] = arena_.site_offset(k) * n_ * 2;
@@ -106,6 +109,9 @@ class CoarseOp {
   int* nb_ = nullptr;
   int V_ = 0, n_ = 0, nt_ = 0;
   unsigned version_ = 0;
+  T* diag_base_ = nullptr;          // [V][n] the self couplings' diagonal (real parts) before any shift
+  unsigned diag_base_version_ = 0;  // version_ the base belongs to (0: none)
+  double shift_total_ = 0.0;
   size_t msize_ = 0;
   mutable HaloArena arena_;
   mutable HaloArena wide_arena_;      // created at the first wide_halo_exchange

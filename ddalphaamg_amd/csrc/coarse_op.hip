@@ -711,18 +711,25 @@ void CoarseOp<T>::compute_self_inverse(hipStream_t st) {
 // mass shift on a coarse level: P^H P = 1 on every aggregate and chirality, so P^H (D + d) P = D_c + d -- the self coupling
 // of every site gets d on its diagonal (shift_update_PRECISION, depth > 0 branch, src/dirac_generic.c:528-546)
 template <typename T>
-__global__ void shift_self_diagonal_kernel(T* __restrict__ M, int V, int n, int nt, size_t msize, T diff) {
+__global__ void shift_self_diagonal_kernel(T* __restrict__ M, T* __restrict__ base, int V, int n, int nt, size_t msize, T total, int capture) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (size_t)V * n) return;
   const size_t s = i / n; const int d = (int)(i % n);
-  M[(s * 5 * msize + (size_t)((d >> 3) * nt + (d >> 3)) * 64 + (d & 7) * 9) * 2] += diff;
+  T* m = M + (s * 5 * msize + (size_t)((d >> 3) * nt + (d >> 3)) * 64 + (d & 7) * 9) * 2;
+  if (capture) base[i] = m[0];
+  m[0] = base[i] + total;
 }
 template <typename T>
 void CoarseOp<T>::shift_diagonal(double diff, hipStream_t st) {
-  version_++;
   const size_t tot = (size_t)V_ * n_;
-  hipLaunchKernelGGL(shift_self_diagonal_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, M_, V_, n_, nt_, msize_, (T)diff);
+  const bool capture = diag_base_ == nullptr || diag_base_version_ != version_;    // the couplings were rewritten since the last shift
+  if (!diag_base_) DDAMG_HIP_CHECK(device_alloc(&diag_base_, sizeof(T) * tot));
+  if (capture) shift_total_ = 0.0;
+  shift_total_ += diff;
+  hipLaunchKernelGGL(shift_self_diagonal_kernel<T>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, M_, diag_base_, V_, n_, nt_, msize_, (T)shift_total_, capture ? 1 : 0);
   DDAMG_HIP_CHECK(hipGetLastError());
+  version_++;
+  diag_base_version_ = version_;
 }
 
 // ---- allocation / import / export ---------------------------------------------------------------
@@ -730,6 +737,7 @@ template <typename T> CoarseOp<T>::~CoarseOp() {
   if (M_) (void)hipFree(M_);
   if (Minv_) (void)hipFree(Minv_);
   if (bwd_) (void)hipFree(bwd_);
+  if (diag_base_) (void)hipFree(diag_base_);
   if (nb_) (void)hipFree(nb_);
   if (d_interior_) (void)hipFree(d_interior_);
   if (d_boundary_) (void)hipFree(d_boundary_);

@@ -264,8 +264,8 @@ void run_setup(int iterations, int* status) {
   if (!S.conf_set) fatal("dd_alpha_amg_setup: no configuration set");
   reupload_if_dirty();
   int ci = 0;
-  check(ddamg_hip_setup(S.ctx, 0, &ci), "dd_alpha_amg_setup");            // method_setup
-  ci += iterative_setup_at_setup_mass(iterations);                         // method_update
+  if (S.hp.method <= 0 || S.hp.method == 5 || S.hp.num_levels < 2) check(ddamg_hip_setup(S.ctx, 0, &ci), "dd_alpha_amg_setup");
+  else check(ddamg_hip_setup_at_mass(S.ctx, iterations > 0 ? iterations : 0, S.setup_m0, &ci), "dd_alpha_amg_setup");   // method_setup + method_update, one workspace
   S.setup_done = true;
   S.status.gauge_updates_since_last_setup = 0;
   S.status.gauge_updates_since_last_setup_update = 0;

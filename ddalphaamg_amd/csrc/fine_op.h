@@ -61,6 +61,8 @@ class FineOp {
   FineOpDev<T> dev() const { return FineOpDev<T>{D_, clover_, clover_inv_, nb_, V_, halo_.recv(), halo_.dev(), tile_nb_, tnb_, parity_, Dc_, Dsgn_}; }
   bool links_compressed() const { return Dc_ != nullptr; }
   int V() const { return V_; }
+  // the fp64 operator on an fp32 input vector (converted in the loads); false where that form is not built
+  bool apply_f32in(T* eta, const float* phi, hipStream_t st) const;
   void set_comm(Comm* c) { comm_ = c; }
   // fill the receive arena with the boundary half spinors of `v` (for kernels other than apply() that couple
   // to off-process neighbours through FineOpDev::halo: Schwarz residual updates, Galerkin products)

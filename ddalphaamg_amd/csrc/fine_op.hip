@@ -93,14 +93,27 @@ __device__ __forceinline__ int tile_neighbor(const int* __restrict__ nb, size_t 
   }
 }
 
+// a site of an input vector of another precision (its own chunked layout), converted on the way in: the fp64 operator on the
+// fp32 iterates the V-cycle hands to the outer solver (FineOp<double>::apply_f32in)
+template <typename T, typename TIN, int NR>
+__device__ __forceinline__ void load_site_as(const TIN* __restrict__ base, size_t V, size_t s, T (&out)[NR]) {
+  if constexpr (sizeof(T) == sizeof(TIN)) load_site<T, NR>(reinterpret_cast<const T*>(base), V, s, out);
+  else {
+    TIN tmp[NR];
+    load_site<TIN, NR>(base, V, s, tmp);
+#pragma unroll
+    for (int k = 0; k < NR; k++) out[k] = (T)tmp[k];
+  }
+}
+
 #ifdef DDAMG_FACE_DIAG
 // diagnostic build only (tools/gpu/facediag.sh: what the couplings that leave a tile cost, per direction):
 // bit mu = forward, bit 4+mu = backward coupling across the tile face is computed
 __device__ int g_face_mask = 0xff;
 #endif
 
-template <typename T, int MU, bool ARITH, bool DEFER, bool CMP, bool HB2>
-__device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOpDev<T>& op, size_t s, bool live, int tile0, const uint4& q,
+template <typename T, int MU, bool ARITH, bool DEFER, bool CMP, bool HB2, typename TIN = T>
+__device__ __forceinline__ void tile_dir(const TIN* __restrict__ phi, const FineOpDev<T>& op, size_t s, bool live, int tile0, const uint4& q,
                                          const T (&p)[24], T (&e)[24], T* __restrict__ sp, T* __restrict__ hb) {
   const size_t V = op.V;
   const int t = threadIdx.x;
@@ -128,7 +141,7 @@ __device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOp
         take = (g_face_mask >> MU & 1) != 0;
         if (take)
 #endif
-        load_site<T, 24>(phi, V, j, pn);
+        load_site_as<T, TIN, 24>(phi, V, j, pn);
       }
       if (take) hop_accumulate<T, MU, true>(U, pn, e);
     } else {
@@ -152,7 +165,7 @@ __device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOp
 #endif
     {
       T pn[24], Un[18];
-      load_site<T, 24>(phi, V, j, pn);
+      load_site_as<T, TIN, 24>(phi, V, j, pn);
       load_link<T, MU, CMP>(op, V, (size_t)j, Un);
       hop_accumulate<T, MU, false>(Un, pn, e);
     }
@@ -160,8 +173,8 @@ __device__ __forceinline__ void tile_dir(const T* __restrict__ phi, const FineOp
   if constexpr (!HB2) __syncthreads();   // HB2: the caller alternates between two hb buffers, one barrier per direction
 }
 
-template <typename T, bool ARITH, bool DEFER, bool CMP = false>
-__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) void dirac_apply_lds_kernel(T* __restrict__ eta, const T* __restrict__ phi, FineOpDev<T> op, int ntiles,
+template <typename T, bool ARITH, bool DEFER, bool CMP = false, typename TIN = T>
+__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) void dirac_apply_lds_kernel(T* __restrict__ eta, const TIN* __restrict__ phi, FineOpDev<T> op, int ntiles,
                                                                   const int* __restrict__ tile_list) {
   // fp32: two buffers for the backward products, used in turn, so that one barrier per direction is enough (48 KB of LDS,
   // three workgroups per CU as before); fp64 keeps one buffer and two barriers (its tile already takes 72 KB)
@@ -181,7 +194,7 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) void dirac_apply_lds
   T p[24], e[24];
   uint4 q = make_uint4(0, 0, 0, 0);
   if constexpr (ARITH) q = reinterpret_cast<const uint4*>(op.tnb)[threadIdx.x];
-  if (live) load_site<T, 24>(phi, V, s, p);
+  if (live) load_site_as<T, TIN, 24>(phi, V, s, p);
   else {
 #pragma unroll
     for (int k = 0; k < 24; k++) p[k] = 0;
@@ -196,10 +209,10 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) void dirac_apply_lds
     herm6_mul<T>(cl, p + 12, e + 12);
   }
   __syncthreads();
-  tile_dir<T, 0, ARITH, DEFER, CMP, HB2>(phi, op, s, live, tile0, q, p, e, sp, hb);
-  tile_dir<T, 1, ARITH, DEFER, CMP, HB2>(phi, op, s, live, tile0, q, p, e, sp, hb1);
-  tile_dir<T, 2, ARITH, DEFER, CMP, HB2>(phi, op, s, live, tile0, q, p, e, sp, hb);
-  tile_dir<T, 3, ARITH, DEFER, CMP, HB2>(phi, op, s, live, tile0, q, p, e, sp, hb1);
+  tile_dir<T, 0, ARITH, DEFER, CMP, HB2, TIN>(phi, op, s, live, tile0, q, p, e, sp, hb);
+  tile_dir<T, 1, ARITH, DEFER, CMP, HB2, TIN>(phi, op, s, live, tile0, q, p, e, sp, hb1);
+  tile_dir<T, 2, ARITH, DEFER, CMP, HB2, TIN>(phi, op, s, live, tile0, q, p, e, sp, hb);
+  tile_dir<T, 3, ARITH, DEFER, CMP, HB2, TIN>(phi, op, s, live, tile0, q, p, e, sp, hb1);
   if (live) store_site<T, 24, DDAMG_NT_STORE>(eta, V, s, e);
 }
 
@@ -390,6 +403,26 @@ void FineOp<T>::apply(T* eta, const T* phi, hipStream_t st) const {
   launch(halo_.n_interior(), halo_.interior_tiles());
   halo_.exchange_finish(comm_, st);
   launch(halo_.n_boundary(), halo_.boundary_tiles());
+}
+
+// eta = D phi with phi an fp32 vector (its own layout): the fp64 operator of the outer solver on the iterates that come out of the
+// fp32 V-cycle (fgmres_double + preconditioner(), src/linsolve_generic.c:219-413, src/preconditioner.c:25-69, where the iterate is
+// converted first) -- the conversion happens in the loads, the result is the one of apply() on the converted vector bit for bit.
+// false where this form is not built (a process grid, the gather variant): the caller converts and calls apply().
+template <typename T>
+bool FineOp<T>::apply_f32in(T* eta, const float* phi, hipStream_t st) const {
+  if constexpr (sizeof(T) == 8) {
+    DDAMG_REQUIRE(D_ != nullptr, "fine operator not uploaded");
+    if (g_dirac_variant < 0) { const char* e = getenv("DDAMG_DIRAC_VARIANT"); g_dirac_variant = e ? atoi(e) : 1; }
+    if (halo_.active() || g_dirac_variant == 0) return false;
+    const int ntiles = (V_ + 255) / 256;
+    if (tnb_ && g_dirac_variant != 4 && Dc_) hipLaunchKernelGGL((dirac_apply_lds_kernel<T, true, false, true, float>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, (const int*)nullptr);
+    else if (tnb_ && g_dirac_variant != 4) hipLaunchKernelGGL((dirac_apply_lds_kernel<T, true, false, false, float>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, (const int*)nullptr);
+    else hipLaunchKernelGGL((dirac_apply_lds_kernel<T, false, false, false, float>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, (const int*)nullptr);
+    DDAMG_HIP_CHECK(hipGetLastError());
+    return true;
+  }
+  return false;
 }
 
 template <typename T>

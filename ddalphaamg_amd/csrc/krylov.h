@@ -43,6 +43,17 @@ struct Gmres {
   // the global sum of step k travels while the operator is applied for step k+1.  Needs the Z vectors (alloc with_Z) and
   // one more of them; set by the owner before alloc.
   bool pipelined = false;
+  // The iterates Z_j of a right-preconditioned solve in fp32 where the preconditioner works in fp32 anyway (the fp64 outer
+  // solver around the fp32 V-cycle, fgmres_double + preconditioner() src/preconditioner.c:25-69: the reference converts the
+  // V-cycle's result to fp64 and keeps THAT): nothing is lost -- fp32 numbers are fp64 numbers -- the conversion pass and half of
+  // the basis' memory and traffic go.  prec32 writes Z_j in fp32, op32 applies the fp64 operator to it (conversion in its
+  // loads), the solution update reads the fp32 vectors with fp64 arithmetic.  Set by the owner before alloc (z_fp32) / solve.
+  bool z_fp32 = false;
+  float* Zb32 = nullptr;
+  std::function<void(float* z, const T* v, int res)> prec32;
+  std::function<void(T* out, const float* z)> op32;
+  size_t sites32 = 0; int nreal32 = 0;      // shape of the vectors (fp32 and fp64 chunk layouts differ)
+  float* Z32(int i) const { return Zb32 + vstride * i; }
   // storage (owned)
   T* slab = nullptr;
   T *x = nullptr, *b = nullptr, *r = nullptr, *w = nullptr, *Vb = nullptr, *Zb = nullptr;
@@ -57,24 +68,30 @@ struct Gmres {
     vec_elems = vec_elems_;
     restart_length = restart_length_;
     vstride = (vec_elems + 63) / 64 * 64;
-    size_t nvec = 4 + (restart_length + 1) + (with_Z ? restart_length + 2 : 0);
+    const bool z64 = with_Z && !z_fp32;
+    size_t nvec = 4 + (restart_length + 1) + (z64 ? restart_length + 2 : 0);
     DDAMG_HIP_CHECK(device_alloc(&slab, sizeof(T) * vstride * nvec));
     DDAMG_HIP_CHECK(device_zero(slab, sizeof(T) * vstride * nvec));
     x = slab; b = x + vstride; r = b + vstride; w = r + vstride;
     Vb = w + vstride;
-    Zb = with_Z ? Vb + vstride * (restart_length + 1) : nullptr;
+    Zb = z64 ? Vb + vstride * (restart_length + 1) : nullptr;
+    if (with_Z && z_fp32) {
+      DDAMG_HIP_CHECK(device_alloc(&Zb32, sizeof(float) * vstride * (restart_length + 2)));
+      DDAMG_HIP_CHECK(device_zero(Zb32, sizeof(float) * vstride * (restart_length + 2)));
+    }
     H.assign((size_t)(restart_length + 1) * (restart_length + 2), cd(0));
     y.assign(restart_length + 2, cd(0)); gamma.assign(restart_length + 2, cd(0));
     c.assign(restart_length + 2, cd(0)); s.assign(restart_length + 2, cd(0));
   }
-  void release() { if (slab) (void)hipFree(slab); slab = nullptr; }
+  void release() { if (slab) (void)hipFree(slab); slab = nullptr; if (Zb32) (void)hipFree(Zb32); Zb32 = nullptr; }
   T* V(int i) const { return Vb + vstride * i; }
   T* Z(int i) const { return Zb + vstride * i; }
 
   int solve() {
     DDAMG_REQUIRE(slab && rw && op, "gmres not set up");
     DDAMG_REQUIRE(restart_length + 2 <= rw->max_m, "reduction workspace too small for this restart length");
-    const bool right = (bool)prec;
+    DDAMG_REQUIRE(!Zb32 || (prec32 && op32 && !pipelined && !prec_gives_Dphi && sites32 > 0), "gmres: fp32 iterates need prec32 / op32 and the vector shape");
+    const bool right = (bool)prec || Zb32 != nullptr;
     int j = -1, finish = 0, res;
     iter = 0; norm_r0 = 1; gamma_jp1 = 1;
     history.clear();
@@ -115,7 +132,7 @@ struct Gmres {
           break;
         }
       }
-      compute_solution(right ? Zb : Vb, j, (res == NO_RES) ? ol : 1);
+      compute_solution(right && !Zb32 ? Zb : Vb, j, (res == NO_RES) ? ol : 1);
     }
     return iter;
   }
@@ -135,7 +152,10 @@ struct Gmres {
 
   bool arnoldi_step(int j, bool right) {
     T* w = single_allreduce ? V(j + 1) : this->w;      // the reference builds w in place in V[j+1] there
-    if (right) {
+    if (Zb32) {
+      prec32(Z32(j), V(j), NO_RES);
+      op32(w, Z32(j));
+    } else if (right) {
       if (prec_gives_Dphi) {
         prec(Z(j), w, V(j), NO_RES);
       } else {
@@ -225,6 +245,9 @@ struct Gmres {
     // here, and the solution update overlaps with whatever the caller enqueues next.
     upload_coefficients(*rw, 2 * (j + 1), st);
     if (!ol) vec_zero<T>(x, view, st);
+    if constexpr (sizeof(T) == 8) {
+      if (Zb32) { vec_multi_axpy_f32basis(x, Zb32, vstride, j + 1, rw->d_coef, 1.0, sites32, nreal32, st); return; }
+    }
     vec_multi_axpy_dev<T>(x, basis, vstride, j + 1, rw->d_coef, 1.0, view, st);
   }
 };

@@ -848,6 +848,7 @@ void Multigrid<T>::release_setup_workspace() {
 
 template <typename T>
 void Multigrid<T>::re_setup(int l) {
+  if (l == 0) p_orthonormal_ = true;    // every level's interpolation operator is orthonormalised again below
   if (lv_[l]->coarsest) return;
   const double t0 = tick(nullptr, 0);
   orthonormalize(l);
@@ -863,6 +864,7 @@ template <typename T>
 void Multigrid<T>::initial_setup_from(int l0) {
   // method_setup -> next_level_setup -> interpolation_PRECISION_define -> coarse_grid_correction_PRECISION_setup
   const int L = num_levels();
+  if (l0 == 0) p_orthonormal_ = true;
   for (int l = l0; l + 1 < L; l++) {
     MGLevel<T>& lv = *lv_[l];
     if (l > 0) {
@@ -1034,6 +1036,11 @@ void Multigrid<T>::operator_changed() {
 // is done here without touching P: diagonal kernels and the inverses of the self couplings where a solver reads them.
 template <typename T>
 void Multigrid<T>::mass_shifted(double diff) {
+  if (!p_orthonormal_) {
+    // interpolation vectors imported as they are: P^H (D + d) P is not D_c + d -- the reference's way, the Galerkin construction
+    operator_changed();
+    return;
+  }
   for (int l = 1; l < num_levels(); l++) {
     MGLevel<T>& lv = *lv_[l];
     lv.cop.shift_diagonal(diff, st_);
@@ -1061,6 +1068,7 @@ void Multigrid<T>::import_interpolation(const double* P_lex_host) {
     vec_from_lex<T>(lv.fip.interp_vector(k), d_stage_, d_lex0_, lv.g->V, 12, st_);
     DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
   }
+  p_orthonormal_ = false;  // "as they are": the caller's vectors need not be orthonormal on the aggregates
   build_coarse_operator(0);
   initial_setup_from(1);   // deeper levels get their own initial setup on the new level-1 operator
 }
@@ -1080,6 +1088,7 @@ void Multigrid<T>::import_interpolation_level(int l, const double* P_lex_host) {
     DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
   }
   DDAMG_HIP_CHECK(hipFree(d_lex));
+  p_orthonormal_ = false;
   build_coarse_operator(l);
   initial_setup_from(l + 1);
 }

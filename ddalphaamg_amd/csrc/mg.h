@@ -137,6 +137,7 @@ class Multigrid {
  private:
   double tick(const char* phase, double t0);
   std::vector<std::unique_ptr<MGLevel<T>>> lv_;
+  bool p_orthonormal_ = true;   // false after interpolation vectors were imported as they are: then P^H P = 1 cannot be assumed
   int* d_lex0_ = nullptr;
   int* d_identity0_ = nullptr;
   double* d_stage_ = nullptr;

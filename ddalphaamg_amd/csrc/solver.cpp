@@ -44,6 +44,13 @@ static void ensure_outer(ddamg_hip_ctx* c) {
   if (c->outer_ready) return;
   const size_t n = (size_t)24 * c->levels[0]->geom.V;
   c->rw_outer.init(c->par.restart + 4);
+  // mixed precision 1 with a multigrid preconditioner on one process: the iterates Z_j of the outer FGMRES stay in fp32, as the
+  // V-cycle leaves them (Gmres::z_fp32); DDAMG_OUTER_Z_FP64 keeps the converted fp64 copies of rounds 1-3
+  {
+    const char* dv = getenv("DDAMG_DIRAC_VARIANT");
+    c->outer.z_fp32 = c->par.method >= 1 && c->par.method <= 4 && c->par.mixed_precision == 1 && !c->levels[0]->geom.distributed() &&
+                      !(dv && atoi(dv) == 0) && getenv("DDAMG_OUTER_Z_FP64") == nullptr;
+  }
   // pure CGN keeps its 8 vectors in a 4-vector Krylov structure, as the reference does (src/init.c:178-180)
   c->outer.alloc(n, c->par.method == -1 ? 4 : c->par.restart, c->par.method > 0);
   c->outer.num_restart = c->par.max_restart;
@@ -86,6 +93,16 @@ static void ensure_outer(ddamg_hip_ctx* c) {
         c->mg32->vcycle(0, c->p32_out, nullptr, c->p32_in, res);
         vec_convert<double, float>(phi, c->p32_out, V, 24, c->stream);
       };
+      if (c->outer.z_fp32) {
+        c->outer.sites32 = c->levels[0]->geom.V; c->outer.nreal32 = 24;
+        c->outer.prec32 = [c](float* z, const double* eta, int res) {
+          vec_convert<float, double>(c->p32_in, eta, c->levels[0]->geom.V, 24, c->stream);
+          c->mg32->vcycle(0, z, nullptr, c->p32_in, res);
+        };
+        c->outer.op32 = [c](double* out, const float* z) {
+          DDAMG_REQUIRE(c->fop64.apply_f32in(out, z, c->stream), "outer solver: the fp64 operator on fp32 input is not available in this configuration");
+        };
+      }
     }
   }
   c->outer_ready = true;
@@ -235,7 +252,13 @@ static int solve_mp(ddamg_hip_ctx* c, double tol, double* relres) {
 
 extern "C" {
 
-int ddamg_hip_setup(ddamg_hip_ctx* c, int setup_iterations, int* coarse_iterations) {
+static int setup_impl(ddamg_hip_ctx* c, int setup_iterations, int* coarse_iterations, const double* setup_m0);
+int ddamg_hip_setup(ddamg_hip_ctx* c, int setup_iterations, int* coarse_iterations) { return setup_impl(c, setup_iterations, coarse_iterations, nullptr); }
+int ddamg_hip_setup_at_mass(ddamg_hip_ctx* c, int setup_iterations, double setup_m0, int* coarse_iterations) { return setup_impl(c, setup_iterations, coarse_iterations, &setup_m0); }
+
+// method_setup, then -- on the operator shifted to *setup_m0 where that is given and differs (method_update, src/init.c:326-357) --
+// the iterative setup, then the solver mass again; ONE lifetime of the setup workspace around all of it
+static int setup_impl(ddamg_hip_ctx* c, int setup_iterations, int* coarse_iterations, const double* setup_m0) {
   DDAMG_API_BEGIN
   DDAMG_REQUIRE(c, "null context");
   DDAMG_HIP_CHECK(hipSetDevice(c->device));
@@ -250,9 +273,14 @@ int ddamg_hip_setup(ddamg_hip_ctx* c, int setup_iterations, int* coarse_iteratio
   DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
   const double t_hier = wall() - t_h0;
   const int iters = setup_iterations < 0 ? c->par.setup_iter[0] : setup_iterations;
-  if (c->mg32) { c->mg32->coarse_iter_count = 0; c->mg32->initial_setup(); c->mg32->iterative_setup(iters); if (coarse_iterations) *coarse_iterations = c->mg32->coarse_iter_count; }
-  else { c->mg64->coarse_iter_count = 0; c->mg64->initial_setup(); c->mg64->iterative_setup(iters); if (coarse_iterations) *coarse_iterations = c->mg64->coarse_iter_count; }
-  c->setup_done = true;
+  const double solver_m0 = c->par.m0;
+  const bool other_mass = setup_m0 != nullptr && *setup_m0 != solver_m0 && iters > 0;
+  if (c->mg32) { c->mg32->coarse_iter_count = 0; c->mg32->initial_setup(); } else { c->mg64->coarse_iter_count = 0; c->mg64->initial_setup(); }
+  c->setup_done = true;       // the hierarchy exists: the mass shift below reaches every level
+  if (other_mass && ddamg_hip_shift_mass(c, *setup_m0)) throw std::runtime_error(g_ddamg_last_error);
+  if (c->mg32) c->mg32->iterative_setup(iters); else c->mg64->iterative_setup(iters);
+  if (other_mass && ddamg_hip_shift_mass(c, solver_m0)) throw std::runtime_error(g_ddamg_last_error);
+  if (coarse_iterations) *coarse_iterations = c->mg32 ? c->mg32->coarse_iter_count : c->mg64->coarse_iter_count;
   const double t_r0 = wall();
   if (c->mg32) c->mg32->release_setup_workspace(); else c->mg64->release_setup_workspace();
   const double t_rel = wall() - t_r0;

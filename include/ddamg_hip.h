@@ -131,6 +131,9 @@ int ddamg_hip_vec_dot(ddamg_hip_ctx* ctx, const ddamg_hip_vec* x, const ddamg_hi
  * Gram-Schmidt -> Galerkin coarse operator, then `setup_iterations` bootstrap iterations
  * (inv_iter_inv_fcycle, src/setup_generic.c:441-503).  setup_iterations < 0: use params.setup_iter[0]. */
 int ddamg_hip_setup(ddamg_hip_ctx* ctx, int setup_iterations, int* coarse_iterations);
+/* the same with the iterative phase on the operator shifted to setup_m0 and back (method_setup at the solver mass, method_update at
+ * g.setup_m0: src/init.c:134-374,326-357; dd_alpha_amg_par::setup_m0), in ONE lifetime of the setup workspace */
+int ddamg_hip_setup_at_mass(ddamg_hip_ctx* ctx, int setup_iterations, double setup_m0, int* coarse_iterations);
 /* replaces method_update / dd_alpha_amg_setup_update (src/dd_alpha_amg.c:288-310) */
 int ddamg_hip_setup_update(ddamg_hip_ctx* ctx, int iterations, int* coarse_iterations);
 /* replaces the "interpolation: 4" path (test vectors from outside, src/setup_generic.c:131-160 + re_setup :278-321):

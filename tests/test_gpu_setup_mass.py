@@ -76,6 +76,7 @@ def test_mass_shift_on_the_device_equals_upload_and_rebuild(gold8, levels):
     A.set_gauge(U, anti_pbc=True)
     A.setup(2)
     D0, cl0 = A.get_operator()
+    coarse0 = [A.get_coarse_operator(level=l) for l in range(1, levels)]
     A.shift_mass(m_b)                      # device: diagonals of every level
     DA, clA = A.get_operator()
     cl_expect = cl0.copy(); cl_expect[:, :12, 0] += m_b - m_a
@@ -107,6 +108,13 @@ def test_mass_shift_on_the_device_equals_upload_and_rebuild(gold8, levels):
     A.shift_mass(m_a)
     _, cl_back = A.get_operator()
     assert np.max(np.abs(cl_back - cl0)) < 1e-15
+    # ... and bit for bit on every coarse level, however often the shift is repeated (an HMC stream shifts to the setup mass and back at
+    # every setup update): the shifts are one accumulated fp64 number on top of the diagonal the Galerkin construction left
+    for _ in range(3):
+        A.shift_mass(-0.37); A.shift_mass(m_a)
+    for l in range(1, levels):
+        Dl, cll = A.get_coarse_operator(level=l)
+        assert np.array_equal(Dl, coarse0[l - 1][0]) and np.array_equal(cll, coarse0[l - 1][1]), l
     A.close(); B.close()
 
 
