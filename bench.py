@@ -282,7 +282,7 @@ def kernel_source_hash():
 
 def mfma_source_hash():
     h = hashlib.sha256()
-    for f in ("coarse_lockstep.hip", "coarse_lockstep.h", "coarse_batch.hip", "coarse_op.h", "transfer.hip"):
+    for f in ("coarse_lockstep.hip", "coarse_lockstep.h", "coarse_multi.hip", "coarse_multi.h", "mfma_tile.h", "coarse_batch.hip", "coarse_op.h", "transfer.hip"):
         h.update(open(os.path.join(REPO, "ddalphaamg_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
@@ -291,7 +291,7 @@ def pmc_traffic(precision):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes (2*FETCH_SIZE + WRITE_SIZE,
     calibrated as MI355X_MICROARCH.md prescribes).  The file records the hash of the kernel sources it was measured on; when
     the kernel has changed since, the number is stale and null is reported instead."""
-    for name in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):
         try:
             d = json.load(open(os.path.join(REPO, "profiles", name)))
             e = d["dirac_apply_lds_kernel<float>"]
@@ -313,7 +313,7 @@ def coarse_operator_report():
     MFMA figures carry the hash of the kernel sources they were measured on and are reported as null once those changed."""
     import csv
     out = {}
-    for R in ("r03", "r02"):
+    for R in ("r04", "r03", "r02"):
         try:
             rows = list(csv.DictReader(open(os.path.join(REPO, "profiles", R + "_solve32_kernel_stats.csv"))))
             r = [x for x in rows if "coarse_site_kernel<float, 6, 1>" in x["Name"]][0]     # <T, n/8, MODE_HOP>
@@ -326,8 +326,11 @@ def coarse_operator_report():
             break
         except Exception:
             continue
-    try:
-        d = json.load(open(os.path.join(REPO, "profiles", "r03_mfma_busy.json")))
+    for name in ("r04_mfma_busy.json", "r03_mfma_busy.json"):
+        try:
+            d = json.load(open(os.path.join(REPO, "profiles", name)))
+        except Exception:
+            continue
         stale = d.get("kernel_source_sha16") != mfma_source_hash()
         def entry(key, what):
             e = d.get(key, {})
@@ -335,16 +338,21 @@ def coarse_operator_report():
                     "stale": (f"measured on kernel sources {d.get('kernel_source_sha16')}, current {mfma_source_hash()}" if stale else None)}
         out["multi_rhs"] = {
             "formula": d.get("formula"),
+            "level1_schwarz_block_solve": entry("level1_block_minres", "cm_block_minres_op_kernel: the Schwarz block solve of the intermediate level for all test vectors of a bootstrap "
+                                                "iteration at once -- per coupling a complex 48 x 48 times 48 x 32 product on v_mfma_f32_16x16x4_f32, per-column MinRes "
+                                                "coefficients (64^4 three-level setup, level 1 = 16^4)"),
+            "level1_operator": entry("level1_apply", "cm_apply_op_kernel: the operator of the intermediate level for all columns of the K-cycles in lockstep (64^4 three-level setup)"),
+            "level1_restrict": entry("level1_restrict", "cm_restrict_kernel: level 1 -> 2 for all columns"),
+            "level1_interpolate": entry("level1_interpolate", "cm_interpolate_kernel: level 2 -> 1 for all columns"),
             "bootstrap_coarsest_solves_in_lockstep": entry("lockstep_hop", "ls_hop_kernel: hopping terms of the coarsest-level Schur complement for all Nvec test vectors of a "
-                                                           "bootstrap iteration at once, complex n x n times n x 32 on v_mfma_f32_16x16x4_f32 (32^4 two-level setup)"),
-            "galerkin_coarse_apply": entry("galerkin_coarse_apply", "coarse_batch_apply_kernel: all 2*Nvec columns of the coarse-level Galerkin construction (48^4 three-level setup)"),
+                                                           "bootstrap iteration at once, complex n x n times n x 32 on v_mfma_f32_16x16x4_f32"),
+            "galerkin_coarse_apply": entry("galerkin_coarse_apply", "coarse_batch_apply_kernel: all 2*Nvec columns of the coarse-level Galerkin construction"),
             "galerkin_restrict": entry("galerkin_restrict", "restrict_mfma_kernel<2>: the 2*Nvec columns of the fine-level Galerkin construction, five parts each (the four forward "
-                                       "parts on the aggregate faces only), times 24 vectors per aggregate on v_mfma_f32_32x32x2_f32 (48^4 three-level setup)"),
+                                       "parts on the aggregate faces only), times 24 vectors per aggregate"),
             "galerkin_coarse_restrict": entry("galerkin_coarse_restrict", "coarse_batch_restrict_store_mfma_kernel: the coarse level's five batches times its 28 vectors per "
-                                              "aggregate, conj(P) staged in LDS, on v_mfma_f32_16x16x4_f32 (48^4 three-level setup)"),
+                                              "aggregate, conj(P) staged in LDS"),
         }
-    except Exception:
-        pass
+        break
     return out or None
 
 
@@ -419,9 +427,14 @@ def run_solve(q, G, grid, coords, world, rank, transport, group):
     b = np.zeros((V, 12, 2)); b[..., 0] = 1.0
     bv = ctx.vector(0, 64).upload(b); xv = ctx.vector(0, 64)
     ctx.solve_vec(xv, bv, 1e-10)                                    # warm-up
+    on_grid = world > 1 or any(g == -1 for g in grid)
+    if on_grid:
+        ctx.comm_stats(reset=True)
     t0 = time.perf_counter(); it, cit, rr = ctx.solve_vec(xv, bv, 1e-10); t_solve = time.perf_counter() - t0
     res = {"seconds_per_solve": t_solve, "setup_seconds": t_setup, "iterations": it, "coarse_iterations": cit, "true_relres": rr,
            "gauge_generation_seconds": t_gauge}
+    if on_grid:
+        res["messages"] = describe_messages(ctx.comm_stats(), q, it, cit)
     if world == 1 and not any(g == -1 for g in grid):
         x, it2, _, _ = ctx.solve(b, 1e-10)
         t0 = time.perf_counter(); ctx.solve(b, 1e-10, out=x); res["seconds_per_solve_host_vectors"] = time.perf_counter() - t0
@@ -452,10 +465,38 @@ def run_solve(q, G, grid, coords, world, rank, transport, group):
     return res
 
 
+def describe_messages(st, q, iterations, coarse_iterations):
+    """what this rank sent during the timed solve (ddamg_hip_comm_stats), payload by payload, next to the model of DESIGN
+    (multi-GPU, 'what travels between the GPUs'): per outer iteration the fp64 residual exchanges once, the fp32 fine level once per
+    operator application and once per colour sweep of the Schwarz smoother (4 per smoother call), level 1 once per hopping term of
+    the K-cycle's operator and smoother; two global sums per Arnoldi step of the outer solver and of the K-cycle; one all-gather per
+    coarsest solve when that level is gathered"""
+    names = {48: "level 0 fp32: half spinor, 6 complex per face site", 96: "level 0 fp64: half spinor, 6 complex per face site"}
+    for l in range(1, q.num_levels):
+        n = 2 * q.num_vect[l - 1]
+        names[8 * n] = f"level {l} fp32: {n} complex per face site"
+        names[8 * n * 64] = f"level {l} setup: {n} x 64 complex per face site (batched Galerkin construction)"
+    out = {"transport": st.get("transport"), "halo_exchanges": []}
+    for e in st.get("halo_exchanges", []):
+        e = dict(e); e["what"] = names.get(e["bytes_per_face_site"], "?")
+        e["exchanges_per_outer_iteration"] = e["exchanges"] / max(1, iterations)
+        e["bytes_per_message"] = e["bytes_sent"] / max(1, e["messages"])
+        out["halo_exchanges"].append(e)
+    for k in ("allreduce", "allgather"):
+        if k in st:
+            out[k] = dict(st[k])
+    if "allreduce" in out:
+        out["allreduce"]["calls_per_outer_iteration"] = out["allreduce"]["calls"] / max(1, iterations)
+    if "allgather" in out:
+        out["allgather"]["calls_per_coarsest_solve_model"] = 1
+        out["allgather"]["coarsest_iterations"] = coarse_iterations
+    return out
+
+
 def committed_n1_strong(G):
     """seconds per solve of the strong-scaling configuration on ONE GPU, measured by the build on its own MI355X box and
     committed with its provenance (profiles/r03_strong_scaling_n1.json, else r02): the denominator of `speedup_vs_n1` on N > 1"""
-    for name in ("r03_strong_scaling_n1.json", "r02_strong_scaling_n1.json"):
+    for name in ("r04_strong_scaling_n1.json", "r03_strong_scaling_n1.json", "r02_strong_scaling_n1.json"):
         try:
             d = json.load(open(os.path.join(REPO, "profiles", name)))
             if list(d["global_lattice"]) == list(G):
@@ -666,6 +707,18 @@ def main():
         except Exception as e:
             out["solve"] = {"error": str(e)[:300]}
 
+    if world == 1 and not args.no_solve and not args.no_strong and not args.self_exchange and L == [32, 32, 32, 32]:
+        # BASELINE configs[3]: 48^4, three levels, fp32 smoother / fp64 outer solver, one GPU (timed next to configs[2] and [4])
+        try:
+            L48 = [48, 48, 48, 48]
+            res = run_solve(amg_params(api, L48, 3, local_rank), L48, [1, 1, 1, 1], [0, 0, 0, 0], 1, 0, args.transport, None)
+            res["workload"] = (f"48x48x48x48, near-unit gauge exp({GAUGE_EPS} i H) seed {GAUGE_SEED}, m0 -0.3, csw 1, 3-level AMG (4^4 then 2^4 aggregates, Nvec 24/28, "
+                               "SAP 2x4 on both smoothing levels, K-cycle 5/2/0.1, coarsest odd-even GMRES to 5e-2), fp64 FGMRES(50) to 1e-10 with the fp32 V-cycle, "
+                               "rhs=ones (BASELINE configs[3]); no same-volume reference run exists (about 87 GB there): 12 iterations at 32^4 and 64 x 32^3")
+            out["three_level_48"] = res
+        except Exception as e:
+            out["three_level_48"] = {"error": str(e)[:300]}
+
     G = list(args.strong_lattice)
     if not args.no_strong and not args.self_exchange:
         if any(G[mu] % (grid[mu] * 8) for mu in range(4)):
@@ -706,6 +759,15 @@ def main():
                 res["speedup_vs_n1"] = n1["seconds_per_solve"] / res["seconds_per_solve"]
             if rank == 0:
                 out["strong_scaling"] = res
+                # the headline `value` is the fine operator at 32^4 sites per GPU (weak scaling: the one metric that exists at every N
+                # and carries the roofline); the north star's other metric, seconds per 64^4 solve at N GPUs, is repeated at the top
+                # level of the line so that a reader of the N > 1 records finds it without descending into `strong_scaling`
+                out["north_star_strong_scaling"] = {"metric": "seconds per FGMRES+AMG solve of ONE global 64^4 lattice", "n_gpus": world,
+                                                    "seconds_per_solve": res["seconds_per_solve"], "iterations": res["iterations"],
+                                                    "speedup_vs_n1": res.get("speedup_vs_n1"), "n1_seconds_per_solve": res.get("n1_seconds_per_solve"),
+                                                    "scaling": "strong", "target": ">= 3.5 x from 1 to 8 GPUs (BASELINE.json north_star)",
+                                                    "note": "`value` / `scaling: weak` above is the fine Wilson-Clover operator at a fixed local volume; THIS object "
+                                                            "is the strong-scaling solve"}
         except Exception as e:
             failed = True
             if world > 1:
@@ -737,7 +799,7 @@ def main():
                    "coarse_iterations": r8["coarse_iterations"], "true_relres": r8["true_relres"],
                    "same_lattice_without_the_machinery": {"seconds_per_solve": r1["seconds_per_solve"], "iterations": r1["iterations"],
                                                           "setup_seconds": r1["setup_seconds"]},
-                   "cost_of_the_machinery": r8["seconds_per_solve"] / r1["seconds_per_solve"]}
+                   "cost_of_the_machinery": r8["seconds_per_solve"] / r1["seconds_per_solve"], "messages": r8.get("messages")}
             ss = out.get("strong_scaling", {})
             corr = 0.0
             c_n1, c_r = ss.get("coarsest", {}), r8.get("coarsest", {})

@@ -80,6 +80,8 @@ def load_library():
     vp = ctypes.c_void_p
     dp = ctypes.POINTER(ctypes.c_double)
     lib.ddamg_hip_last_error.restype = ctypes.c_char_p
+    lib.ddamg_hip_comm_stats.restype = ctypes.c_char_p
+    lib.ddamg_hip_comm_stats.argtypes = [ctypes.c_void_p, ctypes.c_int]
     lib.ddamg_hip_default_params.argtypes = [ctypes.POINTER(Params)]
     lib.ddamg_hip_default_params.restype = None
     sigs = {
@@ -492,6 +494,11 @@ class Context:
         return out
 
     # ---- multi-GPU halo exchange ----
+    def comm_stats(self, reset=False):
+        """what this process sent since the last reset (dict): halo exchanges by payload, global sums, all-gathers"""
+        import json
+        return json.loads(self._lib.ddamg_hip_comm_stats(self._h, int(bool(reset))).decode() or "{}")
+
     def comm_init_rccl(self, unique_id):
         buf = ctypes.create_string_buffer(bytes(unique_id), 128)
         _check(self._lib.ddamg_hip_comm_init_rccl(self._h, ctypes.cast(buf, ctypes.c_void_p)))

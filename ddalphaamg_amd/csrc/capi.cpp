@@ -304,6 +304,12 @@ int ddamg_hip_comm_init_host(ddamg_hip_ctx* c, ddamg_hip_exchange_fn fn, ddamg_h
   DDAMG_API_END
 }
 
+const char* ddamg_hip_comm_stats(ddamg_hip_ctx* c, int reset) {
+  if (!c || !c->comm) return "{}";
+  if (reset) { comm_stats_reset(c->comm); return "{}"; }
+  return comm_stats_json(c->comm);
+}
+
 int ddamg_hip_halo_plan(const int local_lattice[4], const int process_grid[4], const int process_coords[4],
                         int face, int* neighbor_rank, int* count, int* lex_sites) {
   DDAMG_API_BEGIN

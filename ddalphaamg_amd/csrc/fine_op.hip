@@ -414,12 +414,22 @@ bool FineOp<T>::apply_f32in(T* eta, const float* phi, hipStream_t st) const {
   if constexpr (sizeof(T) == 8) {
     DDAMG_REQUIRE(D_ != nullptr, "fine operator not uploaded");
     if (g_dirac_variant < 0) { const char* e = getenv("DDAMG_DIRAC_VARIANT"); g_dirac_variant = e ? atoi(e) : 1; }
-    if (halo_.active() || g_dirac_variant == 0) return false;
-    const int ntiles = (V_ + 255) / 256;
-    if (tnb_ && g_dirac_variant != 4 && Dc_) hipLaunchKernelGGL((dirac_apply_lds_kernel<T, true, false, true, float>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, (const int*)nullptr);
-    else if (tnb_ && g_dirac_variant != 4) hipLaunchKernelGGL((dirac_apply_lds_kernel<T, true, false, false, float>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, (const int*)nullptr);
-    else hipLaunchKernelGGL((dirac_apply_lds_kernel<T, false, false, false, float>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, (const int*)nullptr);
-    DDAMG_HIP_CHECK(hipGetLastError());
+    static const bool defer = getenv("DDAMG_HALO_DEFER") != nullptr;
+    if (g_dirac_variant == 0 || (halo_.active() && defer)) return false;
+    auto launch = [&](int ntiles, const int* tile_list) {
+      if (ntiles == 0) return;
+      if (tnb_ && g_dirac_variant != 4 && Dc_) hipLaunchKernelGGL((dirac_apply_lds_kernel<T, true, false, true, float>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, tile_list);
+      else if (tnb_ && g_dirac_variant != 4) hipLaunchKernelGGL((dirac_apply_lds_kernel<T, true, false, false, float>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, tile_list);
+      else hipLaunchKernelGGL((dirac_apply_lds_kernel<T, false, false, false, float>), dim3(ntiles), dim3(256), 0, st, eta, phi, dev(), ntiles, tile_list);
+      DDAMG_HIP_CHECK(hipGetLastError());
+    };
+    if (!halo_.active()) { launch((V_ + 255) / 256, nullptr); return true; }
+    // on a process grid: the order of events of apply()
+    halo_.pack_f32in(phi, D_, V_, st);
+    halo_.exchange_begin(comm_, st);
+    launch(halo_.n_interior(), halo_.interior_tiles());
+    halo_.exchange_finish(comm_, st);
+    launch(halo_.n_boundary(), halo_.boundary_tiles());
     return true;
   }
   return false;

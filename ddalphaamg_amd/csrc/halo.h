@@ -34,6 +34,9 @@ void comm_sendrecv_host(Comm* c, const void* send, int send_peer, void* recv, in
 void comm_allreduce_host(Comm* c, double* buf, int n);
 // d_recv[r*bytes .. (r+1)*bytes) <- d_send of process r, for every process r (device buffers; enqueued behind st, which waits for it)
 void comm_allgather(Comm* c, const void* d_send, void* d_recv, size_t bytes, hipStream_t st);
+// what travelled since the last reset: halo exchanges by payload (bytes per face site), reductions, all-gathers (JSON object)
+const char* comm_stats_json(Comm* c);
+void comm_stats_reset(Comm* c);
 int comm_rank(const Comm* c);
 int comm_size(const Comm* c);
 
@@ -80,6 +83,7 @@ class Halo {
   int n_boundary_sites() const { return n_bsites_; }
   // pack kernel: fills the send arena from phi (needs the links: D = FineOpDev::D)
   void pack(const T* phi, const T* D, int V, hipStream_t st);
+  void pack_f32in(const float* phi, const T* D, int V, hipStream_t st);    // the same from an fp32 vector (converted in the loads)
   void exchange_begin(Comm* c, hipStream_t st) { arena_.exchange_begin(c, st); }
   void exchange_finish(Comm* c, hipStream_t st) { arena_.exchange_finish(c, st); }
 

@@ -7,6 +7,8 @@
 #include <stdexcept>
 #include <vector>
 #include <string>
+#include <map>
+#include <cstdio>
 
 namespace ddamg {
 
@@ -36,7 +38,58 @@ struct Comm {
   int h_red_n = 0;
   char* h_gather = nullptr;                     // pinned staging for the host transport's all-gather
   size_t h_gather_bytes = 0;
+  // what travelled since the last reset (ddamg_hip_comm_stats): halo exchanges by payload (bytes per face site), reductions
+  // and all-gathers with the time their collective kernels took on the transport stream (RCCL: event pairs around the call,
+  // read when the pair comes round again or at the report)
+  struct Payload { unsigned long long exchanges = 0, messages = 0, bytes = 0; };
+  std::map<size_t, Payload> halo_stats;
+  struct Timed {
+    unsigned long long calls = 0, bytes = 0; double ms = 0;
+    static constexpr int NEV = 32;
+    hipEvent_t a[NEV] = {}, b[NEV] = {}; bool pending[NEV] = {}; int next = 0;
+    void begin(hipStream_t s, size_t nbytes) {
+      calls++; bytes += nbytes;
+      const int i = next;
+      if (!a[i]) { (void)hipEventCreate(&a[i]); (void)hipEventCreate(&b[i]); }
+      if (pending[i]) collect(i);
+      (void)hipEventRecord(a[i], s);
+    }
+    void end(hipStream_t s) { (void)hipEventRecord(b[next], s); pending[next] = true; next = (next + 1) % NEV; }
+    void collect(int i) { float t = 0; if (hipEventSynchronize(b[i]) == hipSuccess && hipEventElapsedTime(&t, a[i], b[i]) == hipSuccess) ms += t; pending[i] = false; }
+    void collect_all() { for (int i = 0; i < NEV; i++) if (pending[i]) collect(i); }
+    void reset() { collect_all(); calls = 0; bytes = 0; ms = 0; }
+    void destroy() { for (int i = 0; i < NEV; i++) { if (a[i]) (void)hipEventDestroy(a[i]); if (b[i]) (void)hipEventDestroy(b[i]); a[i] = b[i] = nullptr; } }
+  } allreduce_stats, allgather_stats;
+  std::string stats_json;
 };
+
+// what travelled since the last reset, as a JSON object (owned by the transport; valid until the next call)
+const char* comm_stats_json(Comm* c) {
+  if (!c) return "{}";
+  c->allreduce_stats.collect_all(); c->allgather_stats.collect_all();
+  char buf[256];
+  std::string s = "{\"transport\": \"";
+  s += c->kind == 1 ? "rccl" : "host";
+  s += "\", \"halo_exchanges\": [";
+  bool first = true;
+  for (auto& kv : c->halo_stats) {
+    snprintf(buf, sizeof buf, "%s{\"bytes_per_face_site\": %zu, \"exchanges\": %llu, \"messages\": %llu, \"bytes_sent\": %llu}", first ? "" : ", ", kv.first,
+             kv.second.exchanges, kv.second.messages, kv.second.bytes);
+    s += buf; first = false;
+  }
+  snprintf(buf, sizeof buf, "], \"allreduce\": {\"calls\": %llu, \"bytes\": %llu, \"milliseconds_on_the_transport_stream\": %s%.3f}", c->allreduce_stats.calls,
+           c->allreduce_stats.bytes, c->kind == 1 ? "" : "null, \"host_note_ms\": ", c->allreduce_stats.ms);
+  s += buf;
+  snprintf(buf, sizeof buf, ", \"allgather\": {\"calls\": %llu, \"bytes_sent\": %llu, \"milliseconds_on_the_transport_stream\": %s%.3f}}", c->allgather_stats.calls,
+           c->allgather_stats.bytes, c->kind == 1 ? "" : "null, \"host_note_ms\": ", c->allgather_stats.ms);
+  s += buf;
+  c->stats_json = s;
+  return c->stats_json.c_str();
+}
+void comm_stats_reset(Comm* c) {
+  if (!c) return;
+  c->halo_stats.clear(); c->allreduce_stats.reset(); c->allgather_stats.reset();
+}
 
 int comm_rank(const Comm* c) { return c ? c->rank : 0; }
 int comm_size(const Comm* c) { return c ? c->nranks : 1; }
@@ -49,12 +102,15 @@ void comm_allgather(Comm* c, const void* d_send, void* d_recv, size_t bytes, hip
   if (c->kind == 1) {
     DDAMG_HIP_CHECK(hipEventRecord(c->ev_a, st));
     DDAMG_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_a, 0));
+    c->allgather_stats.begin(c->stream, bytes);
     DDAMG_NCCL_CHECK(ncclAllGather(d_send, d_recv, bytes, ncclChar, c->nccl, c->stream));
+    c->allgather_stats.end(c->stream);
     DDAMG_HIP_CHECK(hipEventRecord(c->ev_b, c->stream));
     DDAMG_HIP_CHECK(hipStreamWaitEvent(st, c->ev_b, 0));
     return;
   }
   // host transport: staged, one message to and from every other process
+  c->allgather_stats.calls++; c->allgather_stats.bytes += bytes;
   const size_t total = bytes * (size_t)c->nranks;
   if (total > c->h_gather_bytes) {
     if (c->h_gather) DDAMG_HIP_CHECK(hipHostFree(c->h_gather));
@@ -78,11 +134,14 @@ void comm_allreduce(Comm* c, double* d_buf, int n, hipStream_t st) {
   if (c->kind == 1) {
     DDAMG_HIP_CHECK(hipEventRecord(c->ev_a, st));
     DDAMG_HIP_CHECK(hipStreamWaitEvent(c->stream, c->ev_a, 0));
+    c->allreduce_stats.begin(c->stream, sizeof(double) * (size_t)n);
     DDAMG_NCCL_CHECK(ncclAllReduce(d_buf, d_buf, (size_t)n, ncclDouble, ncclSum, c->nccl, c->stream));
+    c->allreduce_stats.end(c->stream);
     DDAMG_HIP_CHECK(hipEventRecord(c->ev_b, c->stream));
     DDAMG_HIP_CHECK(hipStreamWaitEvent(st, c->ev_b, 0));
   } else {
     DDAMG_REQUIRE(c->reduce_fn != nullptr, "host transport without an allreduce callback");
+    c->allreduce_stats.calls++; c->allreduce_stats.bytes += sizeof(double) * (size_t)n;
     if (n > c->h_red_n) {
       if (c->h_red) DDAMG_HIP_CHECK(hipHostFree(c->h_red));
       DDAMG_HIP_CHECK(hipHostMalloc(&c->h_red, sizeof(double) * n));
@@ -117,7 +176,9 @@ void comm_allreduce_begin(Comm* c, double* d_buf, int n, hipStream_t st) {
   hipStream_t rs = own ? c->stream_red : c->stream;
   DDAMG_HIP_CHECK(hipEventRecord(own ? c->ev_ra : c->ev_a, st));
   DDAMG_HIP_CHECK(hipStreamWaitEvent(rs, own ? c->ev_ra : c->ev_a, 0));
+  c->allreduce_stats.begin(rs, sizeof(double) * (size_t)n);
   DDAMG_NCCL_CHECK(ncclAllReduce(d_buf, d_buf, (size_t)n, ncclDouble, ncclSum, own ? c->nccl_red : c->nccl, rs));
+  c->allreduce_stats.end(rs);
   DDAMG_HIP_CHECK(hipEventRecord(own ? c->ev_rb : c->ev_b, rs));
 }
 void comm_allreduce_end(Comm* c, double* d_buf, int n, hipStream_t st) {
@@ -213,14 +274,21 @@ void comm_destroy(Comm* c) {
   if (c->ev_b) (void)hipEventDestroy(c->ev_b);
   if (c->h_red) (void)hipHostFree(c->h_red);
   if (c->h_gather) (void)hipHostFree(c->h_gather);
+  c->allreduce_stats.destroy(); c->allgather_stats.destroy();
   delete c;
 }
 
 // ---- pack -----------------------------------------------------------------------------------------
-template <typename T, int MU>
-__device__ __forceinline__ void pack_site(const T* __restrict__ phi, const T* __restrict__ D, size_t V, int s, bool plus, T (&out)[12]) {
+template <typename T, int MU, typename TIN = T>
+__device__ __forceinline__ void pack_site(const TIN* __restrict__ phi, const T* __restrict__ D, size_t V, int s, bool plus, T (&out)[12]) {
   T p[24];
-  load_site<T, 24>(phi, V, s, p);
+  if constexpr (sizeof(TIN) == sizeof(T)) load_site<T, 24>(reinterpret_cast<const T*>(phi), V, s, p);
+  else {      // an input vector of the other precision (its own chunk layout), converted in the load
+    TIN q[24];
+    load_site<TIN, 24>(phi, V, s, q);
+#pragma unroll
+    for (int k = 0; k < 24; k++) p[k] = (T)q[k];
+  }
   if (plus) {
     T U[18], h[12];
     load_site<T, 18>(D + (size_t)MU * 18 * V, V, s, U);
@@ -231,8 +299,8 @@ __device__ __forceinline__ void pack_site(const T* __restrict__ phi, const T* __
   }
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void halo_pack_kernel(T* __restrict__ send, const T* __restrict__ phi, const T* __restrict__ D,
+template <typename T, typename TIN = T>
+__global__ __launch_bounds__(256) void halo_pack_kernel(T* __restrict__ send, const TIN* __restrict__ phi, const T* __restrict__ D,
                                                         const int* __restrict__ face_sites, HaloDev hd, int V, int total) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= total) return;
@@ -253,10 +321,10 @@ __global__ __launch_bounds__(256) void halo_pack_kernel(T* __restrict__ send, co
   const int s = face_sites[i];
   T out[12];
   switch (mu) {
-    case 0: pack_site<T, 0>(phi, D, V, s, plus, out); break;
-    case 1: pack_site<T, 1>(phi, D, V, s, plus, out); break;
-    case 2: pack_site<T, 2>(phi, D, V, s, plus, out); break;
-    default: pack_site<T, 3>(phi, D, V, s, plus, out); break;
+    case 0: pack_site<T, 0, TIN>(phi, D, V, s, plus, out); break;
+    case 1: pack_site<T, 1, TIN>(phi, D, V, s, plus, out); break;
+    case 2: pack_site<T, 2, TIN>(phi, D, V, s, plus, out); break;
+    default: pack_site<T, 3, TIN>(phi, D, V, s, plus, out); break;
   }
   store_site<T, 12>(send + hd.off[d], (size_t)hd.F[mu], (size_t)slot, out);
 }
@@ -304,6 +372,11 @@ void HaloArena::exchange_begin(Comm* c, hipStream_t st) {
   DDAMG_REQUIRE(c != nullptr, "process grid > 1 but no transport: call ddamg_hip_comm_init_rccl or ddamg_hip_comm_init_host first");
   DDAMG_HIP_CHECK(hipStreamWaitEvent(c->stream, ev_packed_, 0));
   const size_t bytes = bpfs_ * (size_t)total_sites_;
+  {
+    Comm::Payload& ps = c->halo_stats[bpfs_];
+    ps.exchanges++; ps.bytes += bytes;
+    for (int mu = 0; mu < 4; mu++) if (F_[mu]) ps.messages += 2;
+  }
   if (c->kind == 1) {
     DDAMG_NCCL_CHECK(ncclGroupStart());
     for (int mu = 0; mu < 4; mu++) {
@@ -384,6 +457,15 @@ template <typename T>
 void Halo<T>::pack(const T* phi, const T* D, int V, hipStream_t st) {
   const int total = arena_.total_sites();
   hipLaunchKernelGGL(halo_pack_kernel<T>, dim3((total + 255) / 256), dim3(256), 0, st, reinterpret_cast<T*>(arena_.send()), phi, D,
+                     arena_.d_face_sites(), hd_, V, total);
+  DDAMG_HIP_CHECK(hipGetLastError());
+  arena_.mark_packed(st);
+}
+
+template <typename T>
+void Halo<T>::pack_f32in(const float* phi, const T* D, int V, hipStream_t st) {
+  const int total = arena_.total_sites();
+  hipLaunchKernelGGL((halo_pack_kernel<T, float>), dim3((total + 255) / 256), dim3(256), 0, st, reinterpret_cast<T*>(arena_.send()), phi, D,
                      arena_.d_face_sites(), hd_, V, total);
   DDAMG_HIP_CHECK(hipGetLastError());
   arena_.mark_packed(st);

@@ -44,12 +44,12 @@ static void ensure_outer(ddamg_hip_ctx* c) {
   if (c->outer_ready) return;
   const size_t n = (size_t)24 * c->levels[0]->geom.V;
   c->rw_outer.init(c->par.restart + 4);
-  // mixed precision 1 with a multigrid preconditioner on one process: the iterates Z_j of the outer FGMRES stay in fp32, as the
+  // mixed precision 1 with a multigrid preconditioner: the iterates Z_j of the outer FGMRES stay in fp32, as the
   // V-cycle leaves them (Gmres::z_fp32); DDAMG_OUTER_Z_FP64 keeps the converted fp64 copies of rounds 1-3
   {
     const char* dv = getenv("DDAMG_DIRAC_VARIANT");
-    c->outer.z_fp32 = c->par.method >= 1 && c->par.method <= 4 && c->par.mixed_precision == 1 && !c->levels[0]->geom.distributed() &&
-                      !(dv && atoi(dv) == 0) && getenv("DDAMG_OUTER_Z_FP64") == nullptr;
+    c->outer.z_fp32 = c->par.method >= 1 && c->par.method <= 4 && c->par.mixed_precision == 1 && !(dv && atoi(dv) == 0) &&
+                      !(c->levels[0]->geom.distributed() && getenv("DDAMG_HALO_DEFER")) && getenv("DDAMG_OUTER_Z_FP64") == nullptr;
   }
   // pure CGN keeps its 8 vectors in a 4-vector Krylov structure, as the reference does (src/init.c:178-180)
   c->outer.alloc(n, c->par.method == -1 ? 4 : c->par.restart, c->par.method > 0);

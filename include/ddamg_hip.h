@@ -244,6 +244,11 @@ typedef void (*ddamg_hip_allreduce_fn)(void* user, double* buf, int n);
 int ddamg_hip_rccl_unique_id(void* id128);
 int ddamg_hip_comm_init_rccl(ddamg_hip_ctx* ctx, const void* id128);
 int ddamg_hip_comm_init_host(ddamg_hip_ctx* ctx, ddamg_hip_exchange_fn fn, ddamg_hip_allreduce_fn reduce_fn, void* user);
+/* What this process sent since the last reset, as a JSON object owned by the context (valid until the next call): halo exchanges
+ * grouped by payload (bytes per face site: 48 = fp32 half spinor of the fine level, 96 = its fp64 form, 8 n = a coarse level with
+ * n dof), messages and bytes; global sums and all-gathers with the time their collectives took on the transport stream (RCCL).
+ * reset != 0 clears the counters and returns "{}".  For reading a multi-GPU run against the message table of DESIGN. */
+const char* ddamg_hip_comm_stats(ddamg_hip_ctx* ctx, int reset);
 /* host-only helper (no GPU needed): the halo plan of one process.  For face d (0..3: +mu face sending to
  * +mu, 4..7: -mu face) returns the neighbour rank and, if lex_sites != NULL, the local lexicographic index
  * of the face sites in message (slot) order; *count = 0 when the direction is not split. */

@@ -68,6 +68,15 @@ def test_bench_starts_its_own_ranks():
     s = d["strong_scaling"]
     assert s["n_gpus"] == 2 and s["scaling"] == "strong" and s["true_relres"] < 1e-10 and 8 <= s["iterations"] <= 20
     assert "16x16x16x16" in s["workload"] and "local 8x16x16x16" in s["workload"]
+    # the north star's strong-scaling metric at the top level of the N > 1 line, and what travelled during the timed solve
+    ns = d["north_star_strong_scaling"]
+    assert ns["scaling"] == "strong" and ns["n_gpus"] == 2 and ns["seconds_per_solve"] == s["seconds_per_solve"] and ns["iterations"] == s["iterations"]
+    m = s["messages"]
+    kinds = {e["bytes_per_face_site"]: e for e in m["halo_exchanges"]}
+    assert 48 in kinds and 96 in kinds and kinds[48]["what"].startswith("level 0 fp32") and kinds[96]["exchanges"] >= s["iterations"]
+    assert kinds[48]["messages"] == 2 * kinds[48]["exchanges"]             # one split direction: two messages per exchange
+    assert kinds[48]["bytes_per_message"] == 48 * 16 ** 3                  # the T face of the local 8 x 16^3 lattice, 6 complex fp32 per site
+    assert m["allreduce"]["calls"] >= 2 * s["iterations"] and m["allgather"]["calls"] > 0
 
 
 def test_two_processes_under_torchrun():
@@ -108,3 +117,9 @@ def test_rehearsal_of_the_eight_gpu_point_on_one_gpu():
     assert h["predicted_seconds_per_solve_per_gpu"] >= h["seconds_per_solve_per_gpu"] > 0
     assert abs(h["predicted_speedup_vs_n1"] - s["seconds_per_solve"] / h["predicted_seconds_per_solve_per_gpu"]) < 1e-9
     assert h["coarsest_level"]["gathered_sites_on_n_gpus"] == 8 * h["coarsest_level"]["rehearsed_sites"]
+    # what this "rank" sent during the timed solve, payload by payload (to be read against DESIGN's message table)
+    m = h["messages"]
+    kinds = {e["bytes_per_face_site"]: e for e in m["halo_exchanges"]}
+    assert m["transport"] == "rccl" and kinds[48]["messages"] == 6 * kinds[48]["exchanges"]        # three split directions
+    assert kinds[48]["exchanges_per_outer_iteration"] >= 4 and kinds[96]["exchanges"] >= h["iterations"]   # 4 colour sweeps per smoother call
+    assert 8 * 48 in kinds and m["allgather"]["calls"] > 0 and m["allreduce"]["milliseconds_on_the_transport_stream"] > 0
