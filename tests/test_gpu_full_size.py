@@ -15,6 +15,7 @@ import ddalphaamg_amd as dd
 REPO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tools"))
 pytestmark = pytest.mark.gpu
+CURVE_BAND = 0.35
 # the seeded field the reference itself was run on (oracle/run_reference_big.py)
 GAUGE_EPS, GAUGE_SEED = 0.35, 20260101
 
@@ -100,7 +101,9 @@ def test_solve_host_and_device_vectors(ctx32):
     assert rr < 1e-10 and abs(it - ref["iterations"]) <= 1, (it, ref["iterations"])
     hist = np.array(ctx32.residual_history()); href = np.array(ref["residual_history"])
     n = min(len(hist), len(href)) - 1
-    assert np.max(np.abs(np.log10(hist[:n] / href[:n]))) < 0.35      # the same convergence rate: within a factor 2.2 at every step
+    dev = float(np.max(np.abs(np.log10(hist[:n] / href[:n]))))
+    print("residual curve against the reference: max |log10 ratio|", dev)
+    assert dev < CURVE_BAND      # the same convergence rate at every step
     # the returned relative residual is the true one: recompute it with the fp64 operator
     xv = ctx32.vector(0, 64).upload(x); Dx = ctx32.vector(0, 64)
     ctx32.dirac_apply(Dx, xv)
@@ -138,7 +141,9 @@ def test_four_level_hierarchy():
     assert rr < 1e-10 and abs(it - ref["iterations"]) <= 1, (it, ref["iterations"])
     hist = np.array(ctx.residual_history()); href = np.array(ref["residual_history"])
     n = min(len(hist), len(href)) - 1
-    assert np.max(np.abs(np.log10(hist[:n] / href[:n]))) < 0.35
+    dev = float(np.max(np.abs(np.log10(hist[:n] / href[:n]))))
+    print("residual curve against the reference: max |log10 ratio|", dev)
+    assert dev < CURVE_BAND
     ctx.close()
 
 

@@ -10,6 +10,7 @@ import ddalphaamg_amd as dd
 REPO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tools"))
 pytestmark = pytest.mark.gpu
+CURVE_BAND = 0.35
 
 
 def device_norm_of_difference(ctx, a, b):
@@ -47,7 +48,9 @@ def test_three_level_production_shape_against_the_reference_at_the_same_volume(n
     assert rr < 1e-10 and abs(it - ref["iterations"]) <= 1, (it, ref["iterations"])
     hist = np.array(ctx.residual_history()); href = np.array(ref["residual_history"])
     n = min(len(hist), len(href)) - 1
-    assert np.max(np.abs(np.log10(hist[:n] / href[:n]))) < 0.35
+    dev = float(np.max(np.abs(np.log10(hist[:n] / href[:n]))))
+    print("residual curve against the reference: max |log10 ratio|", dev)
+    assert dev < CURVE_BAND
     Dx = ctx.vector(0, 64)
     ctx.dirac_apply(Dx, xv)
     _, nb = ctx.vec_dot(bv, bv)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""tools/commit_profiles.py [SRC_DIR [ROUND]] -- copy the artefacts of tools/gpu/profile_<round>.sh (default gpurun_out/prof_r03,
-r03) into profiles/ and derive the provenance files bench.py reads:
+"""tools/commit_profiles.py [SRC_DIR [ROUND]] -- copy the artefacts of `tools/gpu/run.sh profile <round>` (default gpurun_out/profile,
+r04) into profiles/ and derive the provenance files bench.py reads:
   profiles/<round>_traffic.json            fabric bytes per launch of the fine operator (2*FETCH_SIZE + WRITE_SIZE), with the
                                            commit and the hash of the kernel sources it was measured on
   profiles/<round>_strong_scaling_n1.json  the one-GPU point of the 64^4 strong-scaling solve
@@ -12,8 +12,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
 import bench
 
-R = sys.argv[2] if len(sys.argv) > 2 else "r03"
-src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "gpurun_out", "prof_" + R)
+R = sys.argv[2] if len(sys.argv) > 2 else "r04"
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(REPO, "gpurun_out", "profile")
 dst = os.path.join(REPO, "profiles")
 for f in sorted(os.listdir(src)):
     if f.startswith(R + "_"):
@@ -56,6 +56,8 @@ def busy(fname, key):
     except Exception as e:
         return {"error": str(e)}
 mf = {"formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)",
+      "level1_block_minres": busy(R + "_pmc_mfma64.json", "cm_block_minres_op_kernel"), "level1_apply": busy(R + "_pmc_mfma64.json", "cm_apply_op_kernel"),
+      "level1_restrict": busy(R + "_pmc_mfma64.json", "cm_restrict_kernel"), "level1_interpolate": busy(R + "_pmc_mfma64.json", "cm_interpolate_kernel"),
       "lockstep_hop": busy(R + "_pmc_mfma_lockstep32.json", "ls_hop_kernel"), "lockstep_self": busy(R + "_pmc_mfma_lockstep32.json", "ls_self_kernel"),
       "galerkin_coarse_apply": busy(R + "_pmc_mfma.json", "coarse_batch_apply_kernel"), "galerkin_restrict": busy(R + "_pmc_mfma.json", "restrict_mfma_kernel<2"),
       "galerkin_coarse_restrict": busy(R + "_pmc_mfma.json", "coarse_batch_restrict_store_mfma_kernel"),

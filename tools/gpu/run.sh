@@ -30,7 +30,7 @@ tests)        # smoke() + the -m gpu suite (arguments: extra pytest arguments, e
 tests_full_links)   # the suite on the full link storage (the path every non-SU(3) field takes)
   DDAMG_LINK_COMPRESSION=0 timeout -k 10 1100 python3 -m pytest tests/ -x -q -m gpu --deselect tests/test_gpu_dirac.py::test_two_row_link_storage_and_its_fall_back > $O/tests.log 2>&1; echo "rc=$?"; tail -4 $O/tests.log ;;
 bands)        # iteration counts of the full-size tests, printed (what the +-1 assertions are pinned to)
-  timeout -k 10 1100 python3 -m pytest tests/test_gpu_full_size.py tests/test_gpu_configs.py tests/test_gpu_reference_volumes.py -q -m gpu -s 2>&1 | grep -E "level|method|passed|failed|Error|assert|iterations" | tee $O/bands.log | tail -30 ;;
+  timeout -k 10 1100 python3 -m pytest tests/test_gpu_full_size.py tests/test_gpu_configs.py tests/test_gpu_reference_volumes.py -q -m gpu -s 2>&1 | grep -E "level|method|passed|failed|Error|assert|iterations|residual curve" | tee $O/bands.log | tail -30 ;;
 phases)       # wall-clock seconds per setup phase: run.sh phases "32 2" "48 3" "64 3" (a warm-up process first)
   warm; for cfg in "${@:-32 2}"; do set -- $cfg; echo "== $1^4, $2 levels"; phases $1 $2; done ;;
 env)          # a knob on / off in alternation on one box: run.sh env "DDAMG_X=1 DDAMG_Y=2" <extent> <levels> [repetitions]  (setup phases + solve)
