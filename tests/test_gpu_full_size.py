@@ -15,7 +15,7 @@ import ddalphaamg_amd as dd
 REPO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tools"))
 pytestmark = pytest.mark.gpu
-CURVE_BAND = 0.35
+CURVE_BAND = 0.10      # measured in round 4: 0.023 (32^4 two-level) and 0.047 (16^4 four-level) -- a factor 1.26 at every step
 # the seeded field the reference itself was run on (oracle/run_reference_big.py)
 GAUGE_EPS, GAUGE_SEED = 0.35, 20260101
 

@@ -10,7 +10,7 @@ import ddalphaamg_amd as dd
 REPO = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, REPO); sys.path.insert(0, os.path.join(REPO, "tools"))
 pytestmark = pytest.mark.gpu
-CURVE_BAND = 0.35
+CURVE_BAND = 0.05      # measured in round 4: 0.0097 (32^4) and 0.0147 (64 x 32^3) -- a factor 1.12 at every step
 
 
 def device_norm_of_difference(ctx, a, b):
