@@ -31,6 +31,9 @@ class CoarseMulti {
   // true if the batched path covers this level: fp32 operator on one process, at most 16 sites per Schwarz block, dof counts the
   // matrix-core kernels tile (n % 8 == 0, n <= 64), a red-black colouring
   static bool available(const Geometry& g, const CoarseOp<float>& op, int method);
+  // device memory the batches, the K-cycle's bases and the A-operand copy of the couplings take (an upper estimate, for the
+  // caller's check against the free memory before it commits to the many-vector path)
+  static size_t workspace_bytes(const Geometry& g, int n, int restart_length);
   // ip == nullptr: no transfer to a next level (operator and smoother only)
   void init(const Geometry& g, const CoarseOp<float>* op, const CoarseTransfer<float>* ip, int block_iter, hipStream_t st);
   void release();

@@ -364,6 +364,12 @@ void CoarseMulti::init(const Geometry& g, const CoarseOp<float>* op, const Coars
   DDAMG_HIP_CHECK(hipStreamSynchronize(st));
 }
 
+size_t CoarseMulti::workspace_bytes(const Geometry& g, int n, int restart_length) {
+  const size_t batch = sizeof(float2) * (size_t)g.V * n * LOCKSTEP_COLS;
+  // r, latest, x of the smoother; residual, w and the two bases of the K-cycle; up to six work() batches of the callers
+  return batch * (size_t)(3 + 2 * restart_length + 3 + 6) + sizeof(float4) * (size_t)g.V * 9 * mfma_op_matrix_elems(n);
+}
+
 float2* CoarseMulti::work(int i) {
   if ((int)work_.size() <= i) work_.resize(i + 1, nullptr);
   if (!work_[i]) DDAMG_HIP_CHECK(device_alloc(&work_[i], sizeof(float2) * batch_elems()));

@@ -1,6 +1,7 @@
 // mg.cpp -- see mg.h
 #include "mg.h"
 #include "coarse_batch.h"
+#include <cstdio>
 #include <chrono>
 #include <cstdlib>
 #include "setup_kernels.h"
@@ -477,7 +478,18 @@ bool Multigrid<T>::level1_multi_ready(int ncols) {
     if (num_levels() != 3 || gath_.on || comm_ != nullptr || par_.mixed_precision == 2 || !par_.odd_even || ncols < 2 || ncols > LOCKSTEP_COLS) return false;
     MGLevel<T>& l1 = *lv_[1];
     if (l1.nvec > 32 || !CoarseMulti::available(*l1.g, l1.cop, par_.method) || !LockstepCoarseSolver::available(lv_[2]->cop, ncols, true)) return false;
-    if (!multi1_.ready()) multi1_.init(*l1.g, &l1.cop, &l1.cip, par_.block_iter[1], st_);
+    if (!multi1_.ready()) {
+      // the batches are tens of GB at 64^4: next to a context that already holds its solver workspace they may not fit, and a
+      // failed allocation in the middle of a setup is worse than the one-vector-at-a-time path
+      size_t free_b = 0, total_b = 0;
+      DDAMG_HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+      const size_t need = CoarseMulti::workspace_bytes(*l1.g, l1.n, l1.gm.restart_length);
+      if (need + need / 8 > free_b) {
+        if (getenv("DDAMG_SETUP_TIMING")) fprintf(stderr, "[ddamg setup] level 1 one vector at a time: %zu bytes free, %zu needed\n", free_b, need);
+        return false;
+      }
+      multi1_.init(*l1.g, &l1.cop, &l1.cip, par_.block_iter[1], st_);
+    }
     ensure_lockstep();
     return true;
   }
@@ -858,7 +870,7 @@ void Multigrid<T>::re_setup(int l) {
 }
 
 template <typename T>
-void Multigrid<T>::initial_setup() { initial_setup_from(0); }
+void Multigrid<T>::initial_setup() { setup_times.clear(); initial_setup_from(0); }   // the phase times of one setup, not of all so far
 
 template <typename T>
 void Multigrid<T>::initial_setup_from(int l0) {
@@ -899,7 +911,15 @@ bool Multigrid<T>::bootstrap_vcycles_batched() {
   if (off || sizeof(T) != 4 || !gal_W_ || !gal_C_) return false;
   if (single_only && (comm_ != nullptr || lv.fop->distributed())) return false;
   if (!Interpolation<T>::restrict_batch_available(lv.fip.agg_sites, N) || !Interpolation<T>::interpolate_batch_available(lv.fip.agg_sites, N, N)) return false;
-  if (gal_W_elems_ < (size_t)N * ws || gal_C_elems_ < (size_t)2 * N * cs) return false;
+  // the borrowed workspace holds `cap` fine vectors: all Nvec in a first setup; fewer next to a context that already holds its
+  // solver workspace (64^4: 17 of 24), and then the interpolation + smoothing at the end goes through it in groups
+  int cap = (int)std::min<size_t>((size_t)N, gal_W_elems_ / ws);
+  if (const char* e = getenv("DDAMG_BOOTSTRAP_GROUP")) cap = std::max(1, std::min(cap, atoi(e)));   // tests: groups at any volume
+  if (cap < 1 || gal_C_elems_ < (size_t)2 * N * cs) {
+    if (getenv("DDAMG_SETUP_TIMING"))
+      fprintf(stderr, "[ddamg setup] bootstrap one vector at a time: workspace %zu / %zu elements, needed %zu / %zu\n", gal_W_elems_, gal_C_elems_, (size_t)N * ws, (size_t)2 * N * cs);
+    return false;
+  }
   T* F = gal_W_;                 // N fine vectors: the iterates of the V-cycles
   T* Cb = gal_C_;                // N coarse right-hand sides
   T* Cx = gal_C_ + (size_t)N * cs;   // N coarse solutions
@@ -954,11 +974,14 @@ bool Multigrid<T>::bootstrap_vcycles_batched() {
     }
     vec_copy<T>(Cx + (size_t)i * cs, nx.gm.x, call, st_);
   }
-  lv.fip.interpolate_batch(F, ws, Cx, cs, N, st_);
-  for (int i = 0; i < N; i++) {
-    T* out = F + (size_t)i * ws;
-    smoother(0, out, nullptr, test_vector(0, i), par_.post_smooth_iter[0], RES);
-    vec_scale<T>(test_vector(0, i), out, 1.0 / norm_of(0, out), 0.0, all, st_);
+  for (int i0 = 0; i0 < N; i0 += cap) {
+    const int ni = std::min(cap, N - i0);
+    lv.fip.interpolate_batch(F, ws, Cx + (size_t)i0 * cs, cs, ni, st_);
+    for (int i = 0; i < ni; i++) {
+      T* out = F + (size_t)i * ws;
+      smoother(0, out, nullptr, test_vector(0, i0 + i), par_.post_smooth_iter[0], RES);
+      vec_scale<T>(test_vector(0, i0 + i), out, 1.0 / norm_of(0, out), 0.0, all, st_);
+    }
   }
   return true;
 }

@@ -461,6 +461,21 @@ def test_bootstrap_with_one_restriction_and_one_interpolation_for_all_test_vecto
     assert relerr(res[0][1], res[1][1]) < 1e-8
 
 
+def test_bootstrap_in_groups_when_the_workspace_holds_fewer_vectors(gold_b4, gold8, monkeypatch):
+    """a setup repeated in a context that already holds its solver workspace finds less free device memory (64^4: room for 17
+    of the 24 iterates): interpolation + smoothing at the end of the batched bootstrap then go through the workspace in groups
+    (DDAMG_BOOTSTRAP_GROUP forces groups at any volume).  The columns are independent: the same bits"""
+    res = []
+    for group in (None, "5"):
+        if group:
+            monkeypatch.setenv("DDAMG_BOOTSTRAP_GROUP", group)
+        ctx = make_ctx_b4(gold_b4, gold8)
+        ctx.setup(3)
+        res.append(ctx.get_test_vectors())
+        ctx.close()
+    assert np.array_equal(res[0], res[1])
+
+
 @pytest.mark.parametrize("coarse_restrict", ["mfma", "valu"])
 @pytest.mark.parametrize("fixture", ["ref_16x16_3lvl.npz", "ref_16x16_3lvl_hard.npz"], ids=["random-links", "smooth-links"])
 def test_three_level_production_block_shapes_16x16(fixture, coarse_restrict, monkeypatch):
