@@ -66,6 +66,14 @@ sap_chain)    # the MinRes step of the Schwarz kernel segment by segment (needs 
 sap_pmc)      # traffic and issue counters of the Schwarz kernel
   export SAP_BENCH_ITERS=4    # (never `env VAR=.. program` behind rocprofv3's `--`: the profiler has initialised the GPU, and that hop is an exec)
   pmc sap FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT" -- python3 tools/sap_bench.py ;;
+transfer_context)  # restriction / interpolation alone: back to back, then after other kernels that write (default) or only read 1 GB
+  for ro in 0 1; do
+    [ $ro = 1 ] && export TRANSFER_BENCH_READ_ONLY=1
+    TRANSFER_BENCH_INTERLEAVE=1 rocprofv3 --kernel-trace -d $O/t$ro -o t -- python3 tools/transfer_bench.py > $O/tb$ro.log 2>$O/err$ro.log
+    echo "== other traffic read-only: $ro   (23 launches back to back, then 10 with the other traffic in between; us)"
+    KSEQ_PERIOD=1 python3 tools/kernel_seq.py $O/t$ro/t_results.db "restrict_kernel<float, 1>" 33; KSEQ_PERIOD=1 python3 tools/kernel_seq.py $O/t$ro/t_results.db "interpolate_kernel<float>" 33
+    rm -rf $O/t$ro
+  done ;;
 transfer_pmc) # restriction against interpolation (same bytes): issue, wait, LDS and cache counters of a 32^4 solve
   pmc transfer FETCH_SIZE WRITE_SIZE "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_LDS" \
       "SQ_INSTS_VALU SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM" "TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_LATENCY_sum" "TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum" -- $SP 5 1 32 2

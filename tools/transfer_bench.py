@@ -25,4 +25,17 @@ for name, fn in (("restrict", lambda: ctx.restrict(c, f)), ("interpolate", lambd
         fn()
     ms = ctx.timer_end()
     print(f"{name}: {ms / 20 * 1e3:.1f} us  ({(96 * 24 + 96) * V / (ms / 20 * 1e-3) / 1e12:.2f} TB/s algorithmic)")
+if os.environ.get("TRANSFER_BENCH_INTERLEAVE"):
+    # the same launches with other memory touched in between (what a solve does between two restrictions): N GB of fp64 vectors
+    others = [ctx.vector(0, 64) for _ in range(int(os.environ["TRANSFER_BENCH_INTERLEAVE"]) * 5)]
+    for name, fn in (("restrict", lambda: ctx.restrict(c, f)), ("interpolate", lambda: ctx.interpolate(f, c, add=True))):
+        tot = 0.0
+        for _ in range(10):
+            for a in others:
+                if os.environ.get("TRANSFER_BENCH_READ_ONLY"):
+                    ctx.vec_dot(a, a)
+                else:
+                    ctx.vec_axpy(a, a, a, 0.5)
+            ctx.sync(); ctx.timer_begin(); fn(); tot += ctx.timer_end()
+        print(f"{name} after {len(others) * 0.2:.0f} GB of other traffic: {tot / 10 * 1e3:.1f} us")
 ctx.close()
