@@ -441,7 +441,7 @@ def run_solve(q, G, grid, coords, world, rank, transport, group):
     if world == 1 and not any(g == -1 for g in grid):
         # The same setup once more in this context (what every later setup of a process costs, e.g. one per HMC trajectory):
         # `setup_seconds` above is the first setup of the context and, on a freshly started box, also pays for device memory no
-        # process has allocated before (13-30 ms per GB) -- the two are reported side by side.
+        # process has allocated before (13-30 ms per GB, docs/design/09_rounds_2_3.md) -- the two are reported side by side.
         try:
             t0 = time.perf_counter(); ctx.setup(q.setup_iter[0]); ctx.sync(); res["setup_seconds_repeated"] = time.perf_counter() - t0
             it3, cit3, rr3 = ctx.solve_vec(xv, bv, 1e-10)

@@ -746,7 +746,7 @@ void Multigrid<T>::build_coarse_operator(int l) {
         // the lattice in slabs of whole aggregates -- D P and its restriction are local to an aggregate.
         // The slab is no larger than what the bootstrap borrows (Nvec fine vectors) or 512 aggregates: the time of a build does
         // not depend on the slab size from 512 aggregates on, and memory that is never allocated need not be mapped -- the first
-        // process on a freshly started box pays ~20-40 ms per GB of never-used device memory
+        // process on a freshly started box pays ~20-40 ms per GB of never-used device memory (docs/design/09_rounds_2_3.md)
         const size_t per_agg = sizeof(T) * 2 * N * wcol_agg;
         const size_t coarse_b = sizeof(T) * 5 * 2 * N * cs;           // gal_C_: all columns on the coarse lattice
         DDAMG_REQUIRE(coarse_b + per_agg < free_b, "Galerkin construction: not enough device memory for the coarse columns and one aggregate of fields");

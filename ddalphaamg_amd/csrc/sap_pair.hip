@@ -588,7 +588,7 @@ void sap_pair_launch(const SapPairArgs& a_in, bool dist, hipStream_t st) {
   const SapPairArgs& a = a_in;
 #endif
   // blocks per workgroup: 2 (lockstep pair with complementary wavefront roles) or 1 (two independent workgroups per CU,
-  // whose load and compute phases drift apart and overlap); DDAMG_SAP_BLOCKS_PER_WG selects, see DESIGN.md for the numbers
+  // whose load and compute phases drift apart and overlap); DDAMG_SAP_BLOCKS_PER_WG selects, see docs/design/04a_schwarz_block_solver.md for the numbers
   static const int nb = [] { const char* e = getenv("DDAMG_SAP_BLOCKS_PER_WG"); return e ? atoi(e) : 1; }();
   if (nb == 2) {
     const int grid = (a.nblocks + 1) / 2;

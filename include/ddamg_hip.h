@@ -247,7 +247,8 @@ int ddamg_hip_comm_init_host(ddamg_hip_ctx* ctx, ddamg_hip_exchange_fn fn, ddamg
 /* What this process sent since the last reset, as a JSON object owned by the context (valid until the next call): halo exchanges
  * grouped by payload (bytes per face site: 48 = fp32 half spinor of the fine level, 96 = its fp64 form, 8 n = a coarse level with
  * n dof), messages and bytes; global sums and all-gathers with the time their collectives took on the transport stream (RCCL).
- * reset != 0 clears the counters and returns "{}".  For reading a multi-GPU run against the message table of DESIGN. */
+ * reset != 0 clears the counters and returns "{}".  For reading a multi-GPU run against the message table of
+ * docs/design/06a_rehearsal_and_messages.md. */
 const char* ddamg_hip_comm_stats(ddamg_hip_ctx* ctx, int reset);
 /* host-only helper (no GPU needed): the halo plan of one process.  For face d (0..3: +mu face sending to
  * +mu, 4..7: -mu face) returns the neighbour rank and, if lex_sites != NULL, the local lexicographic index

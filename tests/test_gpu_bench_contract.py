@@ -117,7 +117,7 @@ def test_rehearsal_of_the_eight_gpu_point_on_one_gpu():
     assert h["predicted_seconds_per_solve_per_gpu"] >= h["seconds_per_solve_per_gpu"] > 0
     assert abs(h["predicted_speedup_vs_n1"] - s["seconds_per_solve"] / h["predicted_seconds_per_solve_per_gpu"]) < 1e-9
     assert h["coarsest_level"]["gathered_sites_on_n_gpus"] == 8 * h["coarsest_level"]["rehearsed_sites"]
-    # what this "rank" sent during the timed solve, payload by payload (to be read against DESIGN's message table)
+    # what this "rank" sent during the timed solve, payload by payload (to be read against the message table of docs/design/06a_rehearsal_and_messages.md)
     m = h["messages"]
     kinds = {e["bytes_per_face_site"]: e for e in m["halo_exchanges"]}
     assert m["transport"] == "rccl" and kinds[48]["messages"] == 6 * kinds[48]["exchanges"]        # three split directions

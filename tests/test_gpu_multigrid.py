@@ -392,7 +392,7 @@ def test_setup_and_solve_with_256_site_blocks_vs_reference(gold_b4, gold8):
 
 def test_slab_wise_galerkin_construction_is_the_same_operator(gold_b4, gold8, monkeypatch):
     """volumes whose Galerkin workspace does not hold all columns for the whole lattice (64^4) walk the lattice in slabs of
-    whole aggregates with ALL columns; forced here with slabs of 5 of the 16 aggregates (an uneven last slab):
+    whole aggregates with ALL columns (docs/design/05_host.md); forced here with slabs of 5 of the 16 aggregates (an uneven last slab):
     the coarse operator, and with it every number of the solve, must not change"""
     res = []
     for slabs in (None, "5"):
@@ -412,7 +412,7 @@ def test_slab_wise_galerkin_construction_is_the_same_operator(gold_b4, gold8, mo
 @pytest.mark.parametrize("slabs", [None, "5"], ids=["whole-lattice", "slabs"])
 def test_face_compacted_galerkin_fields_give_the_same_operator(gold_b4, gold8, monkeypatch, slabs):
     """the four forward parts of D P are zero away from the aggregate faces; the Galerkin construction keeps and restricts them
-    on the face sites only, and builds them on 256-site tiles through LDS.  Against the five full fields per column
+    on the face sites only, and builds them on 256-site tiles through LDS (docs/design/05_host.md).  Against the five full fields per column
     (DDAMG_GALERKIN_FULL_FIELDS) and against the gather form of the field kernel (DDAMG_AGGREGATE_DIRAC_GATHER): the same
     coarse operator up to the rounding of another summation order, the same solve; against the restriction's results passing
     through coarse column vectors (DDAMG_GALERKIN_STORE_COLUMNS): identical"""
@@ -443,7 +443,7 @@ def test_face_compacted_galerkin_fields_give_the_same_operator(gold_b4, gold8, m
 
 def test_bootstrap_with_one_restriction_and_one_interpolation_for_all_test_vectors(gold_b4, gold8, monkeypatch):
     """the setup's bootstrap V-cycles of the fine level share their two passes over the interpolation operator (restriction
-    on the matrix cores, batched interpolation).  Against the vector-by-vector form (DDAMG_BOOTSTRAP_UNBATCHED):
+    on the matrix cores, batched interpolation; docs/design/05_host.md).  Against the vector-by-vector form (DDAMG_BOOTSTRAP_UNBATCHED):
     the same test vectors up to the rounding of a different summation order, the same solve"""
     res = []
     for unbatched in (None, "1"):
