@@ -783,11 +783,11 @@ void Multigrid<T>::build_coarse_operator(int l) {
         const size_t wss = (size_t)24 * na * as;        // one field of this slab
         if (compact) {
           for (int c = 0; c < 2 * N; c++)
-            aggregate_dirac_compact<T>(Wb + (size_t)c * na * wcol_agg, lv.fip.interp_vector(c % N), c / N, *lv.fop, lv.d_agg_face, af, a0, na, st_);
+            aggregate_dirac_compact<T>(Wb + (size_t)c * na * wcol_agg, interpolation_column(lv.fip, c % N), c / N, *lv.fop, lv.d_agg_face, af, a0, na, st_);
           lv.fip.restrict_batch_compact(Cb, cs, Wb, 2 * N, af, a0, na, st_, direct ? nx.cop.matrices() : nullptr, nx.cop.nt(), nx.cop.msize(), 0);
         } else {
           for (int c = 0; c < 2 * N; c++)
-            aggregate_dirac_slab<T>(Wb + (size_t)5 * c * wss, lv.fip.interp_vector(c % N), c / N, *lv.fop, lv.d_agg_face, (size_t)a0 * as, (size_t)na * as, st_);
+            aggregate_dirac_slab<T>(Wb + (size_t)5 * c * wss, interpolation_column(lv.fip, c % N), c / N, *lv.fop, lv.d_agg_face, (size_t)a0 * as, (size_t)na * as, st_);
           lv.fip.restrict_batch_slab(Cb, cs, Wb, wss, 5 * 2 * N, a0, na, st_);
         }
       }
@@ -797,11 +797,11 @@ void Multigrid<T>::build_coarse_operator(int l) {
       const int nb = std::min(batch, 2 * N - c0);
       if (compact) {
         for (int c = 0; c < nb; c++)
-          aggregate_dirac_compact<T>(Wb + (size_t)c * wcol, lv.fip.interp_vector((c0 + c) % N), (c0 + c) / N, *lv.fop, lv.d_agg_face, af, 0, nagg, st_);
+          aggregate_dirac_compact<T>(Wb + (size_t)c * wcol, interpolation_column(lv.fip, (c0 + c) % N), (c0 + c) / N, *lv.fop, lv.d_agg_face, af, 0, nagg, st_);
         lv.fip.restrict_batch_compact(Cb, cs, Wb, nb, af, 0, nagg, st_, direct ? nx.cop.matrices() : nullptr, nx.cop.nt(), nx.cop.msize(), c0);
       } else {
         for (int c = 0; c < nb; c++)
-          aggregate_dirac<T>(Wb + (size_t)5 * c * ws, lv.fip.interp_vector((c0 + c) % N), (c0 + c) / N, *lv.fop, lv.d_agg_face, st_);
+          aggregate_dirac<T>(Wb + (size_t)5 * c * ws, interpolation_column(lv.fip, (c0 + c) % N), (c0 + c) / N, *lv.fop, lv.d_agg_face, st_);
         lv.fip.restrict_batch(Cb, cs, Wb, ws, 5 * nb, st_);
       }
       if (!direct) for (int c = 0; c < nb; c++) galerkin_store_column<T>(nx.cop, Cb + (size_t)5 * c * cs, c0 + c, st_);
@@ -810,7 +810,7 @@ void Multigrid<T>::build_coarse_operator(int l) {
     for (int chir = 0; chir < 2; chir++)
       for (int j = 0; j < N; j++) {
         if (!W_) DDAMG_HIP_CHECK(device_alloc(&W_, sizeof(T) * lv_[0]->nel * 5));
-        aggregate_dirac<T>(W_, lv.fip.interp_vector(j), chir, *lv.fop, lv.d_agg_face, st_);
+        aggregate_dirac<T>(W_, interpolation_column(lv.fip, j), chir, *lv.fop, lv.d_agg_face, st_);
         galerkin_column<T>(nx.cop, lv.fip, W_, chir * N + j, cwork_, st_);
       }
   } else if constexpr (sizeof(T) == 4) {
@@ -1088,7 +1088,8 @@ void Multigrid<T>::import_interpolation(const double* P_lex_host) {
   MGLevel<T>& lv = *lv_[0];
   for (int k = 0; k < lv.nvec; k++) {
     DDAMG_HIP_CHECK(hipMemcpyAsync(d_stage_, P_lex_host + (size_t)k * lv.nel, sizeof(double) * lv.nel, hipMemcpyHostToDevice, st_));
-    vec_from_lex<T>(lv.fip.interp_vector(k), d_stage_, d_lex0_, lv.g->V, 12, st_);
+    vec_from_lex<T>(lv.buf[0], d_stage_, d_lex0_, lv.g->V, 12, st_);
+    lv.fip.set_column(k, lv.buf[0], st_);       // P is stored aggregate by aggregate (transfer.hip)
     DDAMG_HIP_CHECK(hipStreamSynchronize(st_));
   }
   p_orthonormal_ = false;  // "as they are": the caller's vectors need not be orthonormal on the aggregates

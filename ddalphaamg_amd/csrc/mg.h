@@ -165,7 +165,6 @@ class Multigrid {
   void bootstrap(int l, int iters);     // inv_iter_inv_fcycle_PRECISION
   bool bootstrap_vcycles_batched();     // the fine level's Nvec V-cycles with ONE restriction and ONE interpolation for all of them
   T* test_vector(int l, int j) { return l == 0 ? lv_[0]->fip.test_vector(j) : lv_[l]->cip.test_vector(j); }
-  T* interp_vector(int l, int j) { return l == 0 ? lv_[0]->fip.interp_vector(j) : lv_[l]->cip.interp_vector(j); }
   T* tv_base(int l) { return l == 0 ? lv_[0]->fip.tv : lv_[l]->cip.tv; }
   size_t tv_stride(int l) { return l == 0 ? lv_[0]->fip.pstride : lv_[l]->cip.pstride; }
 };

@@ -4,6 +4,14 @@
 
 namespace ddamg {
 
+// NR reals of site s of the input column, from its real number `first` on (a multiple of the chunk width).  One form for both
+// kinds of column: a vector in lattice order is the one "aggregate" of V sites.
+template <typename T, int NR>
+__device__ __forceinline__ void load_column(const ColumnView<T>& c, size_t s, T (&out)[NR], int first = 0) {
+  const size_t a = s / (size_t)c.agg_sites;
+  load_site<T, NR>(c.base + a * c.chunk + (size_t)first * c.plane, c.plane, s - a * (size_t)c.agg_sites, out);
+}
+
 template <typename T>
 __device__ __forceinline__ void mask_chirality(T (&v)[24], int chir) {
 #pragma unroll
@@ -13,7 +21,7 @@ __device__ __forceinline__ void mask_chirality(T (&v)[24], int chir) {
 // W holds the sites [w0site, w0site + Vw) of the lattice only (Vw == V, w0site == 0: the whole lattice).
 // COMPACT: the forward part of direction MU is kept on the face sites only (AggFaces: aggregate `wagg` of W, local site `li`)
 template <typename T, int MU, bool DIST, bool COMPACT>
-__device__ __forceinline__ void agg_hop_pair(const T* __restrict__ v, int chir, const FineOpDev<T>& op, const unsigned char face,
+__device__ __forceinline__ void agg_hop_pair(const ColumnView<T>& v, int chir, const FineOpDev<T>& op, const unsigned char face,
                                              size_t s, T (&w0)[24], T* __restrict__ W, size_t wstride, size_t Vw, size_t w0site,
                                              const AggFaces& af, size_t wagg, int li, size_t naggs) {
   const size_t V = op.V;
@@ -22,7 +30,7 @@ __device__ __forceinline__ void agg_hop_pair(const T* __restrict__ v, int chir, 
     T pn[24], U[18];
     // (a neighbour on another process has no site here: the load reads this site instead and its value is not used -- a
     // conditional load leaves pn partly undefined and the compiler then keeps it in scratch memory: 975 against 571 us)
-    load_site<T, 24>(v, V, (DIST && j < 0) ? s : (size_t)j, pn);
+    load_column<T, 24>(v, (DIST && j < 0) ? s : (size_t)j, pn);
     mask_chirality<T>(pn, chir);
     load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, s, U);
     if (face & (1u << MU)) {
@@ -54,7 +62,7 @@ __device__ __forceinline__ void agg_hop_pair(const T* __restrict__ v, int chir, 
   if (!(face & (1u << (4 + MU)))) {
     const int j = op.nb[(size_t)(4 + MU) * V + s];
     T pn[24], U[18];
-    load_site<T, 24>(v, V, j, pn);
+    load_column<T, 24>(v, (size_t)j, pn);
     mask_chirality<T>(pn, chir);
     load_site<T, 18>(op.D + (size_t)MU * 18 * V, V, j, U);
     hop_accumulate<T, MU, false>(U, pn, w0);
@@ -62,7 +70,7 @@ __device__ __forceinline__ void agg_hop_pair(const T* __restrict__ v, int chir, 
 }
 
 template <typename T, bool DIST, bool COMPACT>
-__global__ __launch_bounds__(256) void aggregate_dirac_kernel(T* __restrict__ W, const T* __restrict__ v, int chir, FineOpDev<T> op,
+__global__ __launch_bounds__(256) void aggregate_dirac_kernel(T* __restrict__ W, const ColumnView<T> v, int chir, FineOpDev<T> op,
                                                               const unsigned char* __restrict__ agg_face, size_t w0site, size_t Vw, AggFaces af) {
   const size_t s = w0site + (size_t)blockIdx.x * 256 + threadIdx.x;
   const size_t V = op.V;
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(256) void aggregate_dirac_kernel(T* __restrict__ W,
   T w0[24];
   {
     T p[24], cl[36];
-    load_site<T, 24>(v, V, s, p);
+    load_column<T, 24>(v, s, p);
 #pragma unroll
     for (int k = 0; k < 24; k++) w0[k] = 0;
     if (chir == 0) { load_site<T, 36>(op.clover, V, s, cl); herm6_mul<T>(cl, p, w0); }
@@ -100,7 +108,7 @@ __global__ __launch_bounds__(256) void aggregate_dirac_kernel(T* __restrict__ W,
 // memory (a quarter of the sites per direction with 4^4 aggregates; a neighbour inside the aggregate but outside the tile
 // too, for aggregates larger than a tile).  CHIR is a template parameter so that the zero half of the input folds away.
 template <typename T, int MU, int CHIR, bool CMP, bool DIST>
-__device__ __forceinline__ void agg_tile_dir(const T* __restrict__ vh, const FineOpDev<T>& op, const unsigned face, size_t s, bool live, size_t tile0,
+__device__ __forceinline__ void agg_tile_dir(const ColumnView<T>& v, const FineOpDev<T>& op, const unsigned face, size_t s, bool live, size_t tile0,
                                              const T (&p)[24], T (&e)[24], const T* __restrict__ sp, T* __restrict__ hb,
                                              T* __restrict__ W, const AggFaces& af, size_t wagg, int li, size_t naggs) {
   const size_t V = op.V;
@@ -131,7 +139,7 @@ __device__ __forceinline__ void agg_tile_dir(const T* __restrict__ vh, const Fin
       for (int c = 0; c < 12; c++) pn[12 * CHIR + c] = sp[c * 256 + (int)(j - tile0)];
     } else {
       T ph[12];
-      load_site<T, 12>(vh, V, j, ph);
+      load_column<T, 12>(v, j, ph, 12 * CHIR);
 #pragma unroll
       for (int c = 0; c < 12; c++) pn[12 * CHIR + c] = ph[c];
     }
@@ -139,9 +147,18 @@ __device__ __forceinline__ void agg_tile_dir(const T* __restrict__ vh, const Fin
       T acc[24];
 #pragma unroll
       for (int k = 0; k < 24; k++) acc[k] = 0;
-      if (remote) halo_forward<T, MU>(op, -1 - jn, U, acc);
-      else
       hop_accumulate<T, MU, true>(U, pn, acc);  // acc = -hop
+      // (the product for every site, then the remote sites replace it: as `if (remote) halo_forward(..) else hop_accumulate(..)`
+      // the distributed instantiation of this kernel came out of hipcc 7.2.0 with wrong spin-1 components in the Y and X parts
+      // once the column loads went through ColumnView -- every site, also with no remote neighbour in those directions; found by
+      // tests/test_gpu_self_exchange.py, pinned there against the undivided construction)
+      if constexpr (DIST) {
+        if (remote) {
+#pragma unroll
+          for (int k = 0; k < 24; k++) acc[k] = 0;
+          halo_forward<T, MU>(op, -1 - jn, U, acc);
+        }
+      }
 #pragma unroll
       for (int k = 0; k < 24; k++) acc[k] = -acc[k];
       store_site<T, 24>(W + (size_t)24 * af.part_offset_sites(1 + MU, naggs), naggs * (size_t)af.nface[MU],
@@ -161,7 +178,7 @@ __device__ __forceinline__ void agg_tile_dir(const T* __restrict__ vh, const Fin
       spin_reconstruct_sub<T, MU, +1>(g, e);
     } else {
       T pn[24], ph[12], Un[18];
-      load_site<T, 12>(vh, V, j, ph);
+      load_column<T, 12>(v, j, ph, 12 * CHIR);
 #pragma unroll
       for (int c = 0; c < 12; c++) { pn[12 * CHIR + c] = ph[c]; pn[12 * (1 - CHIR) + c] = 0; }
       load_link<T, MU, CMP>(op, V, j, Un);
@@ -172,7 +189,7 @@ __device__ __forceinline__ void agg_tile_dir(const T* __restrict__ vh, const Fin
 }
 
 template <typename T, int CHIR, bool CMP, bool DIST>
-__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) void aggregate_dirac_tile_kernel(T* __restrict__ W, const T* __restrict__ v, FineOpDev<T> op,
+__global__ __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) void aggregate_dirac_tile_kernel(T* __restrict__ W, const ColumnView<T> v, FineOpDev<T> op,
                                                                                              const unsigned char* __restrict__ agg_face, size_t w0site, size_t Vw,
                                                                                              AggFaces af) {
   __shared__ T sp[12 * 256];
@@ -181,7 +198,6 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) void aggregate_dirac
   const size_t tile0 = w0site + (size_t)blockIdx.x * 256;
   const size_t s = tile0 + threadIdx.x;
   const bool live = s < w0site + Vw;
-  const T* __restrict__ vh = v + (size_t)12 * CHIR * V;      // the chirality half: chunk rows 3 CHIR .. 3 CHIR + 2
   unsigned face = 0;
   size_t wagg = 0;
   int li = 0;
@@ -194,27 +210,40 @@ __global__ __launch_bounds__(256, (sizeof(T) == 4 ? 3 : 2)) void aggregate_dirac
     wagg = (s - w0site) / (size_t)af.agg_sites;
     li = (int)((s - w0site) - wagg * (size_t)af.agg_sites);
     T ph[12], cl[36];
-    load_site<T, 12>(vh, V, s, ph);
+    load_column<T, 12>(v, s, ph, 12 * CHIR);      // the chirality half: reals 12 CHIR .. 12 CHIR + 11
 #pragma unroll
     for (int c = 0; c < 12; c++) { p[12 * CHIR + c] = ph[c]; sp[c * 256 + threadIdx.x] = ph[c]; }
     load_site<T, 36>(op.clover + (size_t)36 * CHIR * V, V, s, cl);
     herm6_mul<T>(cl, p + 12 * CHIR, e + 12 * CHIR);
   }
   __syncthreads();
-  agg_tile_dir<T, 0, CHIR, CMP, DIST>(vh, op, face, s, live, tile0, p, e, sp, hb, W, af, wagg, li, naggs);
-  agg_tile_dir<T, 1, CHIR, CMP, DIST>(vh, op, face, s, live, tile0, p, e, sp, hb + 12 * 256, W, af, wagg, li, naggs);
-  agg_tile_dir<T, 2, CHIR, CMP, DIST>(vh, op, face, s, live, tile0, p, e, sp, hb, W, af, wagg, li, naggs);
-  agg_tile_dir<T, 3, CHIR, CMP, DIST>(vh, op, face, s, live, tile0, p, e, sp, hb + 12 * 256, W, af, wagg, li, naggs);
+  agg_tile_dir<T, 0, CHIR, CMP, DIST>(v, op, face, s, live, tile0, p, e, sp, hb, W, af, wagg, li, naggs);
+  agg_tile_dir<T, 1, CHIR, CMP, DIST>(v, op, face, s, live, tile0, p, e, sp, hb + 12 * 256, W, af, wagg, li, naggs);
+  agg_tile_dir<T, 2, CHIR, CMP, DIST>(v, op, face, s, live, tile0, p, e, sp, hb, W, af, wagg, li, naggs);
+  agg_tile_dir<T, 3, CHIR, CMP, DIST>(v, op, face, s, live, tile0, p, e, sp, hb + 12 * 256, W, af, wagg, li, naggs);
   if (live) store_site<T, 24>(W, Vw, s - w0site, e);
 }
 
+// the chirality-masked copy of a column as a vector in lattice order (what a process sends the boundary of to its neighbours)
 template <typename T>
-void aggregate_dirac(T* W, const T* v, int chir, const FineOp<T>& op, const unsigned char* d_agg_face, hipStream_t st) {
+__global__ void column_chirality_kernel(T* __restrict__ out, const ColumnView<T> v, int chir, size_t V) {
+  const size_t s = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= V) return;
+  T p[24];
+  load_column<T, 24>(v, s, p);
+  mask_chirality<T>(p, chir);
+  store_site<T, 24>(out, V, s, p);
+}
+template <typename T>
+static void column_chirality_copy(T* out, const ColumnView<T>& v, int chir, size_t V, hipStream_t st) {
+  hipLaunchKernelGGL(column_chirality_kernel<T>, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, st, out, v, chir, V);
+}
+
+template <typename T>
+void aggregate_dirac(T* W, const ColumnView<T>& v, int chir, const FineOp<T>& op, const unsigned char* d_agg_face, hipStream_t st) {
   if (op.distributed()) {
     // W[0] serves as scratch for the chirality-masked copy whose boundary is sent to the neighbours
-    const size_t half = (size_t)12 * op.V();
-    DDAMG_HIP_CHECK(hipMemcpyAsync(W + chir * half, v + chir * half, sizeof(T) * half, hipMemcpyDeviceToDevice, st));
-    DDAMG_HIP_CHECK(hipMemsetAsync(W + (1 - chir) * half, 0, sizeof(T) * half, st));
+    column_chirality_copy<T>(W, v, chir, (size_t)op.V(), st);
     op.halo_exchange(W, st);
     hipLaunchKernelGGL((aggregate_dirac_kernel<T, true, false>), dim3((op.V() + 255) / 256), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face, (size_t)0, (size_t)op.V(), AggFaces{});
   } else {
@@ -224,16 +253,16 @@ void aggregate_dirac(T* W, const T* v, int chir, const FineOp<T>& op, const unsi
 }
 
 template <typename T>
-void aggregate_dirac_slab(T* W, const T* v, int chir, const FineOp<T>& op, const unsigned char* d_agg_face, size_t site0, size_t nsites, hipStream_t st) {
+void aggregate_dirac_slab(T* W, const ColumnView<T>& v, int chir, const FineOp<T>& op, const unsigned char* d_agg_face, size_t site0, size_t nsites, hipStream_t st) {
   DDAMG_REQUIRE(!op.distributed(), "the slab form of the Galerkin construction is a single-process path");
   hipLaunchKernelGGL((aggregate_dirac_kernel<T, false, false>), dim3((unsigned)((nsites + 255) / 256)), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face, site0, nsites, AggFaces{});
   DDAMG_HIP_CHECK(hipGetLastError());
 }
-template void aggregate_dirac_slab<float>(float*, const float*, int, const FineOp<float>&, const unsigned char*, size_t, size_t, hipStream_t);
-template void aggregate_dirac_slab<double>(double*, const double*, int, const FineOp<double>&, const unsigned char*, size_t, size_t, hipStream_t);
+template void aggregate_dirac_slab<float>(float*, const ColumnView<float>&, int, const FineOp<float>&, const unsigned char*, size_t, size_t, hipStream_t);
+template void aggregate_dirac_slab<double>(double*, const ColumnView<double>&, int, const FineOp<double>&, const unsigned char*, size_t, size_t, hipStream_t);
 
 template <typename T, bool DIST>
-static void launch_aggregate_dirac_tile(T* W, const T* v, int chir, const FineOp<T>& op, const unsigned char* d_agg_face, const AggFaces& af, size_t site0, size_t nsites,
+static void launch_aggregate_dirac_tile(T* W, const ColumnView<T>& v, int chir, const FineOp<T>& op, const unsigned char* d_agg_face, const AggFaces& af, size_t site0, size_t nsites,
                                         hipStream_t st) {
   const dim3 grid((unsigned)((nsites + 255) / 256));
   if (op.links_compressed()) {
@@ -246,15 +275,13 @@ static void launch_aggregate_dirac_tile(T* W, const T* v, int chir, const FineOp
 }
 
 template <typename T>
-void aggregate_dirac_compact(T* W, const T* v, int chir, const FineOp<T>& op, const unsigned char* d_agg_face, const AggFaces& af, int agg0, int naggs, hipStream_t st) {
+void aggregate_dirac_compact(T* W, const ColumnView<T>& v, int chir, const FineOp<T>& op, const unsigned char* d_agg_face, const AggFaces& af, int agg0, int naggs, hipStream_t st) {
   const size_t site0 = (size_t)agg0 * af.agg_sites, nsites = (size_t)naggs * af.agg_sites;
   const bool gather = getenv("DDAMG_AGGREGATE_DIRAC_GATHER") != nullptr;   // read at every call: tests switch it within one process
   if (op.distributed()) {
     DDAMG_REQUIRE(agg0 == 0 && nsites == (size_t)op.V(), "Galerkin construction on a process grid: whole lattice only");
     // the self part of the column serves as scratch for the chirality-masked copy whose boundary is sent to the neighbours
-    const size_t half = (size_t)12 * op.V();
-    DDAMG_HIP_CHECK(hipMemcpyAsync(W + chir * half, v + chir * half, sizeof(T) * half, hipMemcpyDeviceToDevice, st));
-    DDAMG_HIP_CHECK(hipMemsetAsync(W + (1 - chir) * half, 0, sizeof(T) * half, st));
+    column_chirality_copy<T>(W, v, chir, (size_t)op.V(), st);
     op.halo_exchange(W, st);
     if (gather) hipLaunchKernelGGL((aggregate_dirac_kernel<T, true, true>), dim3((unsigned)((nsites + 255) / 256)), dim3(256), 0, st, W, v, chir, op.dev(), d_agg_face, site0, nsites, af);
     else launch_aggregate_dirac_tile<T, true>(W, v, chir, op, d_agg_face, af, site0, nsites, st);
@@ -264,8 +291,8 @@ void aggregate_dirac_compact(T* W, const T* v, int chir, const FineOp<T>& op, co
   }
   DDAMG_HIP_CHECK(hipGetLastError());
 }
-template void aggregate_dirac_compact<float>(float*, const float*, int, const FineOp<float>&, const unsigned char*, const AggFaces&, int, int, hipStream_t);
-template void aggregate_dirac_compact<double>(double*, const double*, int, const FineOp<double>&, const unsigned char*, const AggFaces&, int, int, hipStream_t);
+template void aggregate_dirac_compact<float>(float*, const ColumnView<float>&, int, const FineOp<float>&, const unsigned char*, const AggFaces&, int, int, hipStream_t);
+template void aggregate_dirac_compact<double>(double*, const ColumnView<double>&, int, const FineOp<double>&, const unsigned char*, const AggFaces&, int, int, hipStream_t);
 
 // work: 5 coarse AoS vectors [part][Vc][n]; write column `col` of matrix `part` of every coarse site
 template <typename T>
@@ -300,8 +327,8 @@ void galerkin_store_column(CoarseOp<T>& cop, const T* work, int col, hipStream_t
 template void galerkin_store_column<float>(CoarseOp<float>&, const float*, int, hipStream_t);
 template void galerkin_store_column<double>(CoarseOp<double>&, const double*, int, hipStream_t);
 
-template void aggregate_dirac<float>(float*, const float*, int, const FineOp<float>&, const unsigned char*, hipStream_t);
-template void aggregate_dirac<double>(double*, const double*, int, const FineOp<double>&, const unsigned char*, hipStream_t);
+template void aggregate_dirac<float>(float*, const ColumnView<float>&, int, const FineOp<float>&, const unsigned char*, hipStream_t);
+template void aggregate_dirac<double>(double*, const ColumnView<double>&, int, const FineOp<double>&, const unsigned char*, hipStream_t);
 template void galerkin_column<float>(CoarseOp<float>&, const Interpolation<float>&, const float*, int, float*, hipStream_t);
 template void galerkin_column<double>(CoarseOp<double>&, const Interpolation<double>&, const double*, int, double*, hipStream_t);
 

@@ -324,8 +324,9 @@ int ddamg_hip_get_interpolation(ddamg_hip_ctx* c, double* P_lex) {
   const int nvec = c->par.num_vect[0];
   double* st = c->stage(sizeof(double) * nel);
   for (int k = 0; k < nvec; k++) {
-    if (c->mg32) vec_to_lex<float>(st, c->mg32->level(0).fip.interp_vector(k), c->levels[0]->d_lex_of_site, (int)V, 12, c->stream);
-    else vec_to_lex<double>(st, c->mg64->level(0).fip.interp_vector(k), c->levels[0]->d_lex_of_site, (int)V, 12, c->stream);
+    // P is stored aggregate by aggregate (transfer.hip): column k into a vector in lattice order first
+    if (c->mg32) { float* v = c->mg32->level(0).buf[0]; c->mg32->level(0).fip.get_column(k, v, c->stream); vec_to_lex<float>(st, v, c->levels[0]->d_lex_of_site, (int)V, 12, c->stream); }
+    else { double* v = c->mg64->level(0).buf[0]; c->mg64->level(0).fip.get_column(k, v, c->stream); vec_to_lex<double>(st, v, c->levels[0]->d_lex_of_site, (int)V, 12, c->stream); }
     DDAMG_HIP_CHECK(hipMemcpyAsync(P_lex + (size_t)k * nel, st, sizeof(double) * nel, hipMemcpyDeviceToHost, c->stream));
     DDAMG_HIP_CHECK(hipStreamSynchronize(c->stream));
   }

@@ -43,12 +43,19 @@ struct Interpolation {
   int V = 0, nvec = 0, num_aggs = 0, agg_sites = 0;
   size_t pstride = 0;      // elements between consecutive vectors
   T* tv = nullptr;         // test vectors   [nvec][24*V]
-  T* P = nullptr;          // orthonormalised interpolation vectors [nvec][24*V]
+  T* P = nullptr;          // orthonormalised interpolation vectors, aggregate by aggregate: [aggregate][nvec][24 * plane_sites()]
   int* agg_csite = nullptr; // [num_aggs] coarse-level site index of every aggregate
   void alloc(const Geometry& g, const Geometry& gc, int nvec_);
   void release();
   T* test_vector(int j) const { return tv + pstride * j; }
-  T* interp_vector(int j) const { return P + pstride * j; }
+  // column j of P from / into a vector in lattice order (import, export, the Galerkin construction's fall-back paths)
+  void set_column(int j, const T* vec, hipStream_t st);
+  void get_column(int j, T* vec, hipStream_t st) const;
+  // where the sites of aggregate a of column j start, and how a site vector is laid out there (see transfer.hip)
+  int plane_sites() const { return agg_sites; }      // sites per chunk row of an aggregate's block (p_block in transfer.hip)
+  size_t p_elems() const { return (size_t)num_aggs * nvec * 24 * plane_sites(); }
+  const T* column_block(int a, int j) const { return P + ((size_t)a * nvec + j) * 24 * plane_sites(); }
+  size_t row_sites() const { return (size_t)plane_sites(); }      // sites between two chunk rows of one vector
   // P <- tv, then modified Gram-Schmidt per aggregate and chirality
   void orthonormalize(hipStream_t st);
   // phi_c = P^dagger phi          (coarse AoS, n = 2*nvec complex per coarse site = aggregate)

@@ -12,6 +12,21 @@ static inline int wg_threads(int agg_sites) {
   return t;
 }
 
+// The interpolation operator is stored aggregate by aggregate -- [aggregate][vector][chunk row kk of 6][site of the aggregate][4
+// reals] -- so that everything a workgroup reads of it (all vectors on the sites of ITS aggregate: restriction, interpolation,
+// Gram-Schmidt on aggregates, the matrix-core transfers) is one contiguous piece of 96 Nvec agg_sites bytes instead of 6 Nvec
+// pieces 4 V and 24 V floats apart (32^4, Nvec 24: restriction 425 -> 410 us, interpolation 452 -> 412 us back to back,
+// profiles/r04_transfer_context.md).  p_block: the first element of vector j on aggregate a; inside it a site vector is laid out
+// like a lattice of `aps` = agg_sites sites (load_site / store_site with plane stride aps and the site's index in the aggregate).
+// Measured and not kept: 4 / 16 / 20 unused sites behind every chunk row (aps > agg_sites, so that rows do not start multiples of
+// 4 KB apart) and the order [aggregate][row][vector][site] -- neither moves the one kernel that lost with this layout, the
+// matrix-core restriction of 24 fields (1.40 -> 2.27 ms at 32^4, four launches per setup; same instructions, same bytes from
+// memory, fewer requests in flight: profiles/r04_transfer_context.md), and the second slows the two solve kernels (502 / 464 us).
+template <typename T>
+__device__ __forceinline__ T* p_block(T* P, int a, int j, int nvec, int aps) { return P + ((size_t)a * nvec + j) * 24 * aps; }
+// sites between two chunk rows of one vector
+__device__ __forceinline__ size_t p_plane(int nvec, int aps) { return (size_t)aps; }
+
 template <typename T>
 void Interpolation<T>::alloc(const Geometry& g, const Geometry& gc, int nvec_) {
   V = g.V; nvec = nvec_; num_aggs = g.num_aggs; agg_sites = g.agg_sites;
@@ -22,9 +37,9 @@ void Interpolation<T>::alloc(const Geometry& g, const Geometry& gc, int nvec_) {
   DDAMG_HIP_CHECK(hipMemcpy(agg_csite, gc.site_of_lex.data(), sizeof(int) * num_aggs, hipMemcpyHostToDevice));
   pstride = (size_t)24 * V;
   DDAMG_HIP_CHECK(device_alloc(&tv, sizeof(T) * pstride * nvec));
-  DDAMG_HIP_CHECK(device_alloc(&P, sizeof(T) * pstride * nvec));
+  DDAMG_HIP_CHECK(device_alloc(&P, sizeof(T) * p_elems()));
   DDAMG_HIP_CHECK(device_zero(tv, sizeof(T) * pstride * nvec));
-  DDAMG_HIP_CHECK(device_zero(P, sizeof(T) * pstride * nvec));
+  DDAMG_HIP_CHECK(device_zero(P, sizeof(T) * p_elems()));
 }
 template <typename T>
 void Interpolation<T>::release() {
@@ -38,8 +53,8 @@ void Interpolation<T>::release() {
 // NIN input vectors (stride in_stride / out_stride) are restricted in one pass over P.
 template <typename T, int NIN>
 __global__ void restrict_kernel(T* __restrict__ phi_c, size_t out_stride, const T* __restrict__ phi, size_t in_stride,
-                                const T* __restrict__ P, size_t pstride,
-                                int nvec, int V, int agg_sites, const int* __restrict__ agg_csite) {
+                                const T* __restrict__ P,
+                                int nvec, int V, int agg_sites, int aps, const int* __restrict__ agg_csite) {
   constexpr int TL = NIN == 1 ? TILE : 4;  // interpolation vectors per register tile
   __shared__ double red[4 * TL * NIN * 4];  // [value][wave]
   const int a = blockIdx.x, nt = blockDim.x;
@@ -57,7 +72,7 @@ __global__ void restrict_kernel(T* __restrict__ phi_c, size_t out_stride, const 
       for (int t = 0; t < TL; t++) {
         if (t < jt) {
           T p[24];
-          load_site<T, 24, true>(P + (size_t)(j0 + t) * pstride, V, s0 + i, p);
+          load_site<T, 24, true>(p_block(P, a, j0 + t, nvec, aps), p_plane(nvec, aps), i, p);
 #pragma unroll
           for (int m = 0; m < NIN; m++) {
             T f[24];
@@ -122,12 +137,12 @@ __global__ void restrict_kernel(T* __restrict__ phi_c, size_t out_stride, const 
 
 template <typename T>
 void Interpolation<T>::restrict_to(T* phi_c, const T* phi, hipStream_t st) const {
-  hipLaunchKernelGGL((restrict_kernel<T, 1>), dim3(num_aggs), dim3(wg_threads(agg_sites)), 0, st, phi_c, (size_t)0, phi, (size_t)0, P, pstride, nvec, V, agg_sites, agg_csite);
+  hipLaunchKernelGGL((restrict_kernel<T, 1>), dim3(num_aggs), dim3(wg_threads(agg_sites)), 0, st, phi_c, (size_t)0, phi, (size_t)0, P, nvec, V, agg_sites, plane_sites(), agg_csite);
   DDAMG_HIP_CHECK(hipGetLastError());
 }
 template <typename T>
 void Interpolation<T>::restrict5(T* phi_c, size_t out_stride, const T* phi, size_t in_stride, hipStream_t st) const {
-  hipLaunchKernelGGL((restrict_kernel<T, 5>), dim3(num_aggs), dim3(wg_threads(agg_sites)), 0, st, phi_c, out_stride, phi, in_stride, P, pstride, nvec, V, agg_sites, agg_csite);
+  hipLaunchKernelGGL((restrict_kernel<T, 5>), dim3(num_aggs), dim3(wg_threads(agg_sites)), 0, st, phi_c, out_stride, phi, in_stride, P, nvec, V, agg_sites, plane_sites(), agg_csite);
   DDAMG_HIP_CHECK(hipGetLastError());
 }
 
@@ -159,7 +174,7 @@ struct RestrictParts {
 // column tiles without padding (a 32-wide tile pair computes 64), 25 % fewer matrix-instruction cycles.
 template <int NTL, bool W16 = false>
 __global__ __launch_bounds__(256, (NTL == 2 ? 4 : NTL == 1 ? 3 : 2)) void restrict_mfma_kernel(float* __restrict__ out, size_t out_stride, const float* __restrict__ W, size_t wstride, int nw,
-                                                              const float* __restrict__ P, size_t pstride, int nvec, int V, int agg_sites,
+                                                              const float* __restrict__ P, int nvec, int V, int agg_sites, int aps,
                                                               const int* __restrict__ agg_csite, int a0, RestrictParts parts,
                                                               const unsigned short* __restrict__ site_list, int nparts, int naggs,
                                                               float* __restrict__ Mdirect, int nt2, size_t msize2, int col_base) {
@@ -184,7 +199,6 @@ __global__ __launch_bounds__(256, (NTL == 2 ? 4 : NTL == 1 ? 3 : 2)) void restri
   const size_t Vw = parts.Vw[part];
   W += parts.woff[part];
   out += parts.ooff[part];
-  const size_t s0 = (size_t)a * agg_sites;                  // first site of the aggregate in P
   const size_t w0 = (size_t)ai * ksites;                    // first K-site of the aggregate in W
   const int ntile = (nw + 31) >> 5;
   const int my_tile = KSPLIT ? wv % NTL : 0, my_kpart = KSPLIT ? wv / NTL : 0;
@@ -214,8 +228,8 @@ __global__ __launch_bounds__(256, (NTL == 2 ? 4 : NTL == 1 ? 3 : 2)) void restri
       for (int r = 0; r < 2; r++) {
         const int e = tid + 256 * r, i = e / KS, sl = e % KS;
         pa[r] = make_float4(0.f, 0.f, 0.f, 0.f);
-        const size_t site = s0 + (list ? (size_t)list[sb + sl] : (size_t)(sb + sl));
-        if (i < nvec) pa[r] = *reinterpret_cast<const float4*>(P + (size_t)i * pstride + ((size_t)kk * V + site) * 4);
+        const int site = list ? (int)list[sb + sl] : sb + sl;          // site of the aggregate
+        if (i < nvec) pa[r] = *reinterpret_cast<const float4*>(p_block(P, a, i, nvec, aps) + ((size_t)kk * p_plane(nvec, aps) + site) * 4);
       }
 #pragma unroll
       for (int r = 0; r < RB; r++) {
@@ -365,9 +379,14 @@ void Interpolation<T>::restrict_batch(T* phi_c, size_t out_stride, const T* phi,
   if constexpr (sizeof(T) == 4) {
     DDAMG_REQUIRE(restrict_batch_available(agg_sites, nvec) && nw >= 1 && nw <= 256, "batched restriction: unsupported shape");
     const RestrictParts parts = whole_aggregates((size_t)V, agg_sites);
-    if (nw <= 32) hipLaunchKernelGGL(restrict_mfma_kernel<1>, dim3(num_aggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
+    // up to 64 fields (the bootstrap's Nvec right-hand sides): the 16-wide tiles of the Galerkin construction's kernel; with P
+    // stored aggregate by aggregate they take 1.65 ms at 32^4, the 32-wide tile of round 3 (DDAMG_RESTRICT_BATCH_TILES_32) 2.25 ms
+    static const bool w16 = getenv("DDAMG_RESTRICT_BATCH_TILES_32") == nullptr;
+    if (nw <= 64 && w16) hipLaunchKernelGGL((restrict_mfma_kernel<2, true>), dim3(num_aggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, nvec, V, agg_sites, plane_sites(), agg_csite,
                                      0, parts, (const unsigned short*)nullptr, 1, num_aggs, (float*)nullptr, 0, (size_t)0, 0);
-    else hipLaunchKernelGGL(restrict_mfma_kernel<8>, dim3(num_aggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
+    else if (nw <= 32) hipLaunchKernelGGL(restrict_mfma_kernel<1>, dim3(num_aggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, nvec, V, agg_sites, plane_sites(), agg_csite,
+                                     0, parts, (const unsigned short*)nullptr, 1, num_aggs, (float*)nullptr, 0, (size_t)0, 0);
+    else hipLaunchKernelGGL(restrict_mfma_kernel<8>, dim3(num_aggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, nvec, V, agg_sites, plane_sites(), agg_csite,
                             0, parts, (const unsigned short*)nullptr, 1, num_aggs, (float*)nullptr, 0, (size_t)0, 0);
     DDAMG_HIP_CHECK(hipGetLastError());
   } else {
@@ -379,7 +398,7 @@ void Interpolation<T>::restrict_batch_slab(T* phi_c, size_t out_stride, const T*
   if constexpr (sizeof(T) == 4) {
     DDAMG_REQUIRE(restrict_batch_available(agg_sites, nvec) && nw >= 1 && nw <= 256 && agg0 >= 0 && agg0 + naggs <= num_aggs, "batched restriction: unsupported shape");
     const RestrictParts parts = whole_aggregates((size_t)naggs * agg_sites, agg_sites);
-    hipLaunchKernelGGL(restrict_mfma_kernel<8>, dim3(naggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, pstride, nvec, V, agg_sites, agg_csite,
+    hipLaunchKernelGGL(restrict_mfma_kernel<8>, dim3(naggs), dim3(256), 0, st, phi_c, out_stride, phi, in_stride, nw, P, nvec, V, agg_sites, plane_sites(), agg_csite,
                        agg0, parts, (const unsigned short*)nullptr, 1, num_aggs, (float*)nullptr, 0, (size_t)0, 0);
     DDAMG_HIP_CHECK(hipGetLastError());
   } else {
@@ -405,11 +424,11 @@ void Interpolation<T>::restrict_batch_compact(T* phi_c, size_t out_stride, const
     }
     const size_t wstride = (size_t)24 * af.column_sites(naggs);
     const dim3 grid((unsigned)((naggs + 7) / 8 * 8 * 5));
-    if (ncols <= 32) hipLaunchKernelGGL(restrict_mfma_kernel<1>, grid, dim3(256), 0, st, phi_c, 5 * out_stride, W, wstride, ncols, P, pstride, nvec, V, agg_sites, agg_csite,
+    if (ncols <= 32) hipLaunchKernelGGL(restrict_mfma_kernel<1>, grid, dim3(256), 0, st, phi_c, 5 * out_stride, W, wstride, ncols, P, nvec, V, agg_sites, plane_sites(), agg_csite,
                                         agg0, parts, af.list, 5, naggs, (float*)Mdirect, nt2, msize2, col_base);
-    else if (getenv("DDAMG_RESTRICT_TILES_32")) hipLaunchKernelGGL(restrict_mfma_kernel<2>, grid, dim3(256), 0, st, phi_c, 5 * out_stride, W, wstride, ncols, P, pstride, nvec, V, agg_sites, agg_csite,
+    else if (getenv("DDAMG_RESTRICT_TILES_32")) hipLaunchKernelGGL(restrict_mfma_kernel<2>, grid, dim3(256), 0, st, phi_c, 5 * out_stride, W, wstride, ncols, P, nvec, V, agg_sites, plane_sites(), agg_csite,
                             agg0, parts, af.list, 5, naggs, (float*)Mdirect, nt2, msize2, col_base);
-    else hipLaunchKernelGGL((restrict_mfma_kernel<2, true>), grid, dim3(256), 0, st, phi_c, 5 * out_stride, W, wstride, ncols, P, pstride, nvec, V, agg_sites, agg_csite,
+    else hipLaunchKernelGGL((restrict_mfma_kernel<2, true>), grid, dim3(256), 0, st, phi_c, 5 * out_stride, W, wstride, ncols, P, nvec, V, agg_sites, plane_sites(), agg_csite,
                             agg0, parts, af.list, 5, naggs, (float*)Mdirect, nt2, msize2, col_base);
     DDAMG_HIP_CHECK(hipGetLastError());
   } else {
@@ -419,8 +438,8 @@ void Interpolation<T>::restrict_batch_compact(T* phi_c, size_t out_stride, const
 
 // ---- interpolation: phi(x,d) (+)= sum_j P_j(x,d) phi_c[a][h(d)*N + j] -------------------------------
 template <typename T>
-__global__ void interpolate_kernel(T* __restrict__ phi, const T* __restrict__ phi_c, const T* __restrict__ P, size_t pstride,
-                                   int nvec, int V, int agg_sites, int add, const int* __restrict__ agg_csite) {
+__global__ void interpolate_kernel(T* __restrict__ phi, const T* __restrict__ phi_c, const T* __restrict__ P,
+                                   int nvec, int V, int agg_sites, int aps, int add, const int* __restrict__ agg_csite) {
   extern __shared__ char smem_raw[];
   T* pc = reinterpret_cast<T*>(smem_raw);  // [2*nvec][2]
   const int a = blockIdx.x, nt = blockDim.x;
@@ -434,9 +453,13 @@ __global__ void interpolate_kernel(T* __restrict__ phi, const T* __restrict__ ph
 #pragma unroll
       for (int k = 0; k < 24; k++) f[k] = 0;
     }
+#ifndef DDAMG_INTERP_UNROLL
+#define DDAMG_INTERP_UNROLL 2      // two vectors of P in flight per thread (12 loads): 441-459 -> 429-435 us at 32^4; four: 464-469 us
+#endif
+#pragma unroll DDAMG_INTERP_UNROLL
     for (int j = 0; j < nvec; j++) {
       T p[24];
-      load_site<T, 24, true>(P + (size_t)j * pstride, V, s0 + i, p);
+      load_site<T, 24, true>(p_block(P, a, j, nvec, aps), p_plane(nvec, aps), i, p);
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const T cr = pc[2 * (h * nvec + j)], ci = pc[2 * (h * nvec + j) + 1];
@@ -455,7 +478,7 @@ __global__ void interpolate_kernel(T* __restrict__ phi, const T* __restrict__ ph
 template <typename T>
 void Interpolation<T>::interpolate(T* phi, const T* phi_c, bool add, hipStream_t st) const {
   hipLaunchKernelGGL(interpolate_kernel<T>, dim3(num_aggs), dim3(wg_threads(agg_sites)), sizeof(T) * 4 * nvec, st,
-                     phi, phi_c, P, pstride, nvec, V, agg_sites, add ? 1 : 0, agg_csite);
+                     phi, phi_c, P, nvec, V, agg_sites, plane_sites(), add ? 1 : 0, agg_csite);
   DDAMG_HIP_CHECK(hipGetLastError());
 }
 
@@ -465,7 +488,7 @@ void Interpolation<T>::interpolate(T* phi, const T* phi_c, bool add, hipStream_t
 // aggregate sit in LDS and are read as broadcasts.
 template <int NR>
 __global__ __launch_bounds__(256) void interpolate_batch_kernel(float* __restrict__ out, size_t out_stride, const float* __restrict__ cvec, size_t c_stride, int nrhs,
-                                                                const float* __restrict__ P, size_t pstride, int nvec, int V, int agg_sites,
+                                                                const float* __restrict__ P, int nvec, int V, int agg_sites, int aps,
                                                                 const int* __restrict__ agg_csite) {
   extern __shared__ float2 cf_lds[];   // [2*nvec][NR]
   const int a = blockIdx.x;
@@ -485,7 +508,7 @@ __global__ __launch_bounds__(256) void interpolate_batch_kernel(float* __restric
     for (int w = 0; w < NR; w++) acc[w] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j = 0; j < nvec; j++) {
       typedef float f4v __attribute__((ext_vector_type(4)));
-      const f4v pv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(P + (size_t)j * pstride + off));
+      const f4v pv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p_block(P, a, j, nvec, aps) + ((size_t)chunk * p_plane(nvec, aps) + i) * 4));
       const float4 p = make_float4(pv[0], pv[1], pv[2], pv[3]);
       const float2* cj = cf_lds + (size_t)(h * nvec + j) * NR;
 #pragma unroll
@@ -506,9 +529,9 @@ void Interpolation<T>::interpolate_batch(T* out, size_t out_stride, const T* phi
   if constexpr (sizeof(T) == 4) {
     DDAMG_REQUIRE(interpolate_batch_available(agg_sites, nvec, nrhs), "batched interpolation: unsupported shape");
     if (nrhs <= 24) hipLaunchKernelGGL(interpolate_batch_kernel<24>, dim3(num_aggs), dim3(256), sizeof(float2) * 2 * nvec * 24, st, out, out_stride, phi_c, c_stride, nrhs,
-                                       P, pstride, nvec, V, agg_sites, agg_csite);
+                                       P, nvec, V, agg_sites, plane_sites(), agg_csite);
     else hipLaunchKernelGGL(interpolate_batch_kernel<32>, dim3(num_aggs), dim3(256), sizeof(float2) * 2 * nvec * 32, st, out, out_stride, phi_c, c_stride, nrhs,
-                            P, pstride, nvec, V, agg_sites, agg_csite);
+                            P, nvec, V, agg_sites, plane_sites(), agg_csite);
     DDAMG_HIP_CHECK(hipGetLastError());
   } else {
     DDAMG_REQUIRE(false, "batched interpolation is an fp32 path");
@@ -541,13 +564,39 @@ __device__ __forceinline__ void wg_allreduce(double (&v)[NV], double* red /* [NV
   }
 }
 
+// vectors in lattice order (vector j0 + blockIdx.y at vec + blockIdx.y * vstride) -> their columns of P (TO_P), or back
+template <typename T, bool TO_P>
+__global__ __launch_bounds__(256) void p_columns_kernel(T* __restrict__ P, T* __restrict__ vec, size_t vstride, int j0, int nvec, int V, int agg_sites, int aps) {
+  constexpr int CH = Chunk<T>::CH;
+  using cvec = typename Chunk<T>::vec;
+  const int a = blockIdx.x, j = j0 + blockIdx.y;
+  T* blk = p_block(P, a, j, nvec, aps);
+  T* v = vec + (size_t)blockIdx.y * vstride;
+  for (int e = threadIdx.x; e < (24 / CH) * agg_sites; e += 256) {
+    const int kk = e / agg_sites, i = e - kk * agg_sites;
+    cvec* in_p = reinterpret_cast<cvec*>(blk + ((size_t)kk * p_plane(nvec, aps) + i) * CH);
+    cvec* in_v = reinterpret_cast<cvec*>(v + ((size_t)kk * V + (size_t)a * agg_sites + i) * CH);
+    if (TO_P) *in_p = *in_v; else *in_v = *in_p;
+  }
+}
+template <typename T>
+void Interpolation<T>::set_column(int j, const T* vec, hipStream_t st) {
+  hipLaunchKernelGGL((p_columns_kernel<T, true>), dim3(num_aggs, 1), dim3(256), 0, st, P, const_cast<T*>(vec), (size_t)0, j, nvec, V, agg_sites, plane_sites());
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+template <typename T>
+void Interpolation<T>::get_column(int j, T* vec, hipStream_t st) const {
+  hipLaunchKernelGGL((p_columns_kernel<T, false>), dim3(num_aggs, 1), dim3(256), 0, st, P, vec, (size_t)0, j, nvec, V, agg_sites, plane_sites());
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
 // SPT = sites per thread (agg_sites <= 256*SPT).  CB = columns per pass: the projections of CB consecutive columns on an
 // earlier vector u do not depend on each other, so u is read once for all of them and their CB coefficients are summed in one
 // workgroup reduction; the columns of a pass then finish among themselves in registers.  Every column sees the same operations
 // in the same order as one column per pass (CB = 1) -- results are bit-identical -- with 1/CB of the reads of the earlier
 // vectors, which is what bounds this kernel (CB = 1: 27 GB through the L2 at 32^4, Nvec 24).
 template <typename T, int SPT, int CB>
-__global__ __launch_bounds__(256) void gs_aggregates_kernel(T* __restrict__ P, size_t pstride, int nvec, int V, int agg_sites) {
+__global__ __launch_bounds__(256) void gs_aggregates_kernel(T* __restrict__ P, const T* __restrict__ src, size_t sstride, int nvec, int V, int agg_sites, int aps) {
   __shared__ double red[4 * CB * 4];
   const int a = blockIdx.x, nt = blockDim.x, nw = nt >> 6;
   const size_t s0 = (size_t)a * agg_sites;
@@ -558,7 +607,7 @@ __global__ __launch_bounds__(256) void gs_aggregates_kernel(T* __restrict__ P, s
 #pragma unroll
       for (int q = 0; q < SPT; q++) {
         const int i = threadIdx.x + q * nt;
-        if (i < agg_sites && k0 + c < nvec) load_site<T, 24>(P + (size_t)(k0 + c) * pstride, V, s0 + i, v[c][q]);
+        if (i < agg_sites && k0 + c < nvec) load_site<T, 24>(src + (size_t)(k0 + c) * sstride, V, s0 + i, v[c][q]);    // the test vector, lattice order
         else {
 #pragma unroll
           for (int k = 0; k < 24; k++) v[c][q][k] = 0;
@@ -573,7 +622,7 @@ __global__ __launch_bounds__(256) void gs_aggregates_kernel(T* __restrict__ P, s
 #pragma unroll
       for (int q = 0; q < SPT; q++) {
         const int i = threadIdx.x + q * nt;
-        if (i < agg_sites) load_site<T, 24>(P + (size_t)k2 * pstride, V, s0 + i, u[q]);
+        if (i < agg_sites) load_site<T, 24>(p_block(P, a, k2, nvec, aps), p_plane(nvec, aps), i, u[q]);
         else {
 #pragma unroll
           for (int k = 0; k < 24; k++) u[q][k] = 0;
@@ -650,7 +699,7 @@ __global__ __launch_bounds__(256) void gs_aggregates_kernel(T* __restrict__ P, s
           const int i = threadIdx.x + q * nt;
 #pragma unroll
           for (int d = 0; d < 12; d++) { v[c][q][d] *= n0; v[c][q][12 + d] *= n1; }
-          if (i < agg_sites) store_site<T, 24>(P + (size_t)(k0 + c) * pstride, V, s0 + i, v[c][q]);
+          if (i < agg_sites) store_site<T, 24>(p_block(P, a, k0 + c, nvec, aps), p_plane(nvec, aps), i, v[c][q]);
         }
       }
     }
@@ -660,18 +709,19 @@ __global__ __launch_bounds__(256) void gs_aggregates_kernel(T* __restrict__ P, s
 
 template <typename T>
 void Interpolation<T>::orthonormalize(hipStream_t st) {
-  DDAMG_HIP_CHECK(hipMemcpyAsync(P, tv, sizeof(T) * pstride * nvec, hipMemcpyDeviceToDevice, st));
+  // (P <- tv is part of the kernel: a column is read from the test vectors in lattice order and written, orthonormalised, into
+  // its aggregate-major place; the earlier columns it is projected on are read from there)
   const int nt = wg_threads(agg_sites);
   const int spt = (agg_sites + nt - 1) / nt;
   // columns per pass: 2 (measured at 32^4, Nvec 24: 6.8 ms with one column, 4.3 ms with two, 4.5 ms with four -- 190 registers,
   // two workgroups per CU; two columns reproduce the one-column results bit for bit, four do not: the compiler contracts
   // the products of the wider reduction differently)
   static const int columns = getenv("DDAMG_GS_COLUMNS") ? atoi(getenv("DDAMG_GS_COLUMNS")) : 2;
-  if (spt == 1 && columns == 1) hipLaunchKernelGGL((gs_aggregates_kernel<T, 1, 1>), dim3(num_aggs), dim3(nt), 0, st, P, pstride, nvec, V, agg_sites);
-  else if (spt == 1 && columns == 4 && sizeof(T) == 4) hipLaunchKernelGGL((gs_aggregates_kernel<T, 1, 4>), dim3(num_aggs), dim3(nt), 0, st, P, pstride, nvec, V, agg_sites);
-  else if (spt == 1) hipLaunchKernelGGL((gs_aggregates_kernel<T, 1, 2>), dim3(num_aggs), dim3(nt), 0, st, P, pstride, nvec, V, agg_sites);
-  else if (spt == 2) hipLaunchKernelGGL((gs_aggregates_kernel<T, 2, 1>), dim3(num_aggs), dim3(nt), 0, st, P, pstride, nvec, V, agg_sites);
-  else if (spt <= 4) hipLaunchKernelGGL((gs_aggregates_kernel<T, 4, 1>), dim3(num_aggs), dim3(nt), 0, st, P, pstride, nvec, V, agg_sites);
+  if (spt == 1 && columns == 1) hipLaunchKernelGGL((gs_aggregates_kernel<T, 1, 1>), dim3(num_aggs), dim3(nt), 0, st, P, tv, pstride, nvec, V, agg_sites, plane_sites());
+  else if (spt == 1 && columns == 4 && sizeof(T) == 4) hipLaunchKernelGGL((gs_aggregates_kernel<T, 1, 4>), dim3(num_aggs), dim3(nt), 0, st, P, tv, pstride, nvec, V, agg_sites, plane_sites());
+  else if (spt == 1) hipLaunchKernelGGL((gs_aggregates_kernel<T, 1, 2>), dim3(num_aggs), dim3(nt), 0, st, P, tv, pstride, nvec, V, agg_sites, plane_sites());
+  else if (spt == 2) hipLaunchKernelGGL((gs_aggregates_kernel<T, 2, 1>), dim3(num_aggs), dim3(nt), 0, st, P, tv, pstride, nvec, V, agg_sites, plane_sites());
+  else if (spt <= 4) hipLaunchKernelGGL((gs_aggregates_kernel<T, 4, 1>), dim3(num_aggs), dim3(nt), 0, st, P, tv, pstride, nvec, V, agg_sites, plane_sites());
   else DDAMG_REQUIRE(false, "aggregates larger than 1024 sites are not supported by the Gram-Schmidt kernel");
   DDAMG_HIP_CHECK(hipGetLastError());
 }

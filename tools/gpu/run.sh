@@ -41,7 +41,7 @@ lib)          # another build of the library against the current one: run.sh lib
   for rep in 1 2; do for lib in base new; do
     unset DDAMG_HIP_LIBRARY; [ $lib = base ] && export DDAMG_HIP_LIBRARY=$B
     if [ "$1" = sap ]; then echo "$lib:"; SAP_BENCH_ITERS=${SAP_AB_ITERS:-0,4} python3 tools/sap_bench.py 2>&1 | grep block_iter
-    else set -- $1; echo "$lib: $($SP 3 1 $1 $2 2>&1 | tail -1 | cut -c1-170)"; fi
+    else echo "$lib: $($SP 3 1 $1 2>&1 | tail -1 | cut -c1-170)"; fi      # "$1" = "<extent> <levels>", split by the shell here
   done; done ;;
 stats)        # kernel statistics of setup + N solves: run.sh stats <extent> <levels> [N] [grep pattern]
   stats s$1 $SP ${3:-2} 1 $1 $2; tail -1 $O/s$1.log | cut -c1-200; if [ -n "$4" ]; then grep -E "$4" $O/s$1_stats.csv | short; else head -30 $O/s$1_stats.csv | short; fi ;;
