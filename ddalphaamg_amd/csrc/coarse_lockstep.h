@@ -67,6 +67,13 @@ class LockstepCoarseSolver {
   float2* w_ = nullptr;                                   // even-site batch
   double *d_partial_ = nullptr, *d_h_ = nullptr, *d_coef_ = nullptr;
   double *h_h_ = nullptr, *h_coef_ = nullptr;             // pinned
+  // the couplings and the inverted self couplings in A-operand order (coarse_multi.h), refreshed when the operator has moved;
+  // n % 8 == 0, else the kernels read the tile layout of the solve path
+  mutable float4 *Mop_ = nullptr, *Minv_op_ = nullptr;
+  mutable unsigned Mop_version_ = 0, Minv_version_ = 0;
+  mutable bool Mop_valid_ = false;
+  bool operand_order() const;
+  void operands(const float4** Mop, const float4** Minv_op) const;
   size_t even_elems() const { return (size_t)Ve_ * n_ * LOCKSTEP_COLS; }
   void self(float2* out, const float2* in, int s0, int s1, bool inverse);
   void hop(float2* out, const float2* in, int s0, int s1, float sign, bool accumulate);

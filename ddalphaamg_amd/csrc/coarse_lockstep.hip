@@ -1,6 +1,7 @@
 // coarse_lockstep.hip -- see coarse_lockstep.h
 #include "coarse_lockstep.h"
 #include "mfma_tile.h"
+#include "coarse_multi.h"
 #include <complex>
 #include <cmath>
 
@@ -68,6 +69,33 @@ __global__ __launch_bounds__(128) void ls_hop_kernel(float2* __restrict__ out, c
     const int yf = op.nb[(size_t)mu * op.V + x], yb = op.nb[(size_t)(4 + mu) * op.V + x];
     mfma_product<NRT, false>(Mall + ((size_t)x * 5 + 1 + mu) * op.msize, nt, n, in + (size_t)yf * n * NC, col0, sign, aR, aI);
     mfma_product<NRT, true>(Mall + ((size_t)yb * 5 + 1 + mu) * op.msize, nt, n, in + (size_t)yb * n * NC, col0, sign, aR, aI);
+  }
+  store_rows<NRT>(out + (size_t)x * n * NC, n, col0, aR, aI, accumulate != 0);
+}
+
+// the same two kernels on the couplings in A-operand order (coarse_multi.h): a wavefront's A operand of two k-steps is one
+// 16-byte load per lane, requested a pass ahead (mfma_cproduct_op)
+template <int NRT>
+__global__ __launch_bounds__(128) void ls_self_op_kernel(float2* __restrict__ out, const float2* __restrict__ in, const float4* __restrict__ A, int parts, int n, int s0) {
+  const int x = s0 + blockIdx.x;
+  const int col0 = (threadIdx.x >> 6) * 16;
+  f32x4 aR[NRT], aI[NRT];
+  mfma_zero<NRT>(aR, aI);
+  mfma_cproduct_op<NRT>(A + (size_t)x * parts * mfma_op_matrix_elems(n), n, in + (size_t)x * n * NC + col0, NC, 1.f, aR, aI);
+  store_rows<NRT>(out + (size_t)x * n * NC, n, col0, aR, aI, false);
+}
+template <int NRT>
+__global__ __launch_bounds__(128) void ls_hop_op_kernel(float2* __restrict__ out, const float2* __restrict__ in, const float4* __restrict__ Mop, CoarseOpDev<float> op, int s0,
+                                                        float sign, int accumulate) {
+  const int x = s0 + blockIdx.x, n = op.n;
+  const int col0 = (threadIdx.x >> 6) * 16;
+  const size_t me = mfma_op_matrix_elems(n);
+  f32x4 aR[NRT], aI[NRT];
+  mfma_zero<NRT>(aR, aI);
+#pragma nounroll
+  for (int p = 1; p < 9; p++) {
+    const size_t y = (size_t)op.nb[(size_t)(p - 1) * op.V + x];            // p <= 4: x + mu, else x - mu
+    mfma_cproduct_op<NRT>(Mop + ((p <= 4 ? (size_t)x : y) * 9 + p) * me, n, in + y * n * NC + col0, NC, sign, aR, aI);
   }
   store_rows<NRT>(out + (size_t)x * n * NC, n, col0, aR, aI, accumulate != 0);
 }
@@ -217,6 +245,9 @@ void LockstepCoarseSolver::release() {
   for (int i = 0; i < 4; i++) if (W_[i]) { (void)hipFree(W_[i]); W_[i] = nullptr; }
   if (basis_) (void)hipFree(basis_);
   if (w_) (void)hipFree(w_);
+  if (Mop_) (void)hipFree(Mop_);
+  if (Minv_op_) (void)hipFree(Minv_op_);
+  Mop_ = Minv_op_ = nullptr; Mop_valid_ = false;
   if (d_partial_) (void)hipFree(d_partial_);
   if (d_h_) (void)hipFree(d_h_);
   if (d_coef_) (void)hipFree(d_coef_);
@@ -239,11 +270,40 @@ void LockstepCoarseSolver::init(const CoarseOp<float>* cop, int max_steps, doubl
 
 void LockstepCoarseSolver::gather(float2* Wb, const float* src, size_t sstride, int ncols) { batch_gather(Wb, src, sstride, ncols, (size_t)V_ * n_, st_); }
 void LockstepCoarseSolver::scatter(float* dst, size_t dstride, const float2* Wb, int ncols) { batch_scatter(dst, dstride, Wb, ncols, (size_t)V_ * n_, st_); }
+bool LockstepCoarseSolver::operand_order() const {
+  static const bool off = getenv("DDAMG_LOCKSTEP_TILE_LAYOUT") != nullptr;
+  return !off && n_ % 8 == 0;
+}
+void LockstepCoarseSolver::operands(const float4** Mop, const float4** Minv_op) const {
+  const size_t me = mfma_op_matrix_elems(n_);
+  if (!Mop_) {
+    DDAMG_HIP_CHECK(device_alloc(&Mop_, sizeof(float4) * (size_t)V_ * 9 * me));
+    DDAMG_HIP_CHECK(device_alloc(&Minv_op_, sizeof(float4) * (size_t)V_ * me));
+  }
+  if (!Mop_valid_ || Mop_version_ != cop_->version()) { coarse_operands_build(Mop_, *cop_, st_); Mop_version_ = cop_->version(); }
+  if (!Mop_valid_ || Minv_version_ != cop_->inverse_version()) { coarse_inverse_operands_build(Minv_op_, *cop_, st_); Minv_version_ = cop_->inverse_version(); }
+  Mop_valid_ = true;
+  *Mop = Mop_; *Minv_op = Minv_op_;
+}
 void LockstepCoarseSolver::self(float2* out, const float2* in, int s0, int s1, bool inverse) {
+  if (operand_order()) {
+    const float4 *Mop, *Minv_op;
+    operands(&Mop, &Minv_op);
+    launch_nrt((n_ + 15) / 16, ls_self_op_kernel<1>, ls_self_op_kernel<2>, ls_self_op_kernel<3>, ls_self_op_kernel<4>, dim3(s1 - s0), dim3(128), st_, out, in,
+               inverse ? Minv_op : Mop, inverse ? 1 : 9, n_, s0);
+    return;
+  }
   launch_nrt((n_ + 15) / 16, ls_self_kernel<1>, ls_self_kernel<2>, ls_self_kernel<3>, ls_self_kernel<4>, dim3(s1 - s0), dim3(128), st_, out, in, cop_->dev(), s0,
              inverse ? 1 : 0);
 }
 void LockstepCoarseSolver::hop(float2* out, const float2* in, int s0, int s1, float sign, bool accumulate) {
+  if (operand_order()) {
+    const float4 *Mop, *Minv_op;
+    operands(&Mop, &Minv_op);
+    launch_nrt((n_ + 15) / 16, ls_hop_op_kernel<1>, ls_hop_op_kernel<2>, ls_hop_op_kernel<3>, ls_hop_op_kernel<4>, dim3(s1 - s0), dim3(128), st_, out, in, Mop,
+               cop_->dev(), s0, sign, accumulate ? 1 : 0);
+    return;
+  }
   launch_nrt((n_ + 15) / 16, ls_hop_kernel<1>, ls_hop_kernel<2>, ls_hop_kernel<3>, ls_hop_kernel<4>, dim3(s1 - s0), dim3(128), st_, out, in, cop_->dev(), s0, sign,
              accumulate ? 1 : 0);
 }

@@ -25,6 +25,12 @@
 
 namespace ddamg {
 
+// The couplings of a coarse operator in the A-operand order of the matrix instruction (mfma_tile.h): Mop[x][9] -- 0 the self
+// coupling, 1 + mu the forward link, 5 + mu its backward form G5 U^H G5 -- and the inverted self couplings Minv_op[x]
+// (mfma_op_matrix_elems(n) float4 each; n % 8 == 0).  Used by CoarseMulti and by LockstepCoarseSolver.
+void coarse_operands_build(float4* Mop, const CoarseOp<float>& op, hipStream_t st);
+void coarse_inverse_operands_build(float4* Minv_op, const CoarseOp<float>& op, hipStream_t st);
+
 class CoarseMulti {
  public:
   ~CoarseMulti();

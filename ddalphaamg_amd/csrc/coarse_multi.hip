@@ -68,10 +68,12 @@ __device__ __forceinline__ void load_lds(const float2* __restrict__ rsite, int n
 // ---- the couplings in the A-operand order of the matrix instruction (mfma_tile.h) ---------------------------------------------
 // Mop[x][p]: p = 0 the self coupling, 1 + mu the forward link U_mu(x), 5 + mu its backward form G5 U_mu(x)^H G5 (what the site
 // x + mu multiplies its neighbour x with, src/coarse_operator_generic.h:152-171)
-__global__ __launch_bounds__(256) void cm_relayout_kernel(float4* __restrict__ Mop, CoarseOpDev<float> op, int nrt) {
+// (inverse: the one inverted self coupling of every site, CoarseOp::compute_self_inverse, instead: Mop[x])
+__global__ __launch_bounds__(256) void cm_relayout_kernel(float4* __restrict__ Mop, CoarseOpDev<float> op, int nrt, int inverse) {
   const int x = blockIdx.x, p = blockIdx.y, n = op.n, nt = op.nt, npass = n >> 3, half = n >> 1;
-  const float2* M = reinterpret_cast<const float2*>(op.M) + ((size_t)x * 5 + (p == 0 ? 0 : 1 + (p - 1) % 4)) * op.msize;
-  float4* out = Mop + ((size_t)x * 9 + p) * mfma_op_matrix_elems(n);
+  const float2* M = inverse ? reinterpret_cast<const float2*>(op.Minv) + (size_t)x * op.msize
+                            : reinterpret_cast<const float2*>(op.M) + ((size_t)x * 5 + (p == 0 ? 0 : 1 + (p - 1) % 4)) * op.msize;
+  float4* out = Mop + (inverse ? (size_t)x : (size_t)x * 9 + p) * mfma_op_matrix_elems(n);
   const bool dag = p > 4;
   for (int e = threadIdx.x; e < nrt * npass * 64; e += 256) {
     const int lane = e & 63, P = (e >> 6) % npass, rt = (e >> 6) / npass;
@@ -305,6 +307,15 @@ __global__ void cm_sub_kernel(float2* __restrict__ z, const float2* __restrict__
 
 }  // namespace
 
+void coarse_operands_build(float4* Mop, const CoarseOp<float>& op, hipStream_t st) {
+  hipLaunchKernelGGL(cm_relayout_kernel, dim3(op.V(), 9), dim3(256), 0, st, Mop, op.dev(), (op.n() + 15) / 16, 0);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+void coarse_inverse_operands_build(float4* Minv_op, const CoarseOp<float>& op, hipStream_t st) {
+  hipLaunchKernelGGL(cm_relayout_kernel, dim3(op.V(), 1), dim3(256), 0, st, Minv_op, op.dev(), (op.n() + 15) / 16, 1);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
 bool CoarseMulti::available(const Geometry& g, const CoarseOp<float>& op, int method) {
   static const bool off = getenv("DDAMG_BOOTSTRAP_NO_LOCKSTEP") != nullptr;
   if (off || method != 2 || op.distributed() || g.distributed()) return false;
@@ -389,7 +400,7 @@ const float4* CoarseMulti::operands() const {
   const size_t elems = (size_t)V_ * 9 * mfma_op_matrix_elems(n_);
   if (!Mop_) DDAMG_HIP_CHECK(device_alloc(&Mop_, sizeof(float4) * elems));
   if (Mop_version_ != op_->version() || !Mop_valid_) {
-    hipLaunchKernelGGL(cm_relayout_kernel, dim3(V_, 9), dim3(256), 0, st_, Mop_, op_->dev(), (n_ + 15) / 16);
+    hipLaunchKernelGGL(cm_relayout_kernel, dim3(V_, 9), dim3(256), 0, st_, Mop_, op_->dev(), (n_ + 15) / 16, 0);
     DDAMG_HIP_CHECK(hipGetLastError());
     Mop_version_ = op_->version(); Mop_valid_ = true;
   }

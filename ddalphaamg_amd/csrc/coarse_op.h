@@ -73,6 +73,7 @@ class CoarseOp {
   T* matrices() { version_++; return M_; }
   const T* matrices() const { return M_; }
   unsigned version() const { return version_; }
+  unsigned inverse_version() const { return inverse_version_; }   // moves with every compute_self_inverse()
   size_t msize() const { return msize_; }
   int nt() const { return nt_; }
 
@@ -109,6 +110,7 @@ class CoarseOp {
   int* nb_ = nullptr;
   int V_ = 0, n_ = 0, nt_ = 0;
   unsigned version_ = 0;
+  unsigned inverse_version_ = 0;
   T* diag_base_ = nullptr;          // [V][n] the self couplings' diagonal (real parts) before any shift
   unsigned diag_base_version_ = 0;  // version_ the base belongs to (0: none)
   double shift_total_ = 0.0;

@@ -706,6 +706,7 @@ void CoarseOp<T>::compute_self_inverse(hipStream_t st) {
   DDAMG_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&invert_self_kernel<T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(invert_self_kernel<T>, dim3(V_), dim3(256), lds, st, Minv_, M_, n_, nt_, msize_);
   DDAMG_HIP_CHECK(hipGetLastError());
+  inverse_version_++;
 }
 
 // mass shift on a coarse level: P^H P = 1 on every aggregate and chirality, so P^H (D + d) P = D_c + d -- the self coupling
