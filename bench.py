@@ -344,7 +344,7 @@ def coarse_operator_report():
             "level1_operator": entry("level1_apply", "cm_apply_op_kernel: the operator of the intermediate level for all columns of the K-cycles in lockstep (64^4 three-level setup)"),
             "level1_restrict": entry("level1_restrict", "cm_restrict_kernel: level 1 -> 2 for all columns"),
             "level1_interpolate": entry("level1_interpolate", "cm_interpolate_kernel: level 2 -> 1 for all columns"),
-            "bootstrap_coarsest_solves_in_lockstep": entry("lockstep_hop", "ls_hop_kernel: hopping terms of the coarsest-level Schur complement for all Nvec test vectors of a "
+            "bootstrap_coarsest_solves_in_lockstep": entry("lockstep_hop", "ls_hop_op_kernel: hopping terms of the coarsest-level Schur complement for all Nvec test vectors of a "
                                                            "bootstrap iteration at once, complex n x n times n x 32 on v_mfma_f32_16x16x4_f32"),
             "galerkin_coarse_apply": entry("galerkin_coarse_apply", "coarse_batch_apply_kernel: all 2*Nvec columns of the coarse-level Galerkin construction"),
             "galerkin_restrict": entry("galerkin_restrict", "restrict_mfma_kernel<2>: the 2*Nvec columns of the fine-level Galerkin construction, five parts each (the four forward "

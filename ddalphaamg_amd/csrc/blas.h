@@ -83,6 +83,10 @@ template <typename T> void vec_multi_axpy_dev(T* w, const T* X, size_t xstride, 
 void vec_multi_axpy_f32basis(double* w, const float* X, size_t xstride, int m, const double* d_coef, double sign, size_t V, int nreal, hipStream_t st);
 // d_out[2i..2i+1] = < X+i*xstride , w >  for i<m  (conjugate-linear in the first argument)
 // local_only: leave the sum over the processes to the caller (comm_allreduce_begin / _end around other work)
+// W_c -= sum_{i<m} <X_i, W_c> X_i for the nb <= PANEL_COLUMNS vectors W_c = Wp + c * wstride: one pass over the X_i for the dots of
+// the whole panel, one for their updates (coefficients through rw.d_result, summed over the processes on a grid)
+constexpr int PANEL_COLUMNS = 4;
+template <typename T> void vec_panel_project(T* Wp, size_t wstride, int nb, const T* X, size_t xstride, int m, View v, ReduceWork& rw, hipStream_t st);
 template <typename T> void vec_multi_dot(const T* X, size_t xstride, int m, const T* w, View v, ReduceWork& rw, double* d_out, hipStream_t st, bool local_only = false);
 // single-allreduce Arnoldi (src/linsolve_generic.c:776-797): d_h holds m+1 inner products <V_i, w>, the last one <w,w>;
 // d_h[2m] <- sqrt( <w,w> - sum_i |h_i|^2 ), or -1 when the difference is negative (the reference restarts then)

@@ -347,6 +347,124 @@ void vec_multi_dot(const T* X, size_t xstride, int m, const T* w, View v, Reduce
   if (rw.comm && !local_only) comm_allreduce(rw.comm, d_out, 2 * m, st);
 }
 
+// ---- a panel of CB vectors against m earlier ones: the earlier vectors are read once for the whole panel ------------------
+// (Gram-Schmidt on the test vectors of a level, mg.cpp: column by column the projections of vector i read i earlier vectors
+// twice, 2 * sum i = Nvec^2 vector reads per call; by panels of 4 it is a quarter of that plus the panel's own columns)
+// partial[blockIdx.x][(i * CB + c) * 2 ..] for i in tile blockIdx.y, c < nb <= CB: <X_i, W_c>
+template <typename T, int CB, bool NT>
+__global__ __launch_bounds__(BLK) void panel_dot_kernel(const T* __restrict__ X, size_t xstride, int m, const T* __restrict__ Wp, size_t wstride, int nb,
+                                                        View v, double* __restrict__ partial, int gx) {
+  constexpr int CH = Chunk<T>::CH;
+  using vec = typename Chunk<T>::vec;
+  __shared__ double lds[2 * DOT_TILE * CB * 4];
+  // one-dimensional grid of gx * ntile workgroups: the ntile workgroups that walk the same chunks of the panel (one per tile of
+  // earlier vectors) get ids 8 apart, i.e. the same XCD and neighbouring dispatch slots, so that the panel's chunks come from
+  // that XCD's L2 for all but the first of them (tile-major order read the panel from memory once per tile)
+  const int ntile = (m + DOT_TILE - 1) / DOT_TILE;
+  const int bid = (int)blockIdx.x, grp = bid / (8 * ntile), r = bid % (8 * ntile);
+  const int bx = grp * 8 + (r & 7), tile = r >> 3;
+  if (bx >= gx) return;
+  const int i0 = tile * DOT_TILE;
+  const int mt = min(DOT_TILE, m - i0);
+  double acc[2 * DOT_TILE * CB];
+#pragma unroll
+  for (int k = 0; k < 2 * DOT_TILE * CB; k++) acc[k] = 0;
+  const size_t nchunks = v.total() / CH;
+  // fp32 vectors: the products of FLUSH consecutive chunks of a thread are summed in fp32 (16 terms per sum), then added to the
+  // fp64 accumulator -- with 16 complex sums per thread the all-fp64 form of multi_dot_kernel is bound by the conversions and
+  // fp64 additions (15.8 ms per panel at 64^4 whether the products are fp64 or fp32; 7.5 ms in this form)
+  constexpr int FLUSH = CH == 4 ? 4 : 1;
+  float facc[2 * DOT_TILE * CB];
+#pragma unroll
+  for (int k = 0; k < 2 * DOT_TILE * CB; k++) facc[k] = 0.f;
+  int pending = 0;
+  for (size_t c = (size_t)bx * BLK + threadIdx.x; c < nchunks; c += (size_t)gx * BLK) {
+    const size_t a = chunk_addr<T>(v, c);
+    vec wv[CB];
+#pragma unroll
+    for (int q = 0; q < CB; q++) wv[q] = ldv<T>(Wp + (size_t)(q < nb ? q : 0) * wstride + a);
+#pragma unroll
+    for (int t = 0; t < DOT_TILE; t++) {
+      if (t < mt) {
+        const vec xv = ldv_stream<T, NT>(X + (size_t)(i0 + t) * xstride + a);
+#pragma unroll
+        for (int q = 0; q < CB; q++) {
+          if constexpr (CH == 4) {
+            facc[2 * (t * CB + q)]     += xv.x * wv[q].x + xv.y * wv[q].y + xv.z * wv[q].z + xv.w * wv[q].w;
+            facc[2 * (t * CB + q) + 1] += xv.x * wv[q].y - xv.y * wv[q].x + xv.z * wv[q].w - xv.w * wv[q].z;
+          } else {
+            acc[2 * (t * CB + q)]     += xv.x * wv[q].x + xv.y * wv[q].y;
+            acc[2 * (t * CB + q) + 1] += xv.x * wv[q].y - xv.y * wv[q].x;
+          }
+        }
+      }
+    }
+    if (CH == 4 && ++pending == FLUSH) {
+      pending = 0;
+#pragma unroll
+      for (int k = 0; k < 2 * DOT_TILE * CB; k++) { acc[k] += (double)facc[k]; facc[k] = 0.f; }
+    }
+  }
+  if (CH == 4) {
+#pragma unroll
+    for (int k = 0; k < 2 * DOT_TILE * CB; k++) acc[k] += (double)facc[k];
+  }
+  block_sum<2 * DOT_TILE * CB>(acc, lds);
+  if (threadIdx.x == 0)
+    for (int t = 0; t < mt; t++)
+      for (int q = 0; q < CB; q++) {
+        double* p = partial + (size_t)bx * 2 * m * CB + 2 * ((size_t)(i0 + t) * CB + q);
+        p[0] = acc[2 * (t * CB + q)]; p[1] = acc[2 * (t * CB + q) + 1];
+      }
+}
+// W_c += sign * sum_i coef[i][c] X_i for c < nb: coef[(i * CB + c) * 2 ..] as the dots above leave them
+template <typename T, int CB, bool NT>
+__global__ __launch_bounds__(BLK) void panel_axpy_kernel(T* __restrict__ Wp, size_t wstride, int nb, const T* __restrict__ X, size_t xstride, int m,
+                                                         const double* __restrict__ coef, double sign, View v) {
+  constexpr int CH = Chunk<T>::CH;
+  using vec = typename Chunk<T>::vec;
+  const size_t nchunks = v.total() / CH;
+  for (size_t c = (size_t)blockIdx.x * BLK + threadIdx.x; c < nchunks; c += (size_t)gridDim.x * BLK) {
+    const size_t a = chunk_addr<T>(v, c);
+    vec wv[CB];
+#pragma unroll
+    for (int q = 0; q < CB; q++) wv[q] = ldv<T>(Wp + (size_t)(q < nb ? q : 0) * wstride + a);
+    for (int i = 0; i < m; i++) {
+      const vec xv = ldv_stream<T, NT>(X + (size_t)i * xstride + a);
+#pragma unroll
+      for (int q = 0; q < CB; q++) {
+        const T cr = (T)(sign * coef[2 * (i * CB + q)]), ci = (T)(sign * coef[2 * (i * CB + q) + 1]);
+        if constexpr (CH == 4) {
+          wv[q].x += cr * xv.x - ci * xv.y; wv[q].y += cr * xv.y + ci * xv.x;
+          wv[q].z += cr * xv.z - ci * xv.w; wv[q].w += cr * xv.w + ci * xv.z;
+        } else {
+          wv[q].x += cr * xv.x - ci * xv.y; wv[q].y += cr * xv.y + ci * xv.x;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < CB; q++)
+      if (q < nb) stv<T>(Wp + (size_t)q * wstride + a, wv[q]);
+  }
+}
+template <typename T>
+void vec_panel_project(T* Wp, size_t wstride, int nb, const T* X, size_t xstride, int m, View v, ReduceWork& rw, hipStream_t st) {
+  constexpr int CB = PANEL_COLUMNS;
+  DDAMG_REQUIRE(nb >= 1 && nb <= CB && m >= 1 && m * CB <= rw.max_m, "panel projection: too many vectors for the reduction workspace");
+  const size_t nch = v.total() / Chunk<T>::CH;
+  const int gx = std::min(grid_for(nch), 1024), gy = (m + DOT_TILE - 1) / DOT_TILE;
+  const bool nt = stream_sized(v, sizeof(T));
+  const dim3 grid((unsigned)((gx + 7) / 8 * 8 * gy));
+  if (nt) hipLaunchKernelGGL((panel_dot_kernel<T, CB, true>), grid, dim3(BLK), 0, st, X, xstride, m, Wp, wstride, nb, v, rw.d_partial, gx);
+  else hipLaunchKernelGGL((panel_dot_kernel<T, CB, false>), grid, dim3(BLK), 0, st, X, xstride, m, Wp, wstride, nb, v, rw.d_partial, gx);
+  hipLaunchKernelGGL(final_sum_kernel, dim3(2 * m * CB), dim3(BLK), 0, st, rw.d_partial, gx, 2 * m * CB, rw.d_result, 0);
+  DDAMG_HIP_CHECK(hipGetLastError());
+  if (rw.comm) comm_allreduce(rw.comm, rw.d_result, 2 * m * CB, st);
+  if (nt) hipLaunchKernelGGL((panel_axpy_kernel<T, CB, true>), dim3(grid_for(nch)), dim3(BLK), 0, st, Wp, wstride, nb, X, xstride, m, rw.d_result, -1.0, v);
+  else hipLaunchKernelGGL((panel_axpy_kernel<T, CB, false>), dim3(grid_for(nch)), dim3(BLK), 0, st, Wp, wstride, nb, X, xstride, m, rw.d_result, -1.0, v);
+  DDAMG_HIP_CHECK(hipGetLastError());
+}
+
 template <typename T>
 __global__ __launch_bounds__(BLK) void norm2_kernel(const T* __restrict__ x, View v, double* __restrict__ partial) {
   constexpr int CH = Chunk<T>::CH;
@@ -435,6 +553,7 @@ template void vec_random<double>(double*, size_t, unsigned long long, unsigned l
   template void vec_plus<T>(T*, const T*, const T*, View, hipStream_t);                                  \
   template void vec_multi_axpy_dev<T>(T*, const T*, size_t, int, const double*, double, View, hipStream_t); \
   template void vec_multi_dot<T>(const T*, size_t, int, const T*, View, ReduceWork&, double*, hipStream_t, bool); \
+  template void vec_panel_project<T>(T*, size_t, int, const T*, size_t, int, View, ReduceWork&, hipStream_t); \
   template void vec_norm<T>(const T*, View, ReduceWork&, double*, hipStream_t);                          \
   template void vec_dot_and_norm2<T>(const T*, const T*, View, ReduceWork&, double*, hipStream_t);
 INST(float)

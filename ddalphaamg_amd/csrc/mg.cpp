@@ -96,7 +96,7 @@ Multigrid<T>::Multigrid(const ddamg_hip_params& par, const std::vector<const Geo
     }
     if (d > 0 && !lv.coarsest) {
       // K-cycle FGMRES of this level (src/init_generic.c:155-160): restart kcycle_restart, kcycle_max_restart cycles
-      lv.rw.init(std::max(par.kcycle_restart, lv.nvec) + 8);
+      lv.rw.init(std::max(par.kcycle_restart, PANEL_COLUMNS * lv.nvec) + 8);    // the Gram-Schmidt panels project on up to nvec vectors
       lv.gm.alloc(lv.nel, par.kcycle_restart, true);
       lv.gm.num_restart = par.kcycle_max_restart;
       lv.gm.tol = par.kcycle_tol;
@@ -120,7 +120,7 @@ Multigrid<T>::Multigrid(const ddamg_hip_params& par, const std::vector<const Geo
             lv.ref_order.push_back(g.site_of_lex[g.lex(c)]);
           }
     } else if (d == 0) {
-      lv.rw.init(lv.nvec + 8);
+      lv.rw.init(PANEL_COLUMNS * lv.nvec + 8);
     }
     if (lv.coarsest) {
       // coarsest-level GMRES on the even-site Schur complement (src/init_generic.c:148-154)
@@ -994,13 +994,25 @@ void Multigrid<T>::bootstrap(int l, int iters) {
   for (int j = 0; j < iters; j++) {
     // gram_schmidt_PRECISION on the test vectors (classical, src/linalg_generic.c:483-528)
     double tb = tick(nullptr, 0);
-    for (int i = 0; i < lv.nvec; i++) {
-      T* vi = test_vector(l, i);
-      if (i > 0) {
-        vec_multi_dot<T>(tv_base(l), stride, i, vi, all, lv.rw, lv.rw.d_result, st_);
-        vec_multi_axpy_dev<T>(vi, tv_base(l), stride, i, lv.rw.d_result, -1.0, all, st_);
+    // By panels of PANEL_COLUMNS vectors: the projections of a panel on all earlier vectors in two passes over those (one for
+    // the dots, one for the updates), then the panel's own vectors one by one.  Vector i still gets i projections, subtracted in
+    // the order 0 .. i-1; the ones on the earlier vectors of its own panel are taken from the vector as the first pass left it
+    // (classical Gram-Schmidt takes all of them from the original vector: the same in exact arithmetic, differences of the order
+    // of the rounding of the dots).  A quarter of the vector reads of the column-by-column form (DDAMG_TV_GS_COLUMNWISE).
+    const bool columnwise = getenv("DDAMG_TV_GS_COLUMNWISE") != nullptr;   // read at every call: tests switch it within one process
+    const int CBp = columnwise ? 1 : PANEL_COLUMNS;
+    for (int i0 = 0; i0 < lv.nvec; i0 += CBp) {
+      const int nb = std::min(CBp, lv.nvec - i0);
+      if (i0 > 0 && !columnwise) vec_panel_project<T>(test_vector(l, i0), stride, nb, tv_base(l), stride, i0, all, lv.rw, st_);
+      for (int c = 0; c < nb; c++) {
+        const int i = i0 + c, first = columnwise ? 0 : i0;
+        T* vi = test_vector(l, i);
+        if (i > first) {
+          vec_multi_dot<T>(test_vector(l, first), stride, i - first, vi, all, lv.rw, lv.rw.d_result, st_);
+          vec_multi_axpy_dev<T>(vi, test_vector(l, first), stride, i - first, lv.rw.d_result, -1.0, all, st_);
+        }
+        vec_scale<T>(vi, vi, 1.0 / norm_of(l, vi), 0.0, all, st_);
       }
-      vec_scale<T>(vi, vi, 1.0 / norm_of(l, vi), 0.0, all, st_);
     }
     tb = tick("test-vector Gram-Schmidt", tb);
     if (l == 0 && bootstrap_vcycles_batched()) {

@@ -58,7 +58,7 @@ def busy(fname, key):
 mf = {"formula": "SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs x 1024 SIMDs)",
       "level1_block_minres": busy(R + "_pmc_mfma64.json", "cm_block_minres_op_kernel"), "level1_apply": busy(R + "_pmc_mfma64.json", "cm_apply_op_kernel"),
       "level1_restrict": busy(R + "_pmc_mfma64.json", "cm_restrict_kernel"), "level1_interpolate": busy(R + "_pmc_mfma64.json", "cm_interpolate_kernel"),
-      "lockstep_hop": busy(R + "_pmc_mfma_lockstep32.json", "ls_hop_kernel"), "lockstep_self": busy(R + "_pmc_mfma_lockstep32.json", "ls_self_kernel"),
+      "lockstep_hop": busy(R + "_pmc_mfma_lockstep32.json", "ls_hop_op_kernel"), "lockstep_self": busy(R + "_pmc_mfma_lockstep32.json", "ls_self_op_kernel"),
       "galerkin_coarse_apply": busy(R + "_pmc_mfma.json", "coarse_batch_apply_kernel"), "galerkin_restrict": busy(R + "_pmc_mfma.json", "restrict_mfma_kernel<2"),
       "galerkin_coarse_restrict": busy(R + "_pmc_mfma.json", "coarse_batch_restrict_store_mfma_kernel"),
       "commit": commit, "kernel_source_sha16": bench.mfma_source_hash()}
