@@ -24,7 +24,7 @@ template <typename T>
 inline ColumnView<T> lattice_vector(const T* v, size_t V) { return ColumnView<T>{v, 0, V, (int)V}; }
 template <typename T>
 inline ColumnView<T> interpolation_column(const Interpolation<T>& ip, int j) {
-  return ColumnView<T>{ip.column_block(0, j), (size_t)ip.nvec * 24 * ip.plane_sites(), ip.row_sites(), ip.agg_sites};
+  return ColumnView<T>{ip.column_block(0, j), (size_t)ip.nvec * 24 * ip.plane_sites(), (size_t)ip.plane_sites(), ip.agg_sites};
 }
 
 // W[0] = D restricted to couplings inside the aggregates, applied to the chirality-`chir` half of v;

@@ -55,7 +55,6 @@ struct Interpolation {
   int plane_sites() const { return agg_sites; }      // sites per chunk row of an aggregate's block (p_block in transfer.hip)
   size_t p_elems() const { return (size_t)num_aggs * nvec * 24 * plane_sites(); }
   const T* column_block(int a, int j) const { return P + ((size_t)a * nvec + j) * 24 * plane_sites(); }
-  size_t row_sites() const { return (size_t)plane_sites(); }      // sites between two chunk rows of one vector
   // P <- tv, then modified Gram-Schmidt per aggregate and chirality
   void orthonormalize(hipStream_t st);
   // phi_c = P^dagger phi          (coarse AoS, n = 2*nvec complex per coarse site = aggregate)

@@ -24,9 +24,6 @@ static inline int wg_threads(int agg_sites) {
 // memory, fewer requests in flight: profiles/r04_transfer_context.md), and the second slows the two solve kernels (502 / 464 us).
 template <typename T>
 __device__ __forceinline__ T* p_block(T* P, int a, int j, int nvec, int aps) { return P + ((size_t)a * nvec + j) * 24 * aps; }
-// sites between two chunk rows of one vector
-__device__ __forceinline__ size_t p_plane(int nvec, int aps) { return (size_t)aps; }
-
 template <typename T>
 void Interpolation<T>::alloc(const Geometry& g, const Geometry& gc, int nvec_) {
   V = g.V; nvec = nvec_; num_aggs = g.num_aggs; agg_sites = g.agg_sites;
@@ -72,7 +69,7 @@ __global__ void restrict_kernel(T* __restrict__ phi_c, size_t out_stride, const 
       for (int t = 0; t < TL; t++) {
         if (t < jt) {
           T p[24];
-          load_site<T, 24, true>(p_block(P, a, j0 + t, nvec, aps), p_plane(nvec, aps), i, p);
+          load_site<T, 24, true>(p_block(P, a, j0 + t, nvec, aps), aps, i, p);
 #pragma unroll
           for (int m = 0; m < NIN; m++) {
             T f[24];
@@ -229,7 +226,7 @@ __global__ __launch_bounds__(256, (NTL == 2 ? 4 : NTL == 1 ? 3 : 2)) void restri
         const int e = tid + 256 * r, i = e / KS, sl = e % KS;
         pa[r] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int site = list ? (int)list[sb + sl] : sb + sl;          // site of the aggregate
-        if (i < nvec) pa[r] = *reinterpret_cast<const float4*>(p_block(P, a, i, nvec, aps) + ((size_t)kk * p_plane(nvec, aps) + site) * 4);
+        if (i < nvec) pa[r] = *reinterpret_cast<const float4*>(p_block(P, a, i, nvec, aps) + ((size_t)kk * aps + site) * 4);
       }
 #pragma unroll
       for (int r = 0; r < RB; r++) {
@@ -453,13 +450,10 @@ __global__ void interpolate_kernel(T* __restrict__ phi, const T* __restrict__ ph
 #pragma unroll
       for (int k = 0; k < 24; k++) f[k] = 0;
     }
-#ifndef DDAMG_INTERP_UNROLL
-#define DDAMG_INTERP_UNROLL 2      // two vectors of P in flight per thread (12 loads): 441-459 -> 429-435 us at 32^4; four: 464-469 us
-#endif
-#pragma unroll DDAMG_INTERP_UNROLL
+#pragma unroll 2      // two vectors of P in flight per thread (12 loads): 441-459 -> 429-435 us at 32^4; four: 464-469 us
     for (int j = 0; j < nvec; j++) {
       T p[24];
-      load_site<T, 24, true>(p_block(P, a, j, nvec, aps), p_plane(nvec, aps), i, p);
+      load_site<T, 24, true>(p_block(P, a, j, nvec, aps), aps, i, p);
 #pragma unroll
       for (int h = 0; h < 2; h++) {
         const T cr = pc[2 * (h * nvec + j)], ci = pc[2 * (h * nvec + j) + 1];
@@ -508,7 +502,7 @@ __global__ __launch_bounds__(256) void interpolate_batch_kernel(float* __restric
     for (int w = 0; w < NR; w++) acc[w] = make_float4(0.f, 0.f, 0.f, 0.f);
     for (int j = 0; j < nvec; j++) {
       typedef float f4v __attribute__((ext_vector_type(4)));
-      const f4v pv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p_block(P, a, j, nvec, aps) + ((size_t)chunk * p_plane(nvec, aps) + i) * 4));
+      const f4v pv = __builtin_nontemporal_load(reinterpret_cast<const f4v*>(p_block(P, a, j, nvec, aps) + ((size_t)chunk * aps + i) * 4));
       const float4 p = make_float4(pv[0], pv[1], pv[2], pv[3]);
       const float2* cj = cf_lds + (size_t)(h * nvec + j) * NR;
 #pragma unroll
@@ -574,7 +568,7 @@ __global__ __launch_bounds__(256) void p_columns_kernel(T* __restrict__ P, T* __
   T* v = vec + (size_t)blockIdx.y * vstride;
   for (int e = threadIdx.x; e < (24 / CH) * agg_sites; e += 256) {
     const int kk = e / agg_sites, i = e - kk * agg_sites;
-    cvec* in_p = reinterpret_cast<cvec*>(blk + ((size_t)kk * p_plane(nvec, aps) + i) * CH);
+    cvec* in_p = reinterpret_cast<cvec*>(blk + ((size_t)kk * aps + i) * CH);
     cvec* in_v = reinterpret_cast<cvec*>(v + ((size_t)kk * V + (size_t)a * agg_sites + i) * CH);
     if (TO_P) *in_p = *in_v; else *in_v = *in_p;
   }
@@ -622,7 +616,7 @@ __global__ __launch_bounds__(256) void gs_aggregates_kernel(T* __restrict__ P, c
 #pragma unroll
       for (int q = 0; q < SPT; q++) {
         const int i = threadIdx.x + q * nt;
-        if (i < agg_sites) load_site<T, 24>(p_block(P, a, k2, nvec, aps), p_plane(nvec, aps), i, u[q]);
+        if (i < agg_sites) load_site<T, 24>(p_block(P, a, k2, nvec, aps), aps, i, u[q]);
         else {
 #pragma unroll
           for (int k = 0; k < 24; k++) u[q][k] = 0;
@@ -699,7 +693,7 @@ __global__ __launch_bounds__(256) void gs_aggregates_kernel(T* __restrict__ P, c
           const int i = threadIdx.x + q * nt;
 #pragma unroll
           for (int d = 0; d < 12; d++) { v[c][q][d] *= n0; v[c][q][12 + d] *= n1; }
-          if (i < agg_sites) store_site<T, 24>(p_block(P, a, k0 + c, nvec, aps), p_plane(nvec, aps), i, v[c][q]);
+          if (i < agg_sites) store_site<T, 24>(p_block(P, a, k0 + c, nvec, aps), aps, i, v[c][q]);
         }
       }
     }
