@@ -148,10 +148,135 @@ __global__ void aos_gs_kernel(T* __restrict__ P, size_t pstride, int nvec, int n
     __syncthreads();
   }
 }
+// The same with the vector that is being orthogonalised in registers (up to MAXE elements per thread, same element -> thread
+// assignment and the same reductions: bit-identical results): a projection then is one read of the earlier vector -- the next
+// one requested while the sums of this one are reduced -- instead of a read-modify-write of v through global memory behind two
+// more barriers.  16 sites x 48 dof x 28 vectors, 4096 aggregates: 5.9 -> 4.7 ms per call (docs/design/10_round4.md).
+template <typename T, int MAXE>
+__global__ __launch_bounds__(256) void aos_gs_reg_kernel(T* __restrict__ P, size_t pstride, int nvec, int n, int agg_sites) {
+  __shared__ double red[4 * 16];
+  const int a = blockIdx.x;
+  const size_t e0 = (size_t)a * agg_sites * n;
+  const int E = agg_sites * n, half = n >> 1;
+  int hh[MAXE];
+#pragma unroll
+  for (int q = 0; q < MAXE; q++) hh[q] = (((int)threadIdx.x + q * 256) % n) >= half;
+  for (int k1 = 0; k1 < nvec; k1++) {
+    T* v = P + (size_t)k1 * pstride + e0 * 2;
+    T vr[MAXE], vi[MAXE], ur[MAXE], ui[MAXE];
+#pragma unroll
+    for (int q = 0; q < MAXE; q++) {
+      const int e = threadIdx.x + q * 256;
+      vr[q] = e < E ? v[2 * e] : (T)0; vi[q] = e < E ? v[2 * e + 1] : (T)0;
+    }
+    auto load_u = [&](int k2) {
+      const T* u = P + (size_t)k2 * pstride + e0 * 2;
+#pragma unroll
+      for (int q = 0; q < MAXE; q++) {
+        const int e = threadIdx.x + q * 256;
+        ur[q] = e < E ? u[2 * e] : (T)0; ui[q] = e < E ? u[2 * e + 1] : (T)0;
+      }
+    };
+    if (k1 > 0) load_u(0);
+    for (int k2 = 0; k2 < k1; k2++) {
+      double al[4] = {0, 0, 0, 0};
+      T cr[MAXE], ci[MAXE];
+#pragma unroll
+      for (int q = 0; q < MAXE; q++) {
+        cr[q] = ur[q]; ci[q] = ui[q];
+        if ((int)threadIdx.x + q * 256 < E) {
+          al[2 * hh[q]] += (double)(ur[q] * vr[q] + ui[q] * vi[q]);
+          al[2 * hh[q] + 1] += (double)(ur[q] * vi[q] - ui[q] * vr[q]);
+        }
+      }
+      if (k2 + 1 < k1) load_u(k2 + 1);       // in flight while the sums are reduced
+      wg_allsum<4>(al, red);
+#pragma unroll
+      for (int q = 0; q < MAXE; q++) {
+        const T ar = (T)al[2 * hh[q]], ai = (T)al[2 * hh[q] + 1];
+        vr[q] -= ar * cr[q] - ai * ci[q]; vi[q] -= ar * ci[q] + ai * cr[q];
+      }
+    }
+    double nr[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < MAXE; q++)
+      if ((int)threadIdx.x + q * 256 < E) nr[hh[q]] += (double)(vr[q] * vr[q] + vi[q] * vi[q]);
+    wg_allsum<2>(nr, red);
+    const T s0 = (T)(1.0 / sqrt(nr[0])), s1 = (T)(1.0 / sqrt(nr[1]));
+#pragma unroll
+    for (int q = 0; q < MAXE; q++) {
+      const int e = threadIdx.x + q * 256;
+      const T sc = hh[q] ? s1 : s0;
+      if (e < E) { v[2 * e] = vr[q] * sc; v[2 * e + 1] = vi[q] * sc; }
+    }
+    __syncthreads();      // the finished vector is read by the later ones (same workgroup, global memory)
+  }
+}
+// One wavefront per (aggregate, chirality): its up to 64 * MAXE elements of the vector that is being orthogonalised in registers,
+// the two sums of a projection by lane exchanges alone -- no barrier and no LDS on the chain of nvec^2 / 2 dependent projections
+// (16 sites x 24 dof of a chirality x 28 vectors, 4096 aggregates: 1.7 ms against 4.7 ms for the workgroup form above).  The sums
+// run over the same elements in another order: results agree to rounding, not bit for bit.
+template <typename T, int MAXE>
+__global__ __launch_bounds__(256) void aos_gs_wave_kernel(T* __restrict__ P, size_t pstride, int nvec, int n, int agg_sites, int ntasks) {
+  const int task = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (task >= ntasks) return;                       // whole wavefronts leave: no barrier below
+  const int a = task >> 1, h = task & 1, half = n >> 1, E = agg_sites * half;
+  const size_t e0 = (size_t)a * agg_sites * n;
+  int off[MAXE];                                     // element q of the lane: site (e / half), dof h * half + e % half
+#pragma unroll
+  for (int q = 0; q < MAXE; q++) { const int e = lane + 64 * q; off[q] = e < E ? 2 * ((e / half) * n + h * half + e % half) : -1; }
+  auto wave_sum = [](double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+  };
+  for (int k1 = 0; k1 < nvec; k1++) {
+    T* v = P + (size_t)k1 * pstride + e0 * 2;
+    T vr[MAXE], vi[MAXE], ur[MAXE], ui[MAXE];
+#pragma unroll
+    for (int q = 0; q < MAXE; q++) { vr[q] = off[q] >= 0 ? v[off[q]] : (T)0; vi[q] = off[q] >= 0 ? v[off[q] + 1] : (T)0; }
+    auto load_u = [&](int k2) {
+      const T* u = P + (size_t)k2 * pstride + e0 * 2;
+#pragma unroll
+      for (int q = 0; q < MAXE; q++) { ur[q] = off[q] >= 0 ? u[off[q]] : (T)0; ui[q] = off[q] >= 0 ? u[off[q] + 1] : (T)0; }
+    };
+    if (k1 > 0) load_u(0);
+    for (int k2 = 0; k2 < k1; k2++) {
+      double sr = 0, si = 0;
+      T cr[MAXE], ci[MAXE];
+#pragma unroll
+      for (int q = 0; q < MAXE; q++) {
+        cr[q] = ur[q]; ci[q] = ui[q];
+        sr += (double)(ur[q] * vr[q] + ui[q] * vi[q]);
+        si += (double)(ur[q] * vi[q] - ui[q] * vr[q]);
+      }
+      if (k2 + 1 < k1) load_u(k2 + 1);
+      const T ar = (T)wave_sum(sr), ai = (T)wave_sum(si);
+#pragma unroll
+      for (int q = 0; q < MAXE; q++) { vr[q] -= ar * cr[q] - ai * ci[q]; vi[q] -= ar * ci[q] + ai * cr[q]; }
+    }
+    double nr = 0;
+#pragma unroll
+    for (int q = 0; q < MAXE; q++) nr += (double)(vr[q] * vr[q] + vi[q] * vi[q]);
+    const T sc = (T)(1.0 / sqrt(wave_sum(nr)));
+#pragma unroll
+    for (int q = 0; q < MAXE; q++)
+      if (off[q] >= 0) { v[off[q]] = vr[q] * sc; v[off[q] + 1] = vi[q] * sc; }
+    __threadfence_block();     // the finished vector is read back by this wavefront only (later k1), through global memory
+  }
+}
 template <typename T>
 void CoarseTransfer<T>::orthonormalize(int passes, hipStream_t st) {
   DDAMG_HIP_CHECK(hipMemcpyAsync(P, tv, sizeof(T) * pstride * nvec, hipMemcpyDeviceToDevice, st));
-  for (int p = 0; p < passes; p++) hipLaunchKernelGGL(aos_gs_kernel<T>, dim3(num_aggs), dim3(256), 0, st, P, pstride, nvec, n, agg_sites);
+  const int E = agg_sites * n;
+  const bool global_form = getenv("DDAMG_COARSE_GS_GLOBAL") != nullptr;   // read at every call: tests switch it within one process
+  for (int p = 0; p < passes; p++) {
+    const char* form = getenv("DDAMG_COARSE_GS_FORM");      // "workgroup": the bit-identical register form above
+    const bool wave_form = !global_form && !(form && form[0] == 'w') && agg_sites * (n / 2) <= 64 * 8 && n % 2 == 0;
+    if (wave_form) hipLaunchKernelGGL((aos_gs_wave_kernel<T, 8>), dim3((2 * num_aggs + 3) / 4), dim3(256), 0, st, P, pstride, nvec, n, agg_sites, 2 * num_aggs);
+    else if (!global_form && E <= 256 * 4) hipLaunchKernelGGL((aos_gs_reg_kernel<T, 4>), dim3(num_aggs), dim3(256), 0, st, P, pstride, nvec, n, agg_sites);
+    else hipLaunchKernelGGL(aos_gs_kernel<T>, dim3(num_aggs), dim3(256), 0, st, P, pstride, nvec, n, agg_sites);
+  }
   DDAMG_HIP_CHECK(hipGetLastError());
 }
 

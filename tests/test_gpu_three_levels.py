@@ -85,6 +85,28 @@ def test_second_coarse_operator_column_by_column_form(monkeypatch):
     ctx.close()
 
 
+@pytest.mark.parametrize("name", ["ref_8x8_3lvl_small.npz", "ref_16x8_3lvl_prod.npz"])
+def test_gram_schmidt_on_the_aggregates_of_the_intermediate_level_in_registers(name, monkeypatch):
+    """gram_schmidt_on_aggregates (src/linalg_generic.c:400-480) on the intermediate level in its three forms: the vector that is
+    being orthogonalised in registers of one workgroup (DDAMG_COARSE_GS_FORM=workgroup) against the form that updates it through
+    global memory (DDAMG_COARSE_GS_GLOBAL) -- the same element -> thread assignment and the same reductions, so the level-2
+    operator of a whole setup agrees bit for bit -- and the default, one wavefront per aggregate and chirality"""
+    res = []
+    for form in ("wave", "workgroup", "global"):
+        monkeypatch.delenv("DDAMG_COARSE_GS_GLOBAL", raising=False); monkeypatch.delenv("DDAMG_COARSE_GS_FORM", raising=False)
+        if form == "global":
+            monkeypatch.setenv("DDAMG_COARSE_GS_GLOBAL", "1")
+        elif form == "workgroup":
+            monkeypatch.setenv("DDAMG_COARSE_GS_FORM", "workgroup")
+        g, ctx = make_ctx(name)
+        ctx.setup(2)
+        res.append(ctx.get_coarse_operator(level=2))
+        ctx.close()
+    assert np.array_equal(res[1][0], res[2][0]) and np.array_equal(res[1][1], res[2][1])
+    # the default: one wavefront per aggregate and chirality, its sums by lane exchanges -- another order of the same sums
+    assert maxerr(res[0][0], res[1][0]) < 2e-5 and maxerr(res[0][1], res[1][1]) < 2e-5
+
+
 def test_whole_hierarchy_from_the_reference_interpolation_vectors():
     """both Galerkin constructions in a row from the reference's interpolation vectors of both levels (the level-1 operator is
     the library's own here, not the imported one)"""
