@@ -701,6 +701,93 @@ __global__ __launch_bounds__(256) void gs_aggregates_kernel(T* __restrict__ P, c
   }
 }
 
+// The same for 256-site aggregates (fp32) with ONE WAVEFRONT per aggregate and chirality: four sites of the chirality half per
+// lane, CB columns of a pass in registers, the sums of a projection by lane exchanges -- no barrier and no LDS on the chain of
+// dependent projections, and three columns per pass fit (192 of 256 registers), a third fewer reads of the earlier vectors than
+// two.  The sums run over the same products in another order than in the workgroup form: results agree to rounding.
+template <int CB>
+__global__ __launch_bounds__(256) void gs_aggregates_wave_kernel(float* __restrict__ P, const float* __restrict__ src, size_t sstride, int nvec, int V, int aps,
+                                                                 int ntasks) {
+  constexpr int AS = 256, SPL = AS / 64;
+  const int task = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (task >= ntasks) return;                       // whole wavefronts leave: no barrier below
+  const int a = task >> 1, h = task & 1;
+  const size_t s0 = (size_t)a * AS;
+  auto wave_sum = [](double x) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+  };
+  // <u, v> over the lane's sites: re, im
+  auto dot = [&](const float (&u)[SPL][12], const float (&v)[SPL][12], double& re, double& im) {
+    re = 0; im = 0;
+#pragma unroll
+    for (int q = 0; q < SPL; q++)
+#pragma unroll
+      for (int d = 0; d < 6; d++) {
+        re += (double)(u[q][2 * d] * v[q][2 * d] + u[q][2 * d + 1] * v[q][2 * d + 1]);
+        im += (double)(u[q][2 * d] * v[q][2 * d + 1] - u[q][2 * d + 1] * v[q][2 * d]);
+      }
+  };
+  auto project = [&](float (&v)[SPL][12], const float (&u)[SPL][12], double re, double im) {
+    const float ar = (float)wave_sum(re), ai = (float)wave_sum(im);
+#pragma unroll
+    for (int q = 0; q < SPL; q++)
+#pragma unroll
+      for (int d = 0; d < 6; d++) {
+        v[q][2 * d]     -= ar * u[q][2 * d] - ai * u[q][2 * d + 1];
+        v[q][2 * d + 1] -= ar * u[q][2 * d + 1] + ai * u[q][2 * d];
+      }
+  };
+  for (int k0 = 0; k0 < nvec; k0 += CB) {
+    float v[CB][SPL][12];
+#pragma unroll
+    for (int c = 0; c < CB; c++)
+#pragma unroll
+      for (int q = 0; q < SPL; q++) {
+        if (k0 + c < nvec) load_site<float, 12>(src + (size_t)(k0 + c) * sstride + (size_t)12 * h * V, V, s0 + lane + 64 * q, v[c][q]);   // the test vector
+        else {
+#pragma unroll
+          for (int k = 0; k < 12; k++) v[c][q][k] = 0.f;
+        }
+      }
+    for (int k2 = 0; k2 < k0; k2++) {
+      float u[SPL][12];
+#pragma unroll
+      for (int q = 0; q < SPL; q++) load_site<float, 12>(p_block(P, a, k2, nvec, aps) + (size_t)12 * h * aps, aps, lane + 64 * q, u[q]);
+      double re[CB], im[CB];
+#pragma unroll
+      for (int c = 0; c < CB; c++) dot(u, v[c], re[c], im[c]);
+#pragma unroll
+      for (int c = 0; c < CB; c++) project(v[c], u, re[c], im[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < CB; c++) {
+      if (k0 + c < nvec) {       // uniform
+#pragma unroll
+        for (int c2 = 0; c2 < c; c2++) {
+          double re, im;
+          dot(v[c2], v[c], re, im);
+          project(v[c], v[c2], re, im);
+        }
+        double nr = 0;
+#pragma unroll
+        for (int q = 0; q < SPL; q++)
+#pragma unroll
+          for (int d = 0; d < 12; d++) nr += (double)(v[c][q][d] * v[c][q][d]);
+        const float sc = (float)(1.0 / sqrt(wave_sum(nr)));
+#pragma unroll
+        for (int q = 0; q < SPL; q++) {
+#pragma unroll
+          for (int d = 0; d < 12; d++) v[c][q][d] *= sc;
+          store_site<float, 12>(p_block(P, a, k0 + c, nvec, aps) + (size_t)12 * h * aps, aps, lane + 64 * q, v[c][q]);
+        }
+      }
+    }
+    // (every lane reads back only what it has written itself: the earlier columns at its own four sites)
+  }
+}
+
 template <typename T>
 void Interpolation<T>::orthonormalize(hipStream_t st) {
   // (P <- tv is part of the kernel: a column is read from the test vectors in lattice order and written, orthonormalised, into
@@ -711,6 +798,14 @@ void Interpolation<T>::orthonormalize(hipStream_t st) {
   // two workgroups per CU; two columns reproduce the one-column results bit for bit, four do not: the compiler contracts
   // the products of the wider reduction differently)
   static const int columns = getenv("DDAMG_GS_COLUMNS") ? atoi(getenv("DDAMG_GS_COLUMNS")) : 2;
+  if constexpr (sizeof(T) == 4) {
+    const bool workgroup_form = getenv("DDAMG_GS_WORKGROUP") != nullptr || getenv("DDAMG_GS_COLUMNS") != nullptr;   // read at every call (tests)
+    if (agg_sites == 256 && !workgroup_form) {
+      hipLaunchKernelGGL(gs_aggregates_wave_kernel<3>, dim3((2 * num_aggs + 3) / 4), dim3(256), 0, st, P, tv, pstride, nvec, V, plane_sites(), 2 * num_aggs);
+      DDAMG_HIP_CHECK(hipGetLastError());
+      return;
+    }
+  }
   if (spt == 1 && columns == 1) hipLaunchKernelGGL((gs_aggregates_kernel<T, 1, 1>), dim3(num_aggs), dim3(nt), 0, st, P, tv, pstride, nvec, V, agg_sites, plane_sites());
   else if (spt == 1 && columns == 4 && sizeof(T) == 4) hipLaunchKernelGGL((gs_aggregates_kernel<T, 1, 4>), dim3(num_aggs), dim3(nt), 0, st, P, tv, pstride, nvec, V, agg_sites, plane_sites());
   else if (spt == 1) hipLaunchKernelGGL((gs_aggregates_kernel<T, 1, 2>), dim3(num_aggs), dim3(nt), 0, st, P, tv, pstride, nvec, V, agg_sites, plane_sites());

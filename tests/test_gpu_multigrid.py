@@ -461,6 +461,30 @@ def test_bootstrap_with_one_restriction_and_one_interpolation_for_all_test_vecto
     assert relerr(res[0][1], res[1][1]) < 1e-8
 
 
+def test_gram_schmidt_on_256_site_aggregates_one_wavefront_per_chirality(gold_b4, gold8, monkeypatch):
+    """gram_schmidt_on_aggregates (src/linalg_generic.c:400-480) on 4^4 aggregates: one wavefront per aggregate and chirality,
+    three columns per pass, sums by lane exchanges (default) against the workgroup form of rounds 1-3 (DDAMG_GS_WORKGROUP): the
+    same orthonormal columns up to the rounding of another summation order, P^H P = 1 either way, the same solve"""
+    res = []
+    for knob in (None, "1"):
+        if knob:
+            monkeypatch.setenv("DDAMG_GS_WORKGROUP", knob)
+        ctx = make_ctx_b4(gold_b4, gold8)
+        ctx.setup(3)
+        P = ctx.get_interpolation()
+        b = np.zeros((4096, 12, 2)); b[..., 0] = 1.0
+        x, it, cit, rr = ctx.solve(b, 1e-10)
+        res.append((P, x, it, rr))
+        ctx.close()
+    assert relerr(res[0][0], res[1][0]) < 2e-4 and not np.array_equal(res[0][0], res[1][0])   # two code paths did run
+    assert abs(res[0][2] - res[1][2]) <= 1 and res[0][3] < 1e-10 and res[1][3] < 1e-10
+    assert relerr(res[0][1], res[1][1]) < 1e-8
+    # orthonormal on every aggregate and chirality: 2 aggregates per direction, 256 sites each, chirality = first / second 6 dof
+    P = np.asarray(res[0][0]); Pc = (P[..., 0] + 1j * P[..., 1]).reshape(P.shape[0], 8, 8, 8, 8, 12)
+    blk = Pc[:, :4, :4, :4, :4, :6].reshape(P.shape[0], -1)
+    assert np.abs(blk.conj() @ blk.T - np.eye(P.shape[0])).max() < 5e-6
+
+
 def test_test_vector_gram_schmidt_by_panels(gold_b4, gold8, monkeypatch):
     """gram_schmidt_PRECISION on the test vectors (src/linalg_generic.c:483-528) by panels of four: the projections of a panel on
     all earlier vectors share their two passes over those (blas.hip vec_panel_project).  Against the column-by-column form
