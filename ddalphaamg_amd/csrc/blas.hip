@@ -370,10 +370,10 @@ __global__ __launch_bounds__(BLK) void panel_dot_kernel(const T* __restrict__ X,
 #pragma unroll
   for (int k = 0; k < 2 * DOT_TILE * CB; k++) acc[k] = 0;
   const size_t nchunks = v.total() / CH;
-  // fp32 vectors: the products of FLUSH consecutive chunks of a thread are summed in fp32 (16 terms per sum), then added to the
+  // fp32 vectors: the products of FLUSH consecutive chunks of a thread are summed in fp32 (32 terms per sum), then added to the
   // fp64 accumulator -- with 16 complex sums per thread the all-fp64 form of multi_dot_kernel is bound by the conversions and
-  // fp64 additions (15.8 ms per panel at 64^4 whether the products are fp64 or fp32; 7.5 ms in this form)
-  constexpr int FLUSH = CH == 4 ? 4 : 1;
+  // fp64 additions (15.8 ms per panel at 64^4 whether the products are fp64 or fp32; 6.4 ms in this form, 7.5 ms with four chunks)
+  constexpr int FLUSH = CH == 4 ? 8 : 1;
   float facc[2 * DOT_TILE * CB];
 #pragma unroll
   for (int k = 0; k < 2 * DOT_TILE * CB; k++) facc[k] = 0.f;
